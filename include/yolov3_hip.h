@@ -1,0 +1,169 @@
+/*
+ * yolov3_hip.h -- C ABI of libyolov3_hip.so: the MI355X (gfx950) YOLOv3 inference hot path.
+ *
+ * The reference (nrsyed/pytorch-yolov3) has no FFI layer: its hot path is the Python
+ * call chain Darknet.forward -> YOLOLayer.forward -> inference() tail -> non_max_suppression.
+ * Each entry point below replaces the arithmetic of one of those call sites; the Python
+ * package pytorch-yolov3_amd/yolov3 keeps the reference's signatures and binds these
+ * symbols with ctypes.  Citations are into /root/reference.
+ *
+ * Conventions
+ *   - plain C types only; every pointer named d_* is a DEVICE address (hipMalloc'd by the
+ *     caller, e.g. torch tensor .data_ptr()); the library never allocates or frees
+ *     caller-visible memory and never synchronises the device;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - every function returns 0 on success, a negative Y3_ERR_* code otherwise, and
+ *     y3_last_error() then returns a human-readable message (thread-local);
+ *   - activations are NHWC ("pixel-major"): element (b, y, x, c) of a tensor with pixel
+ *     stride ld lives at ((b*H + y)*W + x)*ld + c;  ld >= C, and ld*sizeof(elem) as well
+ *     as every channel-slice offset are multiples of 16 bytes on the MFMA path;
+ *   - one plan / one stream per GPU; entry points are not re-entrant per plan.
+ */
+#ifndef YOLOV3_HIP_H
+#define YOLOV3_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Y3_ABI_VERSION 1
+
+/* error codes */
+#define Y3_OK 0
+#define Y3_ERR_INVALID (-1)   /* bad argument / unsupported shape */
+#define Y3_ERR_HIP (-2)       /* a HIP runtime call failed        */
+#define Y3_ERR_NODEVICE (-3)  /* no gfx950 device visible         */
+
+/* element types of activations / weights */
+#define Y3_F32 0
+#define Y3_BF16 1
+
+/* op kinds of a plan (one per Darknet block that does work) */
+#define Y3_OP_CONV 1      /* conv -> (BN as per-channel scale/bias) -> LeakyReLU -> (+residual)  darknet.py:236-264, :376-379 */
+#define Y3_OP_MAXPOOL 2   /* darknet.py:16-29 (zero-pad right/bottom quirk when stride==1)        */
+#define Y3_OP_UPSAMPLE 3  /* nearest, integer factor: darknet.py:299-305                        */
+#define Y3_OP_ADD 4       /* unfused shortcut: darknet.py:376-379                               */
+#define Y3_OP_COPY 5      /* unfused route slice copy: darknet.py:369-375                       */
+#define Y3_OP_YOLO 6      /* YOLOLayer.forward + head concat + wh/net size: darknet.py:48-122, :389-399 */
+
+/* y3_op.flags */
+#define Y3_F_LEAKY 1u          /* LeakyReLU(0.1) after scale/bias                        */
+#define Y3_F_RESIDUAL 2u       /* add d_res (same dtype as output) after the activation  */
+#define Y3_F_OUT_F32 4u        /* store float32 regardless of dtype (detection-head convs) */
+#define Y3_F_IN_NCHW_F32 8u    /* conv input is the network input, float32 (B,C,H,W) in [0,1]  (inference.py:332-335) */
+#define Y3_F_IN_NHWC_U8BGR 16u /* conv input is uint8 (B,H,W,3) BGR frames; kernel applies BGR->RGB and /255.0 (inference.py:332-333) */
+#define Y3_F_PLAN_INPUT 32u    /* d_in is supplied at y3_plan_run time                  */
+
+/*
+ * One unit of work.  POD, 8-byte aligned, zero-initialise unused fields.
+ * Weight layouts (prepared on the host by yolov3/darknet.py:load_weights):
+ *   igemm path  : d_weight[co][ (ky*ks + kx)*Cin + ci ]  row stride k_ld elements (zero padded),
+ *                 rows padded with zeros up to a multiple of 128; dtype = op dtype
+ *   small-Cin   : (Cin <= 4) d_weight as float32 [ (ky*ks+kx)*Cin + ci ][ co ] with row stride = cout_pad
+ *   direct path : same as igemm layout
+ * d_scale/d_bias: float32 per output channel (BN folded to y = conv*scale + bias; scale=1 for
+ * convs with a bias and no BN), padded like the weight rows.
+ */
+typedef struct y3_op {
+  int32_t kind;
+  int32_t dtype;
+  uint32_t flags;
+  int32_t batch;
+  int32_t in_h, in_w, in_c, in_ld;
+  int32_t out_h, out_w, out_c, out_ld;
+  int32_t ksize, stride, pad;     /* conv / maxpool / upsample factor in `stride` */
+  int32_t res_ld;
+  int32_t k_ld;                   /* weight row stride (elements)                  */
+  int32_t cout_pad;               /* padded rows of weight / length of scale, bias */
+  const void *d_in;
+  void *d_out;
+  const void *d_res;
+  const void *d_weight;
+  const float *d_scale;
+  const float *d_bias;
+  /* Y3_OP_YOLO: d_in is the float32 head tensor (B,h,w,ld) with channel = anchor*n_attr + attr */
+  int32_t n_anchor, n_attr;
+  float anchor_w[8], anchor_h[8]; /* pixels, already selected by `mask` (darknet.py:44) */
+  int32_t row_offset, rows_total; /* this head's first row / total rows M of the concatenated output */
+  float net_w, net_h;             /* cfg [net] width/height (darknet.py:395-399)          */
+  float *d_bbox;                  /* (B, rows_total, 4) cx,cy in [0,1], w,h / net size     */
+  float *d_prob;                  /* (B, rows_total)                                       */
+  int64_t *d_cls;                 /* (B, rows_total)                                       */
+  int32_t block_idx;              /* Darknet block this op implements (diagnostics)        */
+  int32_t reserved;
+} y3_op;
+
+typedef struct y3_plan y3_plan;
+
+/* library / device ------------------------------------------------------------------- */
+int y3_abi_version(void);
+const char *y3_last_error(void);
+/* number of visible HIP devices whose arch is gfx950 (0 on a CPU-only machine) */
+int y3_device_count(void);
+
+/* plan executor: replaces the block loop of Darknet.forward (darknet.py:366-399) -------- */
+/* copies `ops` (host array); `d_zero` = >= 256 bytes of zeroed device memory that outlives the plan */
+int y3_plan_create(const y3_op *ops, int n_ops, const void *d_zero, y3_plan **out_plan);
+void y3_plan_destroy(y3_plan *plan);
+/* launches every op on `stream`; `d_input` feeds ops flagged Y3_F_PLAN_INPUT */
+int y3_plan_run(y3_plan *plan, const void *d_input, void *stream);
+/* same, bracketing every op with HIP events; after the call ms_per_op[i] holds op i's device
+ * time in milliseconds (synchronises the stream; for bench.py / profiling only)              */
+int y3_plan_run_timed(y3_plan *plan, const void *d_input, void *stream, float *ms_per_op);
+/* name of the kernel an op dispatches to, e.g. "conv_igemm_bf16_128x128" (static string)     */
+const char *y3_plan_op_kernel(const y3_plan *plan, int op_index);
+/* algorithmic FLOPs (2*k*k*Cin*Cout*Hout*Wout*B for convs, else 0) and compulsory bytes      */
+double y3_plan_op_flops(const y3_plan *plan, int op_index);
+double y3_plan_op_bytes(const y3_plan *plan, int op_index);
+
+/* kernel family a Y3_OP_CONV op dispatches to: 0 = MFMA implicit GEMM (weights [cout_pad][k_ld] in
+ * the op dtype), 1 = 3-channel stem (weights float32 [27][cout_pad]), 2 = direct fallback (same
+ * layout as 0); -1 if `op` is not a conv.  The host lays weights out accordingly.             */
+int y3_conv_path(const y3_op *op);
+
+/* single op (unit tests): same dispatch as inside a plan */
+int y3_op_run(const y3_op *op, const void *d_input, const void *d_zero, void *stream);
+
+/* detection tail: replaces inference.py:342-366 (threshold, scale, int cast, cxywh_to_tlbr,
+ * per-class non_max_suppression, gather) for a whole batch, on device ---------------------- */
+size_t y3_detect_workspace_bytes(int batch, int rows);
+/*
+ * d_bbox (batch,rows,4) f32, d_prob (batch,rows) f32, d_cls (batch,rows) i64: Darknet.forward outputs.
+ * d_orig_hw (batch,2) int32: original frame height,width (inference.py:351-352).
+ * Outputs, capacity `rows` per frame, detections ordered by (class asc, score desc, row desc):
+ *   d_det_count (batch) int32; d_det_tlbr (batch,rows,4) int64; d_det_prob (batch,rows) f32;
+ *   d_det_cls (batch,rows) int64; d_det_row (batch,rows) int32 = row index into the `rows` predictions.
+ */
+int y3_detect(const float *d_bbox, const float *d_prob, const int64_t *d_cls, int batch, int rows,
+              const int32_t *d_orig_hw, float prob_thresh, double iou_thresh, void *d_workspace,
+              size_t workspace_bytes, int32_t *d_det_count, int64_t *d_det_tlbr, float *d_det_prob,
+              int64_t *d_det_cls, int32_t *d_det_row, void *stream);
+
+/* non_max_suppression (inference.py:161-266) on caller-provided integer boxes -------------- */
+size_t y3_nms_workspace_bytes(int n);
+/*
+ * d_tlbr (n,4) int64, d_prob (n) f32, d_cls (n) int64 or NULL (class-agnostic).
+ * d_keep (n) int64 receives the kept indices ordered by (class asc, score desc, index desc);
+ * d_keep_count (1) int32.
+ */
+int y3_nms(const int64_t *d_tlbr, const float *d_prob, const int64_t *d_cls, int n, double iou_thresh,
+           void *d_workspace, size_t workspace_bytes, int64_t *d_keep, int32_t *d_keep_count,
+           void *stream);
+
+/* cxywh_to_tlbr (inference.py:269-283) on int64 rows of `cols` >= 4 columns ---------------- */
+int y3_cxywh_to_tlbr(const int64_t *d_xywh, int64_t *d_tlbr, int n, int cols, void *stream);
+
+/* padded fixed-size detection records for the multi-GPU all-gather (no reference counterpart:
+ * the reference is single device).  Record = 8 x int32: x1,y1,x2,y2, score bits, class, row, valid.
+ * d_records (batch, kmax, 8) int32, d_counts passthrough of min(count,kmax) in slot [b][0][7]... */
+int y3_pack_records(const int32_t *d_det_count, const int64_t *d_det_tlbr, const float *d_det_prob,
+                    const int64_t *d_det_cls, const int32_t *d_det_row, int batch, int rows, int kmax,
+                    int32_t *d_records, int32_t *d_rec_count, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLOV3_HIP_H */

@@ -1,0 +1,277 @@
+"""CPU ORACLE for the YOLOv3 hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A CPU restatement (torch-CPU fp32 ops + numpy) of the reference's
+``Darknet.forward`` -> YOLO decode -> threshold -> int/tlbr -> per-class NMS
+path.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module, and only as the checker / the
+timed CPU baseline; the product package (pytorch-yolov3_amd/yolov3) never
+imports it and raises when the HIP library is missing.
+
+PARITY PINNED: every function here is checked in ``tests/test_oracle_golden.py``
+(``-m "not gpu"``) against golden vectors produced by importing the real
+reference in the build container (tools/make_goldens.py -> tests/golden/*.npz),
+and against the reference's own known-answer vector for ``cxywh_to_tlbr``
+(/root/reference/tests/test_inference.py:12-23).
+
+The arithmetic of the reference lives in third-party libraries that are not
+vendored (torch: Conv2d/BatchNorm2d/LeakyReLU/max_pool2d/Upsample/softmax;
+numpy: argsort and int64/float64 array arithmetic; both unpinned in
+/root/reference/requirements.txt).  This restatement calls the same public
+torch/numpy primitives, op by op and in the reference's order, so it is the
+"-d cpu" path with the nn.Module plumbing removed.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_PKG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pytorch-yolov3_amd")
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+
+from yolov3.cfgparse import parse_config  # noqa: E402  host-side cfg reader (pinned by G2)
+from yolov3.weights import conv_layout, read_darknet_weights  # noqa: E402
+
+BN_EPS = 1e-5          # torch.nn.BatchNorm2d default, reference darknet.py:252
+LEAKY_SLOPE = 0.1      # reference darknet.py:256
+
+
+# --------------------------------------------------------------------------
+# per-op restatements
+# --------------------------------------------------------------------------
+
+def conv_block(x, p, stride, pad, leaky):
+    """conv -> [BN eval] -> [LeakyReLU 0.1]  (reference darknet.py:236-264, run :367-368).
+
+    x: (B,Cin,H,W) f32.  p: dict with ``weight`` and either BN tensors or
+    ``bias`` (numpy).  ``activation=linear`` means identity (darknet.py:258-261).
+    """
+    w = torch.from_numpy(np.ascontiguousarray(p["weight"]))
+    if "bn_gamma" in p:
+        y = F.conv2d(x, w, None, stride=stride, padding=pad)
+        y = F.batch_norm(
+            y, torch.from_numpy(p["bn_mean"].copy()), torch.from_numpy(p["bn_var"].copy()),
+            torch.from_numpy(p["bn_gamma"].copy()), torch.from_numpy(p["bn_beta"].copy()),
+            training=False, eps=BN_EPS)
+    else:
+        y = F.conv2d(x, w, torch.from_numpy(p["bias"].copy()), stride=stride, padding=pad)
+    if leaky:
+        y = F.leaky_relu(y, LEAKY_SLOPE)
+    return y
+
+
+def maxpool(x, size, stride):
+    """Reference MaxPool2d.forward (darknet.py:16-29).
+
+    size>1 and stride==1: ZERO-pad right/bottom by size-1, then pool with no
+    padding (windows extend down-right, out-of-bounds = 0.0, not -inf).
+    """
+    if size > 1 and stride == 1:
+        x = F.pad(x, (0, size - 1, 0, size - 1), mode="constant", value=0.0)
+    return F.max_pool2d(x, size, stride, 0)
+
+
+def upsample(x, factor):
+    """nn.Upsample(scale_factor, mode='nearest') (darknet.py:299-305)."""
+    return F.interpolate(x, scale_factor=factor, mode="nearest")
+
+
+def yolo_decode(x, anchors):
+    """YOLOLayer.forward (darknet.py:48-122) for one head.
+
+    x: (B, A*(5+C), h, w).  anchors: list of A (w, h) pixel pairs (already
+    selected by ``mask``).  Returns bbox_xywh (B,A*h*w,4) f32 with x,y in
+    grid-normalised units and w,h in PIXELS (the /net size happens in
+    ``forward``), class_prob (B,A*h*w) f32, class_idx (B,A*h*w) i64.
+    Row order a*h*w + y*w + x.
+    """
+    b, ch, h, w = x.shape
+    na = len(anchors)
+    nattr = ch // na
+    t = x.reshape(b, na, nattr, h, w)
+    gx = torch.arange(w, dtype=torch.float32).reshape(1, 1, 1, w)
+    gy = torch.arange(h, dtype=torch.float32).reshape(1, 1, h, 1)
+    aw = torch.tensor([a[0] for a in anchors], dtype=torch.float32).reshape(1, na, 1, 1)
+    ah = torch.tensor([a[1] for a in anchors], dtype=torch.float32).reshape(1, na, 1, 1)
+    bx = (torch.sigmoid(t[:, :, 0]) + gx) / w
+    by = (torch.sigmoid(t[:, :, 1]) + gy) / h
+    bw = torch.exp(t[:, :, 2]) * aw
+    bh = torch.exp(t[:, :, 3]) * ah
+    obj = torch.sigmoid(t[:, :, 4])
+    cls = torch.softmax(t[:, :, 5:], dim=2)
+    best, idx = torch.max(cls, dim=2)
+    prob = best * obj
+    bbox = torch.stack((bx, by, bw, bh), dim=-1).reshape(b, na * h * w, 4)
+    return bbox, prob.reshape(b, -1), idx.reshape(b, -1)
+
+
+# --------------------------------------------------------------------------
+# whole-network forward
+# --------------------------------------------------------------------------
+
+class OracleDarknet:
+    """Functional restatement of reference ``Darknet`` (darknet.py:318-476)."""
+
+    def __init__(self, config_fpath):
+        self.blocks, self.net_info = parse_config(config_fpath)
+        # negative route indices -> absolute (darknet.py:338-343)
+        for i, blk in enumerate(self.blocks):
+            if blk["type"] == "route":
+                blk["layers"] = [j if j >= 0 else i + j for j in blk["layers"]]
+        _, convs = conv_layout(self.blocks, self.net_info)
+        self._conv_slot = {c["block_idx"]: n for n, c in enumerate(convs)}
+        self.params = None
+        self.header = None
+
+    def load_weights(self, path):
+        self.header, self.params = read_darknet_weights(path, self.blocks, self.net_info)
+        return self
+
+    def set_params(self, params):
+        self.params = params
+        return self
+
+    def forward(self, x, collect=None):
+        """x: torch (B,3,H,W) f32.  Returns dict like the reference (darknet.py:401-405).
+
+        ``collect``: optional dict filled with {block_idx: tensor} of every
+        block output (used by per-layer parity tests).
+        """
+        outs = []
+        heads = []
+        with torch.no_grad():
+            for i, blk in enumerate(self.blocks):
+                kind = blk["type"]
+                if kind == "convolutional":
+                    k = blk["size"]
+                    pad = (k - 1) // 2 if "pad" in blk else 0      # darknet.py:240
+                    x = conv_block(x, self.params[self._conv_slot[i]], blk["stride"], pad,
+                                   blk["activation"] == "leaky")
+                elif kind == "maxpool":
+                    x = maxpool(x, blk["size"], blk["stride"])
+                elif kind == "upsample":
+                    x = upsample(x, blk["stride"])
+                elif kind == "route":
+                    x = torch.cat([outs[j] for j in blk["layers"]], dim=1)   # darknet.py:372-375
+                elif kind == "shortcut":
+                    x = outs[i - 1] + outs[i + blk["from"]]                  # darknet.py:379
+                elif kind == "yolo":
+                    anchors = [blk["anchors"][m] for m in blk["mask"]]       # darknet.py:44
+                    heads.append(yolo_decode(x, anchors))
+                outs.append(x)
+                if collect is not None:
+                    collect[i] = x
+            bbox = torch.cat([h[0] for h in heads], dim=1)
+            prob = torch.cat([h[1] for h in heads], dim=1)
+            idx = torch.cat([h[2] for h in heads], dim=1)
+            # w,h divided by the CFG's net size, whatever the input size (darknet.py:395-399)
+            bbox[:, :, 2] = bbox[:, :, 2] / self.net_info["width"]
+            bbox[:, :, 3] = bbox[:, :, 3] / self.net_info["height"]
+        return {"bbox_xywh": bbox, "class_prob": prob, "class_idx": idx}
+
+
+# --------------------------------------------------------------------------
+# post-processing (numpy)
+# --------------------------------------------------------------------------
+
+def frames_to_input(frames):
+    """uint8 BGR HxWx3 frames -> (B,3,H,W) f32 RGB/255 (reference inference.py:332-333)."""
+    arr = np.stack(frames)[:, :, :, ::-1]
+    return np.ascontiguousarray(np.transpose(arr, (0, 3, 1, 2))).astype(np.float32) / 255.0
+
+
+def cxywh_to_tlbr(box):
+    """Integer centre/size -> corners, floor-halving (reference inference.py:269-283)."""
+    out = np.array(box, copy=True)
+    half = box[:, 2:4] // 2
+    out[:, 0:2] = box[:, 0:2] - half
+    out[:, 2:4] = box[:, 0:2] + half
+    return out
+
+
+def nms_single(tlbr, prob, iou_thresh=0.3):
+    """Greedy NMS over one set of boxes (reference inference.py:161-217).
+
+    +1 pixel widths, IoU in float64 (int64 / int64 true division), suppress
+    iff iou > thresh (strict).  Visit order: ``np.argsort(prob)[::-1]``.
+    Returns indices in pick order (numpy int64 scalars like the reference).
+    """
+    tlbr = np.asarray(tlbr)
+    n = tlbr.shape[0]
+    if n == 0:
+        return []
+    x1, y1, x2, y2 = tlbr[:, 0], tlbr[:, 1], tlbr[:, 2], tlbr[:, 3]
+    area = (x2 - x1 + 1) * (y2 - y1 + 1)
+    order = np.argsort(prob)[::-1]
+    alive = np.ones(n, dtype=bool)
+    keep = []
+    for pos in range(n):
+        i = order[pos]
+        if not alive[i]:
+            continue
+        keep.append(i)
+        rest = order[pos + 1:]
+        rest = rest[alive[rest]]
+        if rest.size == 0:
+            continue
+        iw = np.maximum(0, np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]) + 1)
+        ih = np.maximum(0, np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]) + 1)
+        inter = iw * ih
+        iou = inter / (area[i] + area[rest] - inter)
+        alive[rest[iou > iou_thresh]] = False
+    return keep
+
+
+def non_max_suppression(tlbr, class_prob, class_idx=None, iou_thresh=0.3):
+    """Per-class (or class-agnostic) NMS (reference inference.py:220-266)."""
+    if class_idx is None:
+        return nms_single(tlbr, class_prob, iou_thresh)
+    keep = []
+    for cls in set(class_idx):                      # same iteration order as the reference
+        members = np.where(class_idx == cls)[0]
+        sub = nms_single(tlbr[members], class_prob[members], iou_thresh)
+        keep.extend(members[sub].tolist())
+    return keep
+
+
+def postprocess(bbox_xywh, class_prob, class_idx, orig_shapes, prob_thresh=0.05,
+                nms_iou_thresh=0.3):
+    """Tail of reference ``inference()`` (inference.py:338-366) on numpy arrays.
+
+    orig_shapes: per-frame (H, W[, C]).  Returns per frame
+    [tlbr int64 (K,4), prob f32 (K,), cls int64 (K,)].
+    """
+    results = []
+    mask = class_prob >= prob_thresh
+    for i in range(bbox_xywh.shape[0]):
+        box = bbox_xywh[i, mask[i], :].copy()
+        prob = class_prob[i, mask[i]]
+        cls = class_idx[i, mask[i]]
+        box[:, [0, 2]] *= orig_shapes[i][1]
+        box[:, [1, 3]] *= orig_shapes[i][0]
+        with np.errstate(invalid="ignore"):
+            tlbr = cxywh_to_tlbr(box.astype(np.int64))
+        keep = non_max_suppression(tlbr, prob, class_idx=cls, iou_thresh=nms_iou_thresh)
+        results.append([tlbr[keep, :], prob[keep], cls[keep]])
+    return results
+
+
+def inference(net, frames, prob_thresh=0.05, nms_iou_thresh=0.3):
+    """Net-sized uint8 BGR frames -> detections, like reference ``inference()``."""
+    if not isinstance(frames, list):
+        frames = [frames]
+    out = net.forward(torch.from_numpy(frames_to_input(frames)))
+    return postprocess(out["bbox_xywh"].numpy(), out["class_prob"].numpy(),
+                       out["class_idx"].numpy(), [f.shape for f in frames],
+                       prob_thresh, nms_iou_thresh)
+
+
+def canonical_rows(det):
+    """Sort one frame's [tlbr, prob, cls] by (cls, -prob, box) for set-style comparison."""
+    tlbr, prob, cls = det
+    if len(prob) == 0:
+        return tlbr, prob, cls
+    key = np.lexsort((tlbr[:, 3], tlbr[:, 2], tlbr[:, 1], tlbr[:, 0], -prob.astype(np.float64), cls))
+    return tlbr[key], prob[key], cls[key]

@@ -1,0 +1,195 @@
+// C-ABI glue: error string, device query, op dispatch and the plan executor that replaces the
+// block loop of Darknet.forward (/root/reference/yolov3/darknet.py:366-399).
+#include <stdarg.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+static_assert(sizeof(y3_op) == 240, "y3_op layout is part of the ABI (ctypes mirror in yolov3/_hip.py)");
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+void y3_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct y3_plan {
+  std::vector<y3_op> ops;
+  std::vector<const char *> kernel;
+  const void *d_zero;
+  std::vector<hipEvent_t> events;
+};
+
+namespace {
+
+// 0 = MFMA implicit GEMM, 1 = 3-channel stem kernel, 2 = direct fallback
+int conv_path(const y3_op &op) {
+  const bool net_input = op.flags & (Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR);
+  if (net_input && op.in_c == 3 && op.ksize == 3 && !(op.flags & Y3_F_RESIDUAL)) return 1;
+  if (!net_input && y3_conv_igemm_supported(op)) return 0;
+  return 2;
+}
+
+int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream_t s, const char **name,
+             bool dry_run) {
+  const void *in = (op.flags & Y3_F_PLAN_INPUT) ? d_input : op.d_in;
+  if (!dry_run) {
+    Y3_REQUIRE(in != nullptr, "op for block %d has no input pointer", op.block_idx);
+    Y3_REQUIRE(op.d_out != nullptr || op.kind == Y3_OP_YOLO, "op for block %d has no output pointer", op.block_idx);
+  }
+  Y3_REQUIRE(op.dtype == Y3_F32 || op.dtype == Y3_BF16, "op for block %d: unknown dtype %d", op.block_idx, op.dtype);
+  Y3_REQUIRE(op.batch > 0 && op.in_h > 0 && op.in_w > 0 && op.in_c > 0, "op for block %d: empty input shape", op.block_idx);
+  switch (op.kind) {
+    case Y3_OP_CONV: {
+      Y3_REQUIRE(op.out_h == (op.in_h + 2 * op.pad - op.ksize) / op.stride + 1 &&
+                     op.out_w == (op.in_w + 2 * op.pad - op.ksize) / op.stride + 1,
+                 "conv block %d: output size mismatch", op.block_idx);
+      if (!dry_run)
+        Y3_REQUIRE(op.d_weight && op.d_scale && op.d_bias, "conv block %d: missing parameters", op.block_idx);
+      switch (conv_path(op)) {
+        case 0: return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run);
+        case 1: return y3_launch_conv_small(op, in, s, name, dry_run);
+        default: return y3_launch_conv_direct(op, in, s, name, dry_run);
+      }
+    }
+    case Y3_OP_MAXPOOL: return y3_launch_maxpool(op, in, s, name, dry_run);
+    case Y3_OP_UPSAMPLE: return y3_launch_upsample(op, in, s, name, dry_run);
+    case Y3_OP_ADD: return y3_launch_add(op, in, s, name, dry_run);
+    case Y3_OP_COPY: return y3_launch_copy(op, in, s, name, dry_run);
+    case Y3_OP_YOLO: return y3_launch_yolo(op, in, s, name, dry_run);
+    default: break;
+  }
+  y3_set_error("op for block %d: unknown kind %d", op.block_idx, op.kind);
+  return Y3_ERR_INVALID;
+}
+
+}  // namespace
+
+extern "C" {
+
+int y3_abi_version(void) { return Y3_ABI_VERSION; }
+
+const char *y3_last_error(void) { return g_err; }
+
+int y3_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, i) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+  }
+  return ok;
+}
+
+// which kernel family a conv op will use: 0 igemm, 1 stem, 2 direct (the host side lays the
+// weights out accordingly before creating the plan)
+int y3_conv_path(const y3_op *op) {
+  if (!op || op->kind != Y3_OP_CONV) return -1;
+  return conv_path(*op);
+}
+
+int y3_plan_create(const y3_op *ops, int n_ops, const void *d_zero, y3_plan **out_plan) {
+  Y3_REQUIRE(ops && n_ops > 0 && out_plan, "y3_plan_create: bad arguments");
+  Y3_REQUIRE(d_zero, "y3_plan_create: d_zero (zeroed device page) is required");
+  y3_plan *p = new (std::nothrow) y3_plan;
+  Y3_REQUIRE(p, "y3_plan_create: out of host memory");
+  p->ops.assign(ops, ops + n_ops);
+  p->kernel.assign(n_ops, "");
+  p->d_zero = d_zero;
+  for (int i = 0; i < n_ops; ++i) {
+    const int rc = dispatch(p->ops[i], nullptr, d_zero, nullptr, &p->kernel[i], true);
+    if (rc != Y3_OK) {
+      delete p;
+      return rc;
+    }
+  }
+  *out_plan = p;
+  return Y3_OK;
+}
+
+void y3_plan_destroy(y3_plan *plan) {
+  if (!plan) return;
+  for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
+  delete plan;
+}
+
+int y3_plan_run(y3_plan *plan, const void *d_input, void *stream) {
+  Y3_REQUIRE(plan, "y3_plan_run: null plan");
+  const char *name = nullptr;
+  for (size_t i = 0; i < plan->ops.size(); ++i) {
+    const int rc = dispatch(plan->ops[i], d_input, plan->d_zero, static_cast<hipStream_t>(stream), &name, false);
+    if (rc != Y3_OK) return rc;
+  }
+  return Y3_OK;
+}
+
+int y3_plan_run_timed(y3_plan *plan, const void *d_input, void *stream, float *ms_per_op) {
+  Y3_REQUIRE(plan && ms_per_op, "y3_plan_run_timed: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t n = plan->ops.size();
+  while (plan->events.size() < n + 1) {
+    hipEvent_t e;
+    Y3_HIP_CHECK(hipEventCreate(&e));
+    plan->events.push_back(e);
+  }
+  const char *name = nullptr;
+  Y3_HIP_CHECK(hipEventRecord(plan->events[0], s));
+  for (size_t i = 0; i < n; ++i) {
+    const int rc = dispatch(plan->ops[i], d_input, plan->d_zero, s, &name, false);
+    if (rc != Y3_OK) return rc;
+    Y3_HIP_CHECK(hipEventRecord(plan->events[i + 1], s));
+  }
+  Y3_HIP_CHECK(hipEventSynchronize(plan->events[n]));
+  for (size_t i = 0; i < n; ++i) Y3_HIP_CHECK(hipEventElapsedTime(&ms_per_op[i], plan->events[i], plan->events[i + 1]));
+  return Y3_OK;
+}
+
+const char *y3_plan_op_kernel(const y3_plan *plan, int op_index) {
+  if (!plan || op_index < 0 || (size_t)op_index >= plan->ops.size()) return "";
+  return plan->kernel[op_index];
+}
+
+double y3_plan_op_flops(const y3_plan *plan, int op_index) {
+  if (!plan || op_index < 0 || (size_t)op_index >= plan->ops.size()) return 0.0;
+  const y3_op &o = plan->ops[op_index];
+  if (o.kind != Y3_OP_CONV) return 0.0;
+  return 2.0 * o.ksize * o.ksize * o.in_c * (double)o.out_c * o.out_h * o.out_w * o.batch;
+}
+
+double y3_plan_op_bytes(const y3_plan *plan, int op_index) {
+  if (!plan || op_index < 0 || (size_t)op_index >= plan->ops.size()) return 0.0;
+  const y3_op &o = plan->ops[op_index];
+  const double es = y3_elem_size(o.dtype);
+  const double in_px = (double)o.batch * o.in_h * o.in_w, out_px = (double)o.batch * o.out_h * o.out_w;
+  switch (o.kind) {
+    case Y3_OP_CONV: {
+      double in_es = es;
+      if (o.flags & Y3_F_IN_NCHW_F32) in_es = 4;
+      if (o.flags & Y3_F_IN_NHWC_U8BGR) in_es = 1;
+      const double out_es = (o.flags & Y3_F_OUT_F32) ? 4 : es;
+      double b = in_px * o.in_c * in_es + out_px * o.out_c * out_es + (double)o.ksize * o.ksize * o.in_c * o.out_c * es;
+      if (o.flags & Y3_F_RESIDUAL) b += out_px * o.out_c * es;
+      return b;
+    }
+    case Y3_OP_ADD: return 3.0 * out_px * o.out_c * es;
+    case Y3_OP_YOLO: return in_px * o.n_anchor * (o.n_attr * 4.0 + 28.0);
+    default: return (in_px * o.in_c + out_px * o.out_c) * es;
+  }
+}
+
+int y3_op_run(const y3_op *op, const void *d_input, const void *d_zero, void *stream) {
+  Y3_REQUIRE(op, "y3_op_run: null op");
+  const char *name = nullptr;
+  return dispatch(*op, d_input, d_zero, static_cast<hipStream_t>(stream), &name, false);
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// Shared device/host helpers for libyolov3_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "yolov3_hip.h"
+
+typedef __bf16 bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define Y3_WAVE 64
+#define Y3_LEAKY_SLOPE 0.1f
+
+// thread-local error string shared by all translation units
+void y3_set_error(const char *fmt, ...);
+
+#define Y3_HIP_CHECK(expr)                                                               \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      y3_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return Y3_ERR_HIP;                                                                 \
+    }                                                                                    \
+  } while (0)
+
+#define Y3_REQUIRE(cond, ...)     \
+  do {                            \
+    if (!(cond)) {                \
+      y3_set_error(__VA_ARGS__);  \
+      return Y3_ERR_INVALID;      \
+    }                             \
+  } while (0)
+
+static inline int y3_elem_size(int dtype) { return dtype == Y3_BF16 ? 2 : 4; }
+static inline int y3_ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2); give each
+// XCD one contiguous run of logical tile ids so that neighbouring tiles (which share an input
+// halo / weight panel) hit the same L2.  Bijective for any grid size.  Placement only affects
+// speed, never results.
+__device__ __forceinline__ int y3_xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+template <typename T>
+__device__ __forceinline__ float y3_to_float(T v);
+template <>
+__device__ __forceinline__ float y3_to_float<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float y3_to_float<bf16_t>(bf16_t v) { return (float)v; }
+
+template <typename T>
+__device__ __forceinline__ T y3_from_float(float v);
+template <>
+__device__ __forceinline__ float y3_from_float<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16_t y3_from_float<bf16_t>(float v) { return (bf16_t)v; }
+
+// launchers implemented in the .hip files; each fills *kernel_name with a static string
+int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
+                         const char **kernel_name, bool dry_run);
+int y3_launch_conv_small(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
+                         bool dry_run);
+int y3_launch_conv_direct(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
+                          bool dry_run);
+int y3_launch_maxpool(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
+                      bool dry_run);
+int y3_launch_upsample(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
+                       bool dry_run);
+int y3_launch_add(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
+                  bool dry_run);
+int y3_launch_copy(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
+                   bool dry_run);
+int y3_launch_yolo(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
+                   bool dry_run);
+// true when the MFMA implicit-GEMM kernel can take this conv
+bool y3_conv_igemm_supported(const y3_op &op);

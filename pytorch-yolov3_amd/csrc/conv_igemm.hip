@@ -1,0 +1,332 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): conv -> per-channel scale/bias (folded BN or
+// conv bias) -> LeakyReLU(0.1) -> optional residual add, NHWC activations.
+//
+// Replaces the reference's Conv2d + BatchNorm2d(eval) + LeakyReLU nn.Sequential
+// (/root/reference/yolov3/darknet.py:244-257, run at :367-368) and the shortcut add that
+// follows a conv (:376-379).
+//
+// GEMM view:  D[co][m] = sum_k  Wt[co][k] * A[m][k]
+//   m  = (b, oy, ox) output pixel,  k = (ky, kx, ci)  -- ci fastest, so for one filter tap the
+//   K-slice of a pixel is a contiguous run of input channels (NHWC), 128 B per K-tile row;
+//   Wt = weights stored [Cout][ks*ks*Cin] (K contiguous), the MFMA "A" operand;
+//   A  = im2col rows gathered on the fly (never materialised), the MFMA "B" operand, so each
+//        lane ends up with 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
+//
+// Tile: BM pixels x BN channels x 128 bytes of K per step, 256 threads = 4 waves,
+// v_mfma_f32_16x16x32_bf16 (bf16) or v_mfma_f32_16x16x4_f32 (exact fp32 parity path).
+// LDS image per operand: [rows][128 B], 16-byte chunks XOR-swizzled by (row & 7) so that the
+// ds_read_b128 fragment reads (16 rows x one chunk column per lane group) are conflict-free.
+// Padding taps and M-tail rows read a zero page instead of branching.
+#include "common.h"
+
+namespace {
+
+struct IgemmArgs {
+  const char *in;
+  const char *wgt;
+  const float *scale;
+  const float *bias;
+  const char *res;
+  char *out;
+  const char *zero;
+  int H, W, Cin, in_ld;
+  int Ho, Wo, Cout, out_ld, res_ld;
+  int ks, stride, pad;
+  int M, HoWo;
+  int k_ld, K;
+  int n_ktiles, ktiles_per_tap;
+  int m_tiles, n_tiles;
+  uint32_t flags;
+};
+
+template <typename T>
+struct Mma;
+
+template <>
+struct Mma<bf16_t> {
+  // one 128-byte K-tile = 64 bf16 = 2 MFMA k-steps of 32; a lane's 16-byte chunk = 8 k values
+  static __device__ __forceinline__ void run(f32x4 &acc, const u32x4 &w, const u32x4 &x) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w),
+                                                  __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+  }
+};
+
+template <>
+struct Mma<float> {
+  // one 128-byte K-tile = 32 floats = 2 groups of 16; lane (r, q) holds floats 4q..4q+3 of the
+  // group for row r.  MFMA j consumes element j of every lane: it sums k in {j, 4+j, 8+j, 12+j};
+  // the same permutation is applied to both operands, so the four MFMAs cover the group.
+  static __device__ __forceinline__ void run(f32x4 &acc, const u32x4 &w, const u32x4 &x) {
+    const f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j], xf[j], acc, 0, 0, 0);
+  }
+};
+
+template <typename TO>
+__device__ __forceinline__ void store4(char *dst, const float v[4], int nvalid) {
+  TO *p = reinterpret_cast<TO *>(dst);
+  if (nvalid >= 4) {
+    if constexpr (sizeof(TO) == 4) {
+      f32x4 o = {v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4 *>(dst) = o;
+    } else {
+      bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      *reinterpret_cast<bf16x4 *>(dst) = o;
+    }
+  } else {
+    for (int r = 0; r < nvalid; ++r) p[r] = y3_from_float<TO>(v[r]);
+  }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool GENERIC_K>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
+  constexpr int ES = sizeof(T);
+  constexpr int CE = 16 / ES;    // elements per 16-byte chunk
+  constexpr int BKE = 128 / ES;  // elements per K-tile
+  constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
+  constexpr int MI = TM / 16, NI = TN / 16;
+  constexpr int A_CH = BM / 32, B_CH = BN / 32;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(MI >= 1 && NI >= 1 && A_CH >= 1 && B_CH >= 1, "tile too small");
+
+  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * 128];
+  char *sA = smem;             // pixels  [BM][128 B]
+  char *sB = smem + BM * 128;  // weights [BN][128 B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / p.n_tiles) * BM;
+  const int n0 = (tile % p.n_tiles) * BN;
+
+  // ---- loader set-up: thread owns LDS chunk slot (tid&7) of rows (tid>>3) + 32*i ------------
+  const int slot = tid & 7;
+  const int row0 = tid >> 3;
+  const int kc = slot ^ (row0 & 7);  // logical chunk held at this LDS position (source-side swizzle)
+
+  const char *a_base[A_CH];
+  uint32_t a_taps[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int m = m0 + row0 + 32 * i;
+    a_base[i] = p.zero;
+    a_taps[i] = 0u;
+    if (m < p.M) {
+      const int b = m / p.HoWo;
+      const int rem = m - b * p.HoWo;
+      const int oy = rem / p.Wo;
+      const int ox = rem - oy * p.Wo;
+      const int iy0 = oy * p.stride - p.pad;
+      const int ix0 = ox * p.stride - p.pad;
+      const long long pix = ((long long)b * p.H + iy0) * p.W + ix0;
+      a_base[i] = p.in + pix * p.in_ld * ES + (GENERIC_K ? 0 : kc * 16);
+      uint32_t mask = 0u;
+      for (int ky = 0; ky < p.ks; ++ky)
+        for (int kx = 0; kx < p.ks; ++kx) {
+          const bool ok = (unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W;
+          mask |= (ok ? 1u : 0u) << (ky * p.ks + kx);
+        }
+      a_taps[i] = mask;
+    }
+  }
+  const char *b_base[B_CH];
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i)
+    b_base[i] = p.wgt + ((long long)(n0 + row0 + 32 * i) * p.k_ld) * ES + kc * 16;
+
+  u32x4 a_reg[A_CH], b_reg[B_CH];
+
+  auto fetch = [&](int kt) {
+    if constexpr (!GENERIC_K) {
+      // whole K-tile lies inside one filter tap: tap and channel offset are wave-uniform
+      const int tap = kt / p.ktiles_per_tap;
+      const int ci0 = (kt - tap * p.ktiles_per_tap) * BKE;
+      const int ky = tap / p.ks, kx = tap - ky * p.ks;
+      const long long tap_off = ((long long)(ky * p.W + kx) * p.in_ld + ci0) * ES;
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const char *src = ((a_taps[i] >> tap) & 1u) ? a_base[i] + tap_off : p.zero;
+        a_reg[i] = *reinterpret_cast<const u32x4 *>(src);
+      }
+    } else {
+      // per-chunk tap: Cin is only a multiple of the chunk width
+      const int ke = kt * BKE + kc * CE;
+      const int tap = ke / p.Cin;
+      const int ci = ke - tap * p.Cin;
+      const int ky = tap / p.ks, kx = tap - ky * p.ks;
+      const long long tap_off = ((long long)(ky * p.W + kx) * p.in_ld + ci) * ES;
+      const bool in_k = ke < p.K;
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const bool ok = in_k && ((a_taps[i] >> tap) & 1u);
+        const char *src = ok ? a_base[i] + tap_off : p.zero;
+        a_reg[i] = *reinterpret_cast<const u32x4 *>(src);
+      }
+    }
+    const long long koff = (long long)kt * 128;
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) b_reg[i] = *reinterpret_cast<const u32x4 *>(b_base[i] + koff);
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read addresses: lane (r = lane&15, q = lane>>4) reads chunk (g*4 + q) of row r
+  const int fr = lane & 15, fq = lane >> 4;
+
+  fetch(0);
+  for (int kt = 0; kt < p.n_ktiles; ++kt) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4 *>(sA + tid * 16 + i * 4096) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4 *>(sB + tid * 16 + i * 4096) = b_reg[i];
+    __syncthreads();
+    if (kt + 1 < p.n_ktiles) fetch(kt + 1);  // next tile's global loads fly during the MFMAs
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      u32x4 xf[MI], wf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * TM + mi * 16 + fr;
+        xf[mi] = *reinterpret_cast<const u32x4 *>(sA + row * 128 + (((g * 4 + fq) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int row = wn * TN + ni * 16 + fr;
+        wf[ni] = *reinterpret_cast<const u32x4 *>(sB + row * 128 + (((g * 4 + fq) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], wf[ni], xf[mi]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds channels co..co+3 (registers) of pixel m (lane&15) -------------
+  const bool leaky = p.flags & Y3_F_LEAKY;
+  const bool has_res = p.flags & Y3_F_RESIDUAL;
+  const bool out_f32 = (p.flags & Y3_F_OUT_F32) || sizeof(T) == 4;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int co = n0 + wn * TN + ni * 16 + fq * 4;
+    const int nvalid = p.Cout - co;  // may be <= 0 for padded channels
+    if (nvalid <= 0) continue;
+    const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + co);
+    const f32x4 bi = *reinterpret_cast<const f32x4 *>(p.bias + co);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wm * TM + mi * 16 + fr;
+      if (m >= p.M) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = acc[mi][ni][r] * sc[r] + bi[r];
+        if (leaky) t = t > 0.f ? t : Y3_LEAKY_SLOPE * t;
+        v[r] = t;
+      }
+      if (has_res) {
+        const T *rp = reinterpret_cast<const T *>(p.res) + (long long)m * p.res_ld + co;
+        if (nvalid >= 4) {
+          if constexpr (sizeof(T) == 4) {
+            const f32x4 rv = *reinterpret_cast<const f32x4 *>(rp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+          } else {
+            const bf16x4 rv = *reinterpret_cast<const bf16x4 *>(rp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+          }
+        } else {
+          for (int r = 0; r < nvalid; ++r) v[r] += y3_to_float<T>(rp[r]);
+        }
+      }
+      if (out_f32)
+        store4<float>(p.out + ((long long)m * p.out_ld + co) * 4, v, nvalid);
+      else
+        store4<T>(p.out + ((long long)m * p.out_ld + co) * ES, v, nvalid);
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_cfg(const IgemmArgs &a0, bool generic, hipStream_t s) {
+  IgemmArgs a = a0;
+  a.m_tiles = y3_ceil_div(a.M, BM);
+  a.n_tiles = y3_ceil_div(a.Cout, BN);
+  const dim3 grid(a.m_tiles * a.n_tiles), block(256);
+  if (generic)
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, true>), grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, false>), grid, block, 0, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+}  // namespace
+
+bool y3_conv_igemm_supported(const y3_op &op) {
+  const int es = y3_elem_size(op.dtype);
+  const int ce = 16 / es;
+  if (op.flags & (Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR)) return false;
+  if (op.ksize < 1 || op.ksize > 5) return false;
+  if (op.in_c % ce != 0 || op.in_ld % ce != 0) return false;
+  if (op.out_ld % 4 != 0) return false;
+  if ((op.flags & Y3_F_RESIDUAL) && op.res_ld % 4 != 0) return false;
+  if (op.cout_pad % 128 != 0 || op.cout_pad < op.out_c) return false;
+  const int bke = 128 / es;
+  if (op.k_ld % bke != 0 || op.k_ld < op.ksize * op.ksize * op.in_c) return false;
+  return true;
+}
+
+int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
+                         const char **kernel_name, bool dry_run) {
+  Y3_REQUIRE(y3_conv_igemm_supported(op), "conv block %d: shape not supported by the igemm kernel",
+             op.block_idx);
+  const int es = y3_elem_size(op.dtype);
+  const int bke = 128 / es;
+  IgemmArgs a;
+  a.in = static_cast<const char *>(d_in);
+  a.wgt = static_cast<const char *>(op.d_weight);
+  a.scale = op.d_scale;
+  a.bias = op.d_bias;
+  a.res = static_cast<const char *>(op.d_res);
+  a.out = static_cast<char *>(op.d_out);
+  a.zero = static_cast<const char *>(d_zero);
+  a.H = op.in_h; a.W = op.in_w; a.Cin = op.in_c; a.in_ld = op.in_ld;
+  a.Ho = op.out_h; a.Wo = op.out_w; a.Cout = op.out_c; a.out_ld = op.out_ld; a.res_ld = op.res_ld;
+  a.ks = op.ksize; a.stride = op.stride; a.pad = op.pad;
+  a.HoWo = op.out_h * op.out_w;
+  a.M = op.batch * a.HoWo;
+  a.k_ld = op.k_ld;
+  a.K = op.ksize * op.ksize * op.in_c;
+  const bool generic = (op.in_c % bke) != 0;
+  a.ktiles_per_tap = generic ? 0 : op.in_c / bke;
+  a.n_ktiles = generic ? y3_ceil_div(a.K, bke) : op.ksize * op.ksize * a.ktiles_per_tap;
+  a.m_tiles = a.n_tiles = 0;
+  a.flags = op.flags;
+
+  const bool bf = op.dtype == Y3_BF16;
+  // channel-tile width follows Cout so narrow layers do not multiply zero padding
+  int bn = op.out_c > 64 ? 128 : (op.out_c > 32 ? 64 : 32);
+  if (bn == 128) {
+    *kernel_name = bf ? "conv_igemm_bf16_128x128" : "conv_igemm_f32_128x128";
+    if (dry_run) return Y3_OK;
+    return bf ? launch_cfg<bf16_t, 128, 128, 2, 2>(a, generic, s) : launch_cfg<float, 128, 128, 2, 2>(a, generic, s);
+  } else if (bn == 64) {
+    *kernel_name = bf ? "conv_igemm_bf16_128x64" : "conv_igemm_f32_128x64";
+    if (dry_run) return Y3_OK;
+    return bf ? launch_cfg<bf16_t, 128, 64, 2, 2>(a, generic, s) : launch_cfg<float, 128, 64, 2, 2>(a, generic, s);
+  }
+  *kernel_name = bf ? "conv_igemm_bf16_128x32" : "conv_igemm_f32_128x32";
+  if (dry_run) return Y3_OK;
+  return bf ? launch_cfg<bf16_t, 128, 32, 4, 1>(a, generic, s) : launch_cfg<float, 128, 32, 4, 1>(a, generic, s);
+}

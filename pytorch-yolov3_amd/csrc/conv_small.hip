@@ -1,0 +1,212 @@
+// Convolutions that do not fit the MFMA implicit-GEMM kernel.
+//
+//  * conv_stem3x3: the network's first layer (Cin = 3, 3x3).  Reads the network input directly
+//    -- float32 NCHW in [0,1] (what Darknet.forward receives, /root/reference/yolov3/darknet.py:351)
+//    or uint8 NHWC BGR frames with the reference's BGR->RGB flip and /255.0 fused in
+//    (/root/reference/yolov3/inference.py:332-333) -- and writes NHWC activations, so no
+//    layout-conversion pass exists anywhere.  One thread per output pixel, 27 inputs in
+//    registers, weights broadcast from LDS, 8 output channels per register block.
+//  * conv_direct: any other shape (odd channel counts, big kernels).  One thread per output
+//    element; correctness fallback, not a fast path.
+// Both apply the same epilogue as the igemm kernel: *scale + bias, LeakyReLU(0.1), +residual.
+#include "common.h"
+
+namespace {
+
+struct SmallArgs {
+  const void *in;
+  const float *wgt;  // [27][cout_pad] float32
+  const float *scale;
+  const float *bias;
+  char *out;
+  int B, H, W, Ho, Wo, Cout, cout_pad, out_ld, stride, pad, M;
+  uint32_t flags;
+};
+
+template <int MODE>
+__device__ __forceinline__ float load_input(const void *in, int b, int c, int y, int x, int H, int W) {
+  if constexpr (MODE == 0) {  // float32 NCHW
+    return static_cast<const float *>(in)[(((long long)b * 3 + c) * H + y) * W + x];
+  } else {  // uint8 NHWC, BGR in memory; channel c of the RGB tensor is byte 2-c
+    const uint8_t v = static_cast<const uint8_t *>(in)[(((long long)b * H + y) * W + x) * 3 + (2 - c)];
+    return (float)v / 255.0f;
+  }
+}
+
+template <typename TO, int MODE>
+__global__ __launch_bounds__(256) void conv_stem3x3_kernel(SmallArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [27][cout_pad]
+  const int nw = 27 * p.cout_pad;
+  for (int i = threadIdx.x; i < nw; i += 256) sw[i] = p.wgt[i];
+  __syncthreads();
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= p.M) return;
+  const int hw = p.Ho * p.Wo;
+  const int b = m / hw;
+  const int rem = m - b * hw;
+  const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+  const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+  float x[27];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = iy0 + ky, ix = ix0 + kx;
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        x[(ky * 3 + kx) * 3 + c] = ok ? load_input<MODE>(p.in, b, c, iy, ix, p.H, p.W) : 0.f;
+    }
+  const bool leaky = p.flags & Y3_F_LEAKY;
+  TO *orow = reinterpret_cast<TO *>(p.out) + (long long)m * p.out_ld;
+  for (int co = 0; co < p.Cout; co += 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4 *>(sw + k * p.cout_pad + co);
+      const f32x4 w1 = *reinterpret_cast<const f32x4 *>(sw + k * p.cout_pad + co + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] += x[k] * w0[j];
+        acc[4 + j] += x[k] * w1[j];
+      }
+    }
+    const int nvalid = p.Cout - co < 8 ? p.Cout - co : 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = acc[j] * p.scale[co + j] + p.bias[co + j];
+      if (leaky) t = t > 0.f ? t : Y3_LEAKY_SLOPE * t;
+      v[j] = t;
+    }
+    if (nvalid == 8 && (p.out_ld % 8) == 0) {
+      if constexpr (sizeof(TO) == 2) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+        *reinterpret_cast<bf16x8 *>(orow + co) = o;
+      } else {
+        *reinterpret_cast<f32x4 *>(orow + co) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4 *>(orow + co + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      }
+    } else {
+      for (int j = 0; j < nvalid; ++j) orow[co + j] = y3_from_float<TO>(v[j]);
+    }
+  }
+}
+
+struct DirectArgs {
+  const void *in;
+  const void *wgt;  // [cout_pad][k_ld] element type T
+  const float *scale;
+  const float *bias;
+  const void *res;
+  void *out;
+  int B, H, W, Cin, in_ld, Ho, Wo, Cout, out_ld, res_ld, ks, stride, pad, k_ld;
+  long long total;
+  uint32_t flags;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_direct_kernel(DirectArgs p) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.total) return;
+  const int co = (int)(idx % p.Cout);
+  const long long m = idx / p.Cout;
+  const int hw = p.Ho * p.Wo;
+  const int b = (int)(m / hw);
+  const int rem = (int)(m - (long long)b * hw);
+  const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+  const T *w = static_cast<const T *>(p.wgt) + (long long)co * p.k_ld;
+  float acc = 0.f;
+  for (int ky = 0; ky < p.ks; ++ky) {
+    const int iy = oy * p.stride - p.pad + ky;
+    if ((unsigned)iy >= (unsigned)p.H) continue;
+    for (int kx = 0; kx < p.ks; ++kx) {
+      const int ix = ox * p.stride - p.pad + kx;
+      if ((unsigned)ix >= (unsigned)p.W) continue;
+      const T *wk = w + (ky * p.ks + kx) * p.Cin;
+      if (p.flags & Y3_F_IN_NCHW_F32) {
+        for (int c = 0; c < p.Cin; ++c)
+          acc += static_cast<const float *>(p.in)[(((long long)b * p.Cin + c) * p.H + iy) * p.W + ix] *
+                 y3_to_float<T>(wk[c]);
+      } else if (p.flags & Y3_F_IN_NHWC_U8BGR) {
+        for (int c = 0; c < p.Cin; ++c) {
+          const uint8_t u = static_cast<const uint8_t *>(p.in)[(((long long)b * p.H + iy) * p.W + ix) * p.Cin + (p.Cin - 1 - c)];
+          acc += ((float)u / 255.0f) * y3_to_float<T>(wk[c]);
+        }
+      } else {
+        const T *xp = static_cast<const T *>(p.in) + (((long long)b * p.H + iy) * p.W + ix) * p.in_ld;
+        for (int c = 0; c < p.Cin; ++c) acc += y3_to_float<T>(xp[c]) * y3_to_float<T>(wk[c]);
+      }
+    }
+  }
+  float v = acc * p.scale[co] + p.bias[co];
+  if (p.flags & Y3_F_LEAKY) v = v > 0.f ? v : Y3_LEAKY_SLOPE * v;
+  if (p.flags & Y3_F_RESIDUAL) v += y3_to_float<T>(static_cast<const T *>(p.res)[m * p.res_ld + co]);
+  if ((p.flags & Y3_F_OUT_F32) || sizeof(T) == 4)
+    static_cast<float *>(p.out)[m * p.out_ld + co] = v;
+  else
+    static_cast<T *>(p.out)[m * p.out_ld + co] = y3_from_float<T>(v);
+}
+
+}  // namespace
+
+int y3_launch_conv_small(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
+                         bool dry_run) {
+  Y3_REQUIRE(op.in_c == 3 && op.ksize == 3, "conv block %d: stem kernel needs Cin=3, 3x3", op.block_idx);
+  Y3_REQUIRE(op.flags & (Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR),
+             "conv block %d: stem kernel reads the network input only", op.block_idx);
+  Y3_REQUIRE(op.cout_pad % 8 == 0 && op.cout_pad >= op.out_c && op.cout_pad <= 256,
+             "conv block %d: bad cout_pad %d", op.block_idx, op.cout_pad);
+  Y3_REQUIRE(!(op.flags & Y3_F_RESIDUAL), "conv block %d: stem kernel has no residual input", op.block_idx);
+  SmallArgs a;
+  a.in = d_in;
+  a.wgt = static_cast<const float *>(op.d_weight);
+  a.scale = op.d_scale;
+  a.bias = op.d_bias;
+  a.out = static_cast<char *>(op.d_out);
+  a.B = op.batch; a.H = op.in_h; a.W = op.in_w; a.Ho = op.out_h; a.Wo = op.out_w;
+  a.Cout = op.out_c; a.cout_pad = op.cout_pad; a.out_ld = op.out_ld;
+  a.stride = op.stride; a.pad = op.pad;
+  a.M = op.batch * op.out_h * op.out_w;
+  a.flags = op.flags;
+  const bool u8 = op.flags & Y3_F_IN_NHWC_U8BGR;
+  const bool out_bf16 = op.dtype == Y3_BF16 && !(op.flags & Y3_F_OUT_F32);
+  *kernel_name = u8 ? (out_bf16 ? "conv_stem3x3_u8_bf16" : "conv_stem3x3_u8_f32")
+                    : (out_bf16 ? "conv_stem3x3_nchw_bf16" : "conv_stem3x3_nchw_f32");
+  if (dry_run) return Y3_OK;
+  const dim3 grid(y3_ceil_div(a.M, 256)), block(256);
+  const size_t lds = (size_t)27 * op.cout_pad * sizeof(float);
+  if (u8) {
+    if (out_bf16) hipLaunchKernelGGL((conv_stem3x3_kernel<bf16_t, 1>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((conv_stem3x3_kernel<float, 1>), grid, block, lds, s, a);
+  } else {
+    if (out_bf16) hipLaunchKernelGGL((conv_stem3x3_kernel<bf16_t, 0>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((conv_stem3x3_kernel<float, 0>), grid, block, lds, s, a);
+  }
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+int y3_launch_conv_direct(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
+                          bool dry_run) {
+  DirectArgs a;
+  a.in = d_in; a.wgt = op.d_weight; a.scale = op.d_scale; a.bias = op.d_bias; a.res = op.d_res;
+  a.out = op.d_out;
+  a.B = op.batch; a.H = op.in_h; a.W = op.in_w; a.Cin = op.in_c; a.in_ld = op.in_ld;
+  a.Ho = op.out_h; a.Wo = op.out_w; a.Cout = op.out_c; a.out_ld = op.out_ld; a.res_ld = op.res_ld;
+  a.ks = op.ksize; a.stride = op.stride; a.pad = op.pad; a.k_ld = op.k_ld;
+  a.total = (long long)op.batch * op.out_h * op.out_w * op.out_c;
+  a.flags = op.flags;
+  Y3_REQUIRE(op.k_ld >= op.ksize * op.ksize * op.in_c, "conv block %d: k_ld too small", op.block_idx);
+  *kernel_name = op.dtype == Y3_BF16 ? "conv_direct_bf16" : "conv_direct_f32";
+  if (dry_run) return Y3_OK;
+  const dim3 grid((unsigned)((a.total + 255) / 256)), block(256);
+  if (op.dtype == Y3_BF16) hipLaunchKernelGGL(conv_direct_kernel<bf16_t>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(conv_direct_kernel<float>, grid, block, 0, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}

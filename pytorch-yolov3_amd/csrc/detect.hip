@@ -1,0 +1,471 @@
+// Detection tail on device: score threshold + compaction, pixel scaling, integer truncation,
+// centre/size -> corners, per-class greedy NMS, ordered gather.  One 1024-thread workgroup per
+// frame runs all phases back to back in ONE launch (16 wavefronts; phases separated by
+// workgroup barriers), so a batch costs a single kernel and only kept detections ever leave
+// the GPU.
+//
+// Replaces /root/reference/yolov3/inference.py:342-366 (mask = prob >= thr; x,w *= orig_w;
+// y,h *= orig_h; astype(int); cxywh_to_tlbr :269-283; non_max_suppression :220-266 with
+// _non_max_suppression :161-217).  Semantics kept bit-for-bit:
+//   * threshold compare and pixel scaling in float32, truncation toward zero to int64,
+//     corners = centre -/+ (size // 2) in integers;
+//   * areas / intersections with the "+1" pixel convention in int64, IoU = inter / union in
+//     float64, suppress iff IoU > thr (strict), candidates visited in descending score;
+//   * classes are independent.
+// Output order is canonical: class ascending, score descending, then higher row first (the
+// reference's order is Python-set / argsort dependent; tests compare as sets).
+//
+// Wavefront primitives: __ballot + popcount prefix sums for the ordered compactions; the NMS
+// inner loop keeps one box per lane (64 boxes per wavefront chunk), broadcasts the current
+// survivor with ds_bpermute shuffles and clears victims with a ballot mask.
+// Built with -ffp-contract=off.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
+constexpr int kLdsSort = 4096;  // elements sorted in LDS; larger frames sort in global memory
+
+struct DetectArgs {
+  // forward-output mode
+  const float *bbox;
+  const float *prob;
+  const long long *cls;
+  const int *orig_hw;
+  // caller-boxes mode (y3_nms)
+  const long long *in_tlbr;
+  const float *in_prob;
+  const long long *in_cls;
+  int n_in;
+  int rows;      // predictions per frame / capacity
+  int rows_p2;   // next power of two >= rows
+  float prob_thresh;
+  double iou_thresh;
+  // workspace, per frame
+  long long *c_box;             // [rows][4]
+  float *c_prob;                // [rows]
+  int *c_cls;                   // [rows]
+  int *c_row;                   // [rows]
+  unsigned long long *s_key;    // [rows_p2]
+  unsigned int *s_pos;          // [rows_p2]
+  unsigned char *keep;          // [rows]
+  int *seg;                     // [rows]
+  // outputs
+  int *det_count;
+  long long *det_tlbr;
+  float *det_prob;
+  long long *det_cls;
+  int *det_row;
+  long long *keep_idx;
+};
+
+__device__ __forceinline__ unsigned int score_desc_bits(float p) {
+  unsigned int u = __float_as_uint(p);
+  u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;  // ascending-sortable
+  return ~u;                                   // descending
+}
+
+// (key asc, pos desc)
+__device__ __forceinline__ bool elem_less(unsigned long long ka, unsigned int pa, unsigned long long kb,
+                                          unsigned int pb) {
+  return ka < kb || (ka == kb && pa > pb);
+}
+
+__device__ __forceinline__ long long shfl_ll(long long v, int src) {
+  int lo = (int)(v & 0xFFFFFFFFll), hi = (int)(v >> 32);
+  lo = __shfl(lo, src, 64);
+  hi = __shfl(hi, src, 64);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// block-wide ordered compaction step: returns this thread's output slot (valid when flag) and
+// adds the step's total to `running`.  Must be called by all threads.
+__device__ __forceinline__ int ordered_slot(bool flag, int &running, int *wave_tot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long ballot = __ballot(flag);
+  const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_tot[wave] = __popcll(ballot);
+  __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) {
+    const int t = wave_tot[w];
+    before += w < wave ? t : 0;
+    total += t;
+  }
+  const int slot = running + before + prefix;
+  running += total;
+  __syncthreads();
+  return slot;
+}
+
+template <bool NMS_MODE>
+__global__ __launch_bounds__(kThreads) void detect_kernel(DetectArgs p) {
+  __shared__ unsigned long long skey[kLdsSort];
+  __shared__ unsigned int spos[kLdsSort];
+  __shared__ int wave_tot[kWaves];
+  __shared__ int nseg_sh;
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long R = p.rows;
+
+  const long long *c_box = NMS_MODE ? p.in_tlbr : p.c_box + (long long)b * R * 4;
+  const float *c_prob = NMS_MODE ? p.in_prob : p.c_prob + (long long)b * R;
+  unsigned long long *s_key = p.s_key + (long long)b * p.rows_p2;
+  unsigned int *s_pos = p.s_pos + (long long)b * p.rows_p2;
+  unsigned char *keep = p.keep + (long long)b * R;
+  int *seg = p.seg + (long long)b * R;
+
+  // ---- phase 1: threshold + ordered compaction + scale / truncate / corners -----------------
+  int n = 0;
+  if constexpr (!NMS_MODE) {
+    long long *w_box = p.c_box + (long long)b * R * 4;
+    float *w_prob = p.c_prob + (long long)b * R;
+    int *w_cls = p.c_cls + (long long)b * R;
+    int *w_row = p.c_row + (long long)b * R;
+    const float oh = (float)p.orig_hw[b * 2 + 0], ow = (float)p.orig_hw[b * 2 + 1];
+    for (int base = 0; base < p.rows; base += kThreads) {
+      const int r = base + tid;
+      float pr = 0.f;
+      bool flag = false;
+      if (r < p.rows) {
+        pr = p.prob[(long long)b * R + r];
+        flag = pr >= p.prob_thresh;  // float32 compare (inference.py:342)
+      }
+      const int slot = ordered_slot(flag, n, wave_tot);
+      if (flag) {
+        const f32x4 bb = *reinterpret_cast<const f32x4 *>(p.bbox + ((long long)b * R + r) * 4);
+        // float32 products, then truncation toward zero (inference.py:351-353)
+        const long long cx = (long long)(bb[0] * ow), cy = (long long)(bb[1] * oh);
+        const long long bw = (long long)(bb[2] * ow), bh = (long long)(bb[3] * oh);
+        const long long hw = bw >> 1, hh = bh >> 1;  // floor division by 2 (inference.py:281-282)
+        long long *o = w_box + (long long)slot * 4;
+        o[0] = cx - hw; o[1] = cy - hh; o[2] = cx + hw; o[3] = cy + hh;
+        w_prob[slot] = pr;
+        w_cls[slot] = (int)p.cls[(long long)b * R + r];
+        w_row[slot] = r;
+      }
+    }
+    __syncthreads();
+  } else {
+    n = p.n_in;
+  }
+  if (n == 0) {
+    if (tid == 0) p.det_count[b] = 0;
+    return;
+  }
+
+  // ---- phase 2: sort by (class asc, score desc, position desc) ------------------------------
+  int P = 2;
+  while (P < n) P <<= 1;
+  const bool lds_sort = P <= kLdsSort;
+  auto make_key = [&](int i) -> unsigned long long {
+    int c;
+    if constexpr (NMS_MODE) c = p.in_cls ? (int)p.in_cls[i] : 0;
+    else c = p.c_cls[(long long)b * R + i];
+    const unsigned int cu = (unsigned int)c ^ 0x80000000u;  // signed order
+    return ((unsigned long long)cu << 32) | score_desc_bits(c_prob[i]);
+  };
+  if (lds_sort) {
+    for (int i = tid; i < P; i += kThreads) {
+      skey[i] = i < n ? make_key(i) : ~0ull;
+      spos[i] = i < n ? (unsigned int)i : 0u;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < P; i += kThreads) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const unsigned long long ka = skey[i], kb = skey[ixj];
+            const unsigned int pa = spos[i], pb = spos[ixj];
+            const bool up = (i & k) == 0;
+            const bool sw = up ? elem_less(kb, pb, ka, pa) : elem_less(ka, pa, kb, pb);
+            if (sw) {
+              skey[i] = kb; skey[ixj] = ka;
+              spos[i] = pb; spos[ixj] = pa;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    for (int i = tid; i < n; i += kThreads) {
+      s_key[i] = skey[i];
+      s_pos[i] = spos[i];
+    }
+  } else {
+    for (int i = tid; i < P; i += kThreads) {
+      s_key[i] = i < n ? make_key(i) : ~0ull;
+      s_pos[i] = i < n ? (unsigned int)i : 0u;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < P; i += kThreads) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const unsigned long long ka = s_key[i], kb = s_key[ixj];
+            const unsigned int pa = s_pos[i], pb = s_pos[ixj];
+            const bool up = (i & k) == 0;
+            const bool sw = up ? elem_less(kb, pb, ka, pa) : elem_less(ka, pa, kb, pb);
+            if (sw) {
+              s_key[i] = kb; s_key[ixj] = ka;
+              s_pos[i] = pb; s_pos[ixj] = pa;
+            }
+          }
+        }
+        __syncthreads();
+      }
+  }
+  if (tid == 0) nseg_sh = 0;
+  __syncthreads();
+
+  // ---- phase 3: class segments ---------------------------------------------------------------
+  for (int i = tid; i < n; i += kThreads) {
+    const unsigned int c = (unsigned int)(s_key[i] >> 32);
+    if (i == 0 || (unsigned int)(s_key[i - 1] >> 32) != c) seg[atomicAdd(&nseg_sh, 1)] = i;
+  }
+  __syncthreads();
+  const int nseg = nseg_sh;
+
+  // ---- phase 4: greedy NMS, one wavefront per class segment ----------------------------------
+  for (int s = wave; s < nseg; s += kWaves) {
+    const int start = seg[s];
+    const unsigned int c = (unsigned int)(s_key[start] >> 32);
+    int lo = start + 1, hi = n;  // first index in (start, n] whose class differs
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((unsigned int)(s_key[mid] >> 32) == c) lo = mid + 1; else hi = mid;
+    }
+    const int end = lo;
+    for (int c0 = start; c0 < end; c0 += 64) {
+      const int idx = c0 + lane;
+      const bool valid = idx < end;
+      long long x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+      if (valid) {
+        const long long *bp = c_box + (long long)s_pos[idx] * 4;
+        x1 = bp[0]; y1 = bp[1]; x2 = bp[2]; y2 = bp[3];
+      }
+      const long long area = (x2 - x1 + 1) * (y2 - y1 + 1);
+      bool dead = !valid;
+      // survivors of earlier chunks of this class
+      for (int p0 = start; p0 < c0; p0 += 64) {
+        unsigned long long kept = __ballot(keep[p0 + lane] != 0);
+        if (kept == 0ull) continue;
+        const long long *qp = c_box + (long long)s_pos[p0 + lane] * 4;
+        const long long qx1 = qp[0], qy1 = qp[1], qx2 = qp[2], qy2 = qp[3];
+        while (kept) {
+          const int k = __ffsll((long long)kept) - 1;
+          kept &= kept - 1ull;
+          const long long ax1 = shfl_ll(qx1, k), ay1 = shfl_ll(qy1, k);
+          const long long ax2 = shfl_ll(qx2, k), ay2 = shfl_ll(qy2, k);
+          const long long aarea = (ax2 - ax1 + 1) * (ay2 - ay1 + 1);
+          long long iw = (ax2 < x2 ? ax2 : x2) - (ax1 > x1 ? ax1 : x1) + 1;
+          long long ih = (ay2 < y2 ? ay2 : y2) - (ay1 > y1 ? ay1 : y1) + 1;
+          iw = iw > 0 ? iw : 0;
+          ih = ih > 0 ? ih : 0;
+          const long long inter = iw * ih;
+          const double iou = (double)inter / (double)(aarea + area - inter);
+          dead = dead || (iou > p.iou_thresh);
+        }
+      }
+      // greedy inside the chunk, in score order (lane order)
+      unsigned long long alive = __ballot(!dead);
+      for (int k = 0; k < 64; ++k) {
+        if (!((alive >> k) & 1ull)) continue;  // wave-uniform
+        const long long ax1 = shfl_ll(x1, k), ay1 = shfl_ll(y1, k);
+        const long long ax2 = shfl_ll(x2, k), ay2 = shfl_ll(y2, k);
+        const long long aarea = (ax2 - ax1 + 1) * (ay2 - ay1 + 1);
+        long long iw = (ax2 < x2 ? ax2 : x2) - (ax1 > x1 ? ax1 : x1) + 1;
+        long long ih = (ay2 < y2 ? ay2 : y2) - (ay1 > y1 ? ay1 : y1) + 1;
+        iw = iw > 0 ? iw : 0;
+        ih = ih > 0 ? ih : 0;
+        const long long inter = iw * ih;
+        const double iou = (double)inter / (double)(aarea + area - inter);
+        const bool hit = lane > k && (iou > p.iou_thresh);
+        alive &= ~__ballot(hit);
+      }
+      if (valid) keep[idx] = (alive >> lane) & 1ull ? 1 : 0;
+      __threadfence_block();  // later chunks of this wavefront read these flags
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 5: ordered gather of survivors ---------------------------------------------------
+  int kept_n = 0;
+  for (int base = 0; base < n; base += kThreads) {
+    const int i = base + tid;
+    const bool flag = i < n && keep[i] != 0;
+    const int slot = ordered_slot(flag, kept_n, wave_tot);
+    if (flag) {
+      const unsigned int pos = s_pos[i];
+      if constexpr (NMS_MODE) {
+        p.keep_idx[slot] = (long long)pos;
+      } else {
+        const long long *bp = c_box + (long long)pos * 4;
+        long long *o = p.det_tlbr + ((long long)b * R + slot) * 4;
+        o[0] = bp[0]; o[1] = bp[1]; o[2] = bp[2]; o[3] = bp[3];
+        p.det_prob[(long long)b * R + slot] = c_prob[pos];
+        p.det_cls[(long long)b * R + slot] = (long long)p.c_cls[(long long)b * R + pos];
+        p.det_row[(long long)b * R + slot] = p.c_row[(long long)b * R + pos];
+      }
+    }
+  }
+  if (tid == 0) p.det_count[b] = kept_n;
+}
+
+__global__ void cxywh_to_tlbr_kernel(const long long *in, long long *out, int n, int cols) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long *r = in + (long long)i * cols;
+  long long *o = out + (long long)i * cols;
+  const long long cx = r[0], cy = r[1], hw = r[2] >> 1, hh = r[3] >> 1;  // floor(w/2), floor(h/2)
+  o[0] = cx - hw; o[1] = cy - hh; o[2] = cx + hw; o[3] = cy + hh;
+  for (int c = 4; c < cols; ++c) o[c] = r[c];
+}
+
+// record = 8 x int32: x1 y1 x2 y2 | score bits | class | row | 1
+__global__ void pack_records_kernel(const int *cnt, const long long *tlbr, const float *prob,
+                                    const long long *cls, const int *row, int rows, int kmax,
+                                    int *rec, int *rec_count) {
+  const int b = blockIdx.x;
+  const int n = cnt[b] < kmax ? cnt[b] : kmax;
+  if (threadIdx.x == 0) rec_count[b] = cnt[b];
+  for (int k = threadIdx.x; k < kmax; k += blockDim.x) {
+    int *o = rec + ((long long)b * kmax + k) * 8;
+    if (k < n) {
+      const long long *t = tlbr + ((long long)b * rows + k) * 4;
+      o[0] = (int)t[0]; o[1] = (int)t[1]; o[2] = (int)t[2]; o[3] = (int)t[3];
+      o[4] = __float_as_int(prob[(long long)b * rows + k]);
+      o[5] = (int)cls[(long long)b * rows + k];
+      o[6] = row[(long long)b * rows + k];
+      o[7] = 1;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = 0;
+    }
+  }
+}
+
+int next_pow2(int v) {
+  int p = 2;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct WsLayout {
+  size_t box, prob, cls, row, key, pos, keep, seg, total;
+};
+
+WsLayout ws_layout(int batch, int rows) {
+  WsLayout w;
+  const size_t B = (size_t)batch, R = (size_t)rows, P = (size_t)next_pow2(rows);
+  size_t off = 0;
+  w.box = off; off = align_up(off + B * R * 4 * sizeof(long long));
+  w.prob = off; off = align_up(off + B * R * sizeof(float));
+  w.cls = off; off = align_up(off + B * R * sizeof(int));
+  w.row = off; off = align_up(off + B * R * sizeof(int));
+  w.key = off; off = align_up(off + B * P * sizeof(unsigned long long));
+  w.pos = off; off = align_up(off + B * P * sizeof(unsigned int));
+  w.keep = off; off = align_up(off + B * R);
+  w.seg = off; off = align_up(off + B * R * sizeof(int));
+  w.total = off;
+  return w;
+}
+
+}  // namespace
+
+extern "C" size_t y3_detect_workspace_bytes(int batch, int rows) {
+  if (batch <= 0 || rows <= 0) return 0;
+  return ws_layout(batch, rows).total;
+}
+
+extern "C" size_t y3_nms_workspace_bytes(int n) {
+  if (n <= 0) return 256;
+  return ws_layout(1, n).total;
+}
+
+extern "C" int y3_detect(const float *d_bbox, const float *d_prob, const int64_t *d_cls, int batch, int rows,
+                         const int32_t *d_orig_hw, float prob_thresh, double iou_thresh, void *d_workspace,
+                         size_t workspace_bytes, int32_t *d_det_count, int64_t *d_det_tlbr, float *d_det_prob,
+                         int64_t *d_det_cls, int32_t *d_det_row, void *stream) {
+  Y3_REQUIRE(batch > 0 && rows > 0, "y3_detect: batch and rows must be positive");
+  Y3_REQUIRE(d_bbox && d_prob && d_cls && d_orig_hw && d_workspace && d_det_count && d_det_tlbr && d_det_prob &&
+                 d_det_cls && d_det_row, "y3_detect: null pointer argument");
+  const WsLayout w = ws_layout(batch, rows);
+  Y3_REQUIRE(workspace_bytes >= w.total, "y3_detect: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+  char *ws = static_cast<char *>(d_workspace);
+  DetectArgs a = {};
+  a.bbox = d_bbox; a.prob = d_prob; a.cls = reinterpret_cast<const long long *>(d_cls); a.orig_hw = d_orig_hw;
+  a.rows = rows; a.rows_p2 = next_pow2(rows);
+  a.prob_thresh = prob_thresh; a.iou_thresh = iou_thresh;
+  a.c_box = reinterpret_cast<long long *>(ws + w.box);
+  a.c_prob = reinterpret_cast<float *>(ws + w.prob);
+  a.c_cls = reinterpret_cast<int *>(ws + w.cls);
+  a.c_row = reinterpret_cast<int *>(ws + w.row);
+  a.s_key = reinterpret_cast<unsigned long long *>(ws + w.key);
+  a.s_pos = reinterpret_cast<unsigned int *>(ws + w.pos);
+  a.keep = reinterpret_cast<unsigned char *>(ws + w.keep);
+  a.seg = reinterpret_cast<int *>(ws + w.seg);
+  a.det_count = d_det_count; a.det_tlbr = reinterpret_cast<long long *>(d_det_tlbr); a.det_prob = d_det_prob;
+  a.det_cls = reinterpret_cast<long long *>(d_det_cls); a.det_row = d_det_row;
+  hipLaunchKernelGGL(detect_kernel<false>, dim3(batch), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+extern "C" int y3_nms(const int64_t *d_tlbr, const float *d_prob, const int64_t *d_cls, int n, double iou_thresh,
+                      void *d_workspace, size_t workspace_bytes, int64_t *d_keep, int32_t *d_keep_count,
+                      void *stream) {
+  Y3_REQUIRE(n >= 0, "y3_nms: negative n");
+  Y3_REQUIRE(d_keep_count, "y3_nms: null d_keep_count");
+  if (n == 0) {
+    Y3_HIP_CHECK(hipMemsetAsync(d_keep_count, 0, sizeof(int32_t), static_cast<hipStream_t>(stream)));
+    return Y3_OK;
+  }
+  Y3_REQUIRE(d_tlbr && d_prob && d_workspace && d_keep, "y3_nms: null pointer argument");
+  const WsLayout w = ws_layout(1, n);
+  Y3_REQUIRE(workspace_bytes >= w.total, "y3_nms: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+  char *ws = static_cast<char *>(d_workspace);
+  DetectArgs a = {};
+  a.in_tlbr = reinterpret_cast<const long long *>(d_tlbr); a.in_prob = d_prob;
+  a.in_cls = reinterpret_cast<const long long *>(d_cls); a.n_in = n;
+  a.rows = n; a.rows_p2 = next_pow2(n);
+  a.iou_thresh = iou_thresh;
+  a.s_key = reinterpret_cast<unsigned long long *>(ws + w.key);
+  a.s_pos = reinterpret_cast<unsigned int *>(ws + w.pos);
+  a.keep = reinterpret_cast<unsigned char *>(ws + w.keep);
+  a.seg = reinterpret_cast<int *>(ws + w.seg);
+  a.det_count = d_keep_count;
+  a.keep_idx = reinterpret_cast<long long *>(d_keep);
+  hipLaunchKernelGGL(detect_kernel<true>, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+extern "C" int y3_cxywh_to_tlbr(const int64_t *d_xywh, int64_t *d_tlbr, int n, int cols, void *stream) {
+  Y3_REQUIRE(n >= 0 && cols >= 4, "y3_cxywh_to_tlbr: need n >= 0 and at least 4 columns");
+  if (n == 0) return Y3_OK;
+  Y3_REQUIRE(d_xywh && d_tlbr, "y3_cxywh_to_tlbr: null pointer argument");
+  hipLaunchKernelGGL(cxywh_to_tlbr_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const long long *>(d_xywh), reinterpret_cast<long long *>(d_tlbr), n, cols);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+extern "C" int y3_pack_records(const int32_t *d_det_count, const int64_t *d_det_tlbr, const float *d_det_prob,
+                               const int64_t *d_det_cls, const int32_t *d_det_row, int batch, int rows, int kmax,
+                               int32_t *d_records, int32_t *d_rec_count, void *stream) {
+  Y3_REQUIRE(batch > 0 && rows > 0 && kmax > 0, "y3_pack_records: sizes must be positive");
+  Y3_REQUIRE(d_det_count && d_det_tlbr && d_det_prob && d_det_cls && d_det_row && d_records && d_rec_count,
+             "y3_pack_records: null pointer argument");
+  hipLaunchKernelGGL(pack_records_kernel, dim3(batch), dim3(256), 0, static_cast<hipStream_t>(stream), d_det_count,
+                     reinterpret_cast<const long long *>(d_det_tlbr), d_det_prob,
+                     reinterpret_cast<const long long *>(d_det_cls), d_det_row, rows, kmax, d_records, d_rec_count);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}

@@ -1,0 +1,213 @@
+// Memory-bound NHWC layer kernels: max-pool, nearest upsample, add, channel-slice copy.
+// One thread moves one 16-byte channel chunk of one output pixel when strides allow it
+// (VEC = 16 / sizeof(T)), else one element (VEC = 1).  All of them take pixel strides
+// (in_ld / out_ld) so producers write straight into route-concat buffers
+// (/root/reference/yolov3/darknet.py:369-375) and no concat copy is needed on the usual path.
+#include "common.h"
+
+namespace {
+
+struct LayerArgs {
+  const void *in;
+  const void *in2;
+  void *out;
+  int B, H, W, C, in_ld, in2_ld, Ho, Wo, out_ld, k, stride, zero_pad;
+  long long total;  // B*Ho*Wo*(C/VEC)
+};
+
+template <typename T, int VEC>
+struct Vec {
+  T v[VEC];
+};
+
+template <typename T, int VEC>
+__device__ __forceinline__ void load_vec(const T *p, float out[VEC]) {
+  if constexpr (VEC == 1) {
+    out[0] = y3_to_float<T>(*p);
+  } else {
+    const u32x4 raw = *reinterpret_cast<const u32x4 *>(p);
+    if constexpr (sizeof(T) == 4) {
+      const f32x4 f = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[j] = f[j];
+    } else {
+      const bf16x8 h = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) out[j] = (float)h[j];
+    }
+  }
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void store_vec(T *p, const float in[VEC]) {
+  if constexpr (VEC == 1) {
+    *p = y3_from_float<T>(in[0]);
+  } else if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<f32x4 *>(p) = f32x4{in[0], in[1], in[2], in[3]};
+  } else {
+    bf16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (bf16_t)in[j];
+    *reinterpret_cast<bf16x8 *>(p) = h;
+  }
+}
+
+__device__ __forceinline__ void decode_idx(long long idx, int cgroups, int Wo, int Ho, int &b, int &oy,
+                                           int &ox, int &cg) {
+  cg = (int)(idx % cgroups);
+  long long pix = idx / cgroups;
+  ox = (int)(pix % Wo);
+  pix /= Wo;
+  oy = (int)(pix % Ho);
+  b = (int)(pix / Ho);
+}
+
+// Reference MaxPool2d.forward (darknet.py:21-29): stride 1 & k > 1 -> window [y, y+k) x [x, x+k)
+// with out-of-range taps contributing 0.0 (zero padding right/bottom); otherwise floor-mode
+// pooling without padding (all taps in range).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_kernel(LayerArgs p) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.total) return;
+  int b, oy, ox, cg;
+  decode_idx(idx, p.C / VEC, p.Wo, p.Ho, b, oy, ox, cg);
+  float best[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) best[j] = -INFINITY;
+  bool padded = false;
+  for (int ky = 0; ky < p.k; ++ky) {
+    const int iy = oy * p.stride + ky;
+    for (int kx = 0; kx < p.k; ++kx) {
+      const int ix = ox * p.stride + kx;
+      if (iy >= p.H || ix >= p.W) {
+        padded = true;
+        continue;
+      }
+      float v[VEC];
+      load_vec<T, VEC>(static_cast<const T *>(p.in) + (((long long)b * p.H + iy) * p.W + ix) * p.in_ld + cg * VEC, v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) best[j] = fmaxf(best[j], v[j]);
+    }
+  }
+  if (padded && p.zero_pad) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) best[j] = fmaxf(best[j], 0.f);
+  }
+  store_vec<T, VEC>(static_cast<T *>(p.out) + (((long long)b * p.Ho + oy) * p.Wo + ox) * p.out_ld + cg * VEC, best);
+}
+
+// nn.Upsample(scale_factor, mode="nearest") (darknet.py:302-305)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void upsample_kernel(LayerArgs p) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.total) return;
+  int b, oy, ox, cg;
+  decode_idx(idx, p.C / VEC, p.Wo, p.Ho, b, oy, ox, cg);
+  const int iy = oy / p.stride, ix = ox / p.stride;
+  float v[VEC];
+  load_vec<T, VEC>(static_cast<const T *>(p.in) + (((long long)b * p.H + iy) * p.W + ix) * p.in_ld + cg * VEC, v);
+  store_vec<T, VEC>(static_cast<T *>(p.out) + (((long long)b * p.Ho + oy) * p.Wo + ox) * p.out_ld + cg * VEC, v);
+}
+
+// shortcut that could not be fused into a conv epilogue (darknet.py:379)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void add_kernel(LayerArgs p) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.total) return;
+  int b, oy, ox, cg;
+  decode_idx(idx, p.C / VEC, p.Wo, p.Ho, b, oy, ox, cg);
+  const long long pix = ((long long)b * p.Ho + oy) * p.Wo + ox;
+  float x[VEC], y[VEC];
+  load_vec<T, VEC>(static_cast<const T *>(p.in) + pix * p.in_ld + cg * VEC, x);
+  load_vec<T, VEC>(static_cast<const T *>(p.in2) + pix * p.in2_ld + cg * VEC, y);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) x[j] += y[j];
+  store_vec<T, VEC>(static_cast<T *>(p.out) + pix * p.out_ld + cg * VEC, x);
+}
+
+// route member that could not be produced in place (darknet.py:372-375)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void copy_kernel(LayerArgs p) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.total) return;
+  int b, oy, ox, cg;
+  decode_idx(idx, p.C / VEC, p.Wo, p.Ho, b, oy, ox, cg);
+  const long long pix = ((long long)b * p.Ho + oy) * p.Wo + ox;
+  float x[VEC];
+  load_vec<T, VEC>(static_cast<const T *>(p.in) + pix * p.in_ld + cg * VEC, x);
+  store_vec<T, VEC>(static_cast<T *>(p.out) + pix * p.out_ld + cg * VEC, x);
+}
+
+enum Which { MAXPOOL, UPSAMPLE, ADD, COPY };
+
+template <typename T, int VEC>
+void launch_one(Which w, const LayerArgs &a, hipStream_t s) {
+  const dim3 grid((unsigned)((a.total + 255) / 256)), block(256);
+  switch (w) {
+    case MAXPOOL: hipLaunchKernelGGL((maxpool_kernel<T, VEC>), grid, block, 0, s, a); break;
+    case UPSAMPLE: hipLaunchKernelGGL((upsample_kernel<T, VEC>), grid, block, 0, s, a); break;
+    case ADD: hipLaunchKernelGGL((add_kernel<T, VEC>), grid, block, 0, s, a); break;
+    case COPY: hipLaunchKernelGGL((copy_kernel<T, VEC>), grid, block, 0, s, a); break;
+  }
+}
+
+int launch_layer(Which w, const y3_op &op, const void *d_in, hipStream_t s, bool dry_run) {
+  LayerArgs a;
+  a.in = d_in;
+  a.in2 = op.d_res;
+  a.out = op.d_out;
+  a.B = op.batch; a.H = op.in_h; a.W = op.in_w; a.C = op.in_c; a.in_ld = op.in_ld; a.in2_ld = op.res_ld;
+  a.Ho = op.out_h; a.Wo = op.out_w; a.out_ld = op.out_ld;
+  a.k = op.ksize; a.stride = op.stride;
+  a.zero_pad = (op.ksize > 1 && op.stride == 1) ? 1 : 0;
+  Y3_REQUIRE(op.in_c == op.out_c, "block %d: channel count changes in a pool/upsample/add/copy op", op.block_idx);
+  const int es = y3_elem_size(op.dtype);
+  const int vec = 16 / es;
+  bool wide = op.in_c % vec == 0 && op.in_ld % vec == 0 && op.out_ld % vec == 0 &&
+              ((uintptr_t)d_in % 16 == 0) && ((uintptr_t)op.d_out % 16 == 0);
+  if (w == ADD) wide = wide && op.res_ld % vec == 0 && ((uintptr_t)op.d_res % 16 == 0);
+  a.total = (long long)op.batch * op.out_h * op.out_w * (wide ? op.in_c / vec : op.in_c);
+  if (dry_run) return Y3_OK;
+  if (op.dtype == Y3_BF16) {
+    if (wide) launch_one<bf16_t, 8>(w, a, s); else launch_one<bf16_t, 1>(w, a, s);
+  } else {
+    if (wide) launch_one<float, 4>(w, a, s); else launch_one<float, 1>(w, a, s);
+  }
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+}  // namespace
+
+int y3_launch_maxpool(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
+                      bool dry_run) {
+  Y3_REQUIRE(op.ksize >= 1 && op.stride >= 1, "maxpool block %d: bad size/stride", op.block_idx);
+  if (op.stride == 1) {
+    Y3_REQUIRE(op.out_h == op.in_h && op.out_w == op.in_w, "maxpool block %d: stride-1 keeps H,W", op.block_idx);
+  } else {
+    Y3_REQUIRE(op.out_h == (op.in_h - op.ksize) / op.stride + 1 && op.out_w == (op.in_w - op.ksize) / op.stride + 1,
+               "maxpool block %d: output size mismatch", op.block_idx);
+  }
+  *kernel_name = op.dtype == Y3_BF16 ? "maxpool_bf16" : "maxpool_f32";
+  return launch_layer(MAXPOOL, op, d_in, s, dry_run);
+}
+
+int y3_launch_upsample(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
+                       bool dry_run) {
+  Y3_REQUIRE(op.stride >= 1 && op.out_h == op.in_h * op.stride && op.out_w == op.in_w * op.stride,
+             "upsample block %d: output size mismatch", op.block_idx);
+  *kernel_name = op.dtype == Y3_BF16 ? "upsample_bf16" : "upsample_f32";
+  return launch_layer(UPSAMPLE, op, d_in, s, dry_run);
+}
+
+int y3_launch_add(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name, bool dry_run) {
+  Y3_REQUIRE(op.out_h == op.in_h && op.out_w == op.in_w, "add block %d: size mismatch", op.block_idx);
+  *kernel_name = op.dtype == Y3_BF16 ? "add_bf16" : "add_f32";
+  return launch_layer(ADD, op, d_in, s, dry_run);
+}
+
+int y3_launch_copy(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name, bool dry_run) {
+  Y3_REQUIRE(op.out_h == op.in_h && op.out_w == op.in_w, "copy block %d: size mismatch", op.block_idx);
+  *kernel_name = op.dtype == Y3_BF16 ? "copy_bf16" : "copy_f32";
+  return launch_layer(COPY, op, d_in, s, dry_run);
+}

@@ -1,0 +1,127 @@
+"""ctypes binding of libyolov3_hip.so (C ABI: include/yolov3_hip.h).
+
+The library is hand-written HIP for gfx950 and is the ONLY compute backend of this
+package: if it cannot be loaded, or no MI355X is visible, the entry points raise --
+there is deliberately no CPU or PyTorch fallback.
+
+``torch`` is imported first on purpose: PyTorch-ROCm ships its own libamdhip64.so.7
+and must be the HIP runtime of the process, so that tensor ``data_ptr()`` addresses
+and ``torch.cuda`` streams are valid inside this library (same runtime instance).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be loaded before libyolov3_hip.so, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "..", "lib", "libyolov3_hip.so")
+
+Y3_F32, Y3_BF16 = 0, 1
+OP_CONV, OP_MAXPOOL, OP_UPSAMPLE, OP_ADD, OP_COPY, OP_YOLO = 1, 2, 3, 4, 5, 6
+F_LEAKY, F_RESIDUAL, F_OUT_F32, F_IN_NCHW_F32, F_IN_NHWC_U8BGR, F_PLAN_INPUT = 1, 2, 4, 8, 16, 32
+PATH_IGEMM, PATH_STEM, PATH_DIRECT = 0, 1, 2
+
+
+class Y3Op(ctypes.Structure):
+    """Mirror of ``struct y3_op`` (include/yolov3_hip.h)."""
+    _fields_ = [
+        ("kind", ctypes.c_int32), ("dtype", ctypes.c_int32), ("flags", ctypes.c_uint32),
+        ("batch", ctypes.c_int32),
+        ("in_h", ctypes.c_int32), ("in_w", ctypes.c_int32), ("in_c", ctypes.c_int32), ("in_ld", ctypes.c_int32),
+        ("out_h", ctypes.c_int32), ("out_w", ctypes.c_int32), ("out_c", ctypes.c_int32), ("out_ld", ctypes.c_int32),
+        ("ksize", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32),
+        ("res_ld", ctypes.c_int32), ("k_ld", ctypes.c_int32), ("cout_pad", ctypes.c_int32),
+        ("d_in", ctypes.c_void_p), ("d_out", ctypes.c_void_p), ("d_res", ctypes.c_void_p),
+        ("d_weight", ctypes.c_void_p), ("d_scale", ctypes.c_void_p), ("d_bias", ctypes.c_void_p),
+        ("n_anchor", ctypes.c_int32), ("n_attr", ctypes.c_int32),
+        ("anchor_w", ctypes.c_float * 8), ("anchor_h", ctypes.c_float * 8),
+        ("row_offset", ctypes.c_int32), ("rows_total", ctypes.c_int32),
+        ("net_w", ctypes.c_float), ("net_h", ctypes.c_float),
+        ("d_bbox", ctypes.c_void_p), ("d_prob", ctypes.c_void_p), ("d_cls", ctypes.c_void_p),
+        ("block_idx", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    ]
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/yolov3_hip.h declares
+PROTOTYPES = {
+    "y3_abi_version": (ctypes.c_int, []),
+    "y3_last_error": (ctypes.c_char_p, []),
+    "y3_device_count": (ctypes.c_int, []),
+    "y3_plan_create": (ctypes.c_int, [ctypes.POINTER(Y3Op), ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.POINTER(ctypes.c_void_p)]),
+    "y3_plan_destroy": (None, [ctypes.c_void_p]),
+    "y3_plan_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "y3_plan_run_timed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.POINTER(ctypes.c_float)]),
+    "y3_plan_op_kernel": (ctypes.c_char_p, [ctypes.c_void_p, ctypes.c_int]),
+    "y3_plan_op_flops": (ctypes.c_double, [ctypes.c_void_p, ctypes.c_int]),
+    "y3_plan_op_bytes": (ctypes.c_double, [ctypes.c_void_p, ctypes.c_int]),
+    "y3_conv_path": (ctypes.c_int, [ctypes.POINTER(Y3Op)]),
+    "y3_op_run": (ctypes.c_int, [ctypes.POINTER(Y3Op), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "y3_detect_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "y3_detect": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                 ctypes.c_void_p, ctypes.c_float, ctypes.c_double, ctypes.c_void_p,
+                                 ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "y3_nms_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "y3_nms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
+                              ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                              ctypes.c_void_p]),
+    "y3_cxywh_to_tlbr": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_void_p]),
+    "y3_pack_records": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raise if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.abspath(LIB_PATH)
+    if not os.path.exists(path):
+        raise HipLibraryError(
+            "libyolov3_hip.so not found at {} -- build it with "
+            "`make -C pytorch-yolov3_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "This package has no CPU fallback.".format(path))
+    try:
+        handle = ctypes.CDLL(path)
+    except OSError as exc:
+        raise HipLibraryError("cannot load {}: {}".format(path, exc))
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(handle, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if handle.y3_abi_version() != 1:
+        raise HipLibraryError("libyolov3_hip.so ABI version {} != 1".format(handle.y3_abi_version()))
+    _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().y3_last_error()
+        raise RuntimeError("libyolov3_hip: {} (code {})".format(msg.decode() if msg else "unknown error", rc))
+
+
+def require_gpu():
+    """Raise unless a gfx950 GPU is usable by both torch and the library."""
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "no HIP device visible to torch: this package runs its hot path only on MI355X (gfx950); "
+            "there is no CPU fallback")
+    if lib().y3_device_count() < 1:
+        raise RuntimeError("libyolov3_hip: no gfx950 device found")
+
+
+def stream_ptr(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)

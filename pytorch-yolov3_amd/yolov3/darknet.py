@@ -1,0 +1,384 @@
+"""``Darknet``: the reference's model object, executed by HIP kernels on MI355X.
+
+Keeps the surface callers use (/root/reference/yolov3/darknet.py:318-476):
+``Darknet(config_fpath, device)``, ``.load_weights(path) -> self``, ``.eval()``,
+``.cuda(device)``, ``.forward(x) -> {"bbox_xywh", "class_prob", "class_idx"}`` plus the
+attributes ``.blocks .net_info .device .blocks_to_cache .header .modules_``.
+
+What is different underneath: no nn.Module graph.  ``forward`` compiles (once per input
+shape) a flat op plan (yolov3/plan.py) and hands it to libyolov3_hip.so through the C ABI
+(include/yolov3_hip.h); activations are NHWC in an arena, BN is a per-channel scale/bias in
+the conv epilogue, shortcuts/routes/head-concat are fused away.  Extension over the
+reference: ``dtype="bf16"`` (bf16 storage, fp32 accumulate) and uint8 BGR frame input with
+the BGR->RGB, /255 preprocessing fused into the first conv (``forward_frames``).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _hip
+from .cfgparse import parse_config
+from .plan import build_plan
+from .weights import conv_layout, read_darknet_weights
+
+BN_EPS = np.float32(1e-5)
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def f32_to_bf16_bits(a):
+    """Round-to-nearest-even float32 -> bfloat16 bit patterns (uint16)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u >> np.uint64(16)) & np.uint64(1)) + np.uint64(0x7FFF)
+    return ((u + r) >> np.uint64(16)).astype(np.uint16)
+
+
+class BlockInfo(object):
+    """Lightweight stand-in for the reference's per-block nn.Sequential (``modules_[i]``)."""
+
+    def __init__(self, index, block):
+        self.index = index
+        self.type = block["type"]
+        self.block = block
+
+    def __repr__(self):
+        return "BlockInfo({}, {})".format(self.index, self.type)
+
+
+class _CompiledPlan(object):
+    def __init__(self):
+        self.handle = None
+        self.arena = None
+        self.keep = []
+        self.ops = None
+        self.n_ops = 0
+        self.rows_total = 0
+        self.batch = 0
+
+    def destroy(self):
+        if self.handle is not None:
+            _hip.lib().y3_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Darknet(object):
+    def __init__(self, config_fpath, device="cuda", dtype="float32"):
+        """
+        Args:
+            config_fpath (str): Darknet .cfg file.
+            device (str): "cuda", "cuda:N" (an MI355X) -- or "cpu" to only build the
+                description; ``forward`` needs a GPU device (call ``.cuda()``).
+            dtype (str): "float32" (parity path, exact fp32 MFMA) or "bf16"
+                (bf16 activations/weights, fp32 accumulation; throughput path).
+        """
+        self.blocks, self.net_info = parse_config(config_fpath)
+        if self.net_info is None:
+            raise ValueError("cfg {!r} has no [net] section".format(config_fpath))
+        self.config_fpath = config_fpath
+        self.device = device
+        self.header = None
+        self.training = False
+        self.dtype = {"float32": "float32", "fp32": "float32", "f32": "float32",
+                      "bf16": "bf16", "bfloat16": "bf16"}[str(dtype).replace("torch.", "")]
+
+        # absolute route indices + cache set, as the reference computes them (darknet.py:334-349)
+        self.blocks_to_cache = set()
+        for i, blk in enumerate(self.blocks):
+            if blk["type"] == "route":
+                blk["layers"] = [j if j >= 0 else i + j for j in blk["layers"]]
+                self.blocks_to_cache.update(blk["layers"])
+            elif blk["type"] == "shortcut":
+                self.blocks_to_cache.add(i - 1)
+                self.blocks_to_cache.add(i + blk["from"])
+        self._out_channels, self._convs = conv_layout(self.blocks, self.net_info)
+        if self.blocks and self.blocks[0]["type"] != "convolutional":
+            raise ValueError("the first block must be [convolutional] (it reads the network input)")
+        self.modules_ = [BlockInfo(i, b) for i, b in enumerate(self.blocks)]
+        self._params = None          # host copies, list of dicts per conv
+        self._dev_weights = {}       # (slot, path) -> dict of device tensors
+        self._plans = {}
+        self._zero = None
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("inference-only implementation (BatchNorm uses running statistics)")
+        return self.eval()
+
+    def cuda(self, device=None):
+        if device is None:
+            self.device = "cuda"
+        elif isinstance(device, int):
+            self.device = "cuda:%d" % device
+        else:
+            self.device = str(device)
+        return self
+
+    def to(self, device):
+        return self.cuda(device) if str(device).startswith("cuda") else self._set_cpu()
+
+    def cpu(self):
+        return self._set_cpu()
+
+    def _set_cpu(self):
+        self.device = "cpu"
+        return self
+
+    def __call__(self, x):
+        return self.forward(x)
+
+    # ------------------------------------------------------------------ weights
+    def load_weights(self, weights_path):
+        """Read a Darknet ``.weights`` file (same stream order as darknet.py:415-476)."""
+        self.header, params = read_darknet_weights(weights_path, self.blocks, self.net_info)
+        return self.set_params(params)
+
+    def set_params(self, params):
+        """Install per-conv parameter dicts (see weights.read_darknet_weights)."""
+        if len(params) != len(self._convs):
+            raise ValueError("expected {} conv parameter sets, got {}".format(len(self._convs), len(params)))
+        self._params = params
+        self._dev_weights = {}
+        for plan in self._plans.values():
+            plan.destroy()
+        self._plans = {}
+        return self
+
+    def _fold_bn(self, slot):
+        """BN(eval) as y = conv*scale + bias, float32 like torch's CPU batch_norm
+        (alpha = gamma / sqrt(var + eps), beta' = beta - mean * alpha)."""
+        p = self._params[slot]
+        cout = self._convs[slot]["cout"]
+        if "bn_gamma" in p:
+            inv_std = np.float32(1.0) / np.sqrt(p["bn_var"].astype(np.float32) + BN_EPS)
+            scale = (p["bn_gamma"].astype(np.float32) * inv_std).astype(np.float32)
+            bias = (p["bn_beta"].astype(np.float32) - p["bn_mean"].astype(np.float32) * scale).astype(np.float32)
+        else:
+            scale = np.ones(cout, dtype=np.float32)
+            bias = p["bias"].astype(np.float32)
+        return scale, bias
+
+    def _device_weights(self, slot, path, elem_bf16, dev):
+        key = (slot, path, elem_bf16)
+        if key in self._dev_weights:
+            return self._dev_weights[key]
+        c = self._convs[slot]
+        cout, cin, k = c["cout"], c["cin"], c["k"]
+        w = self._params[slot]["weight"].astype(np.float32)
+        scale, bias = self._fold_bn(slot)
+        if path == _hip.PATH_STEM:
+            cout_pad = _round_up(cout, 8)
+            k_ld = cout_pad
+            host = np.zeros((k * k * cin, cout_pad), dtype=np.float32)
+            host[:, :cout] = w.transpose(2, 3, 1, 0).reshape(k * k * cin, cout)
+            dw = torch.from_numpy(host).to(dev)
+        else:
+            es = 2 if elem_bf16 else 4
+            cout_pad = _round_up(cout, 128)
+            k_ld = _round_up(k * k * cin, 128 // es)
+            host = np.zeros((cout_pad, k_ld), dtype=np.float32)
+            host[:cout, :k * k * cin] = w.transpose(0, 2, 3, 1).reshape(cout, k * k * cin)
+            if elem_bf16:
+                dw = torch.from_numpy(f32_to_bf16_bits(host).view(np.int16)).to(dev)
+            else:
+                dw = torch.from_numpy(host).to(dev)
+        sc = np.zeros(cout_pad, dtype=np.float32)
+        bi = np.zeros(cout_pad, dtype=np.float32)
+        sc[:cout] = scale
+        bi[:cout] = bias
+        entry = dict(weight=dw, scale=torch.from_numpy(sc).to(dev), bias=torch.from_numpy(bi).to(dev),
+                     cout_pad=cout_pad, k_ld=k_ld)
+        self._dev_weights[key] = entry
+        return entry
+
+    # ------------------------------------------------------------------ plan compilation
+    def _torch_device(self):
+        if not str(self.device).startswith("cuda"):
+            raise RuntimeError(
+                "Darknet.forward runs only on an MI355X GPU (device={!r}); call .cuda() -- this build "
+                "has no CPU execution path".format(self.device))
+        _hip.require_gpu()
+        return torch.device(self.device)
+
+    def _compile(self, batch, height, width, input_mode):
+        if self._params is None:
+            raise RuntimeError("call load_weights() / set_params() before forward()")
+        dev = self._torch_device()
+        lib = _hip.lib()
+        bf16 = self.dtype == "bf16"
+        es = 2 if bf16 else 4
+        desc = build_plan(self.blocks, self.net_info, batch, height, width, es)
+        cp = _CompiledPlan()
+        cp.batch = batch
+        cp.rows_total = desc["rows_total"]
+        cp.arena = torch.empty(desc["arena_bytes"], dtype=torch.uint8, device=dev)
+        if self._zero is None or self._zero.device != dev:
+            self._zero = torch.zeros(4096, dtype=torch.uint8, device=dev)
+        base = cp.arena.data_ptr()
+
+        def addr(t, elem):
+            if t is None:
+                return None
+            if t.buf == "input":
+                return None
+            return base + desc["offsets"][t.buf] + t.off * elem
+
+        ops = (_hip.Y3Op * len(desc["ops"]))()
+        for n, od in enumerate(desc["ops"]):
+            op = ops[n]
+            kind = od["kind"]
+            op.dtype = _hip.Y3_BF16 if bf16 else _hip.Y3_F32
+            op.batch = batch
+            op.block_idx = od["block"]
+            tin = od["inp"]
+            op.in_h, op.in_w, op.in_c, op.in_ld = tin.h, tin.w, tin.c, tin.ld
+            in_es = 4 if tin.f32 else es
+            if tin.buf == "input":
+                op.flags |= _hip.F_PLAN_INPUT
+                op.flags |= _hip.F_IN_NHWC_U8BGR if input_mode == "u8" else _hip.F_IN_NCHW_F32
+            else:
+                op.d_in = addr(tin, in_es)
+            tout = od.get("out")
+            if tout is not None:
+                op.out_h, op.out_w, op.out_c, op.out_ld = tout.h, tout.w, tout.c, tout.ld
+                op.d_out = addr(tout, 4 if tout.f32 else es)
+                if tout.f32 and bf16:
+                    op.flags |= _hip.F_OUT_F32
+            res = od.get("res")
+            if res is not None:
+                op.d_res = addr(res, es)
+                op.res_ld = res.ld
+            if kind == "conv":
+                op.kind = _hip.OP_CONV
+                op.ksize, op.stride, op.pad = od["ksize"], od["stride"], od["pad"]
+                if od["leaky"]:
+                    op.flags |= _hip.F_LEAKY
+                if res is not None:
+                    op.flags |= _hip.F_RESIDUAL
+                c = self._convs[od["slot"]]
+                # provisional padded sizes so that y3_conv_path can judge the shape
+                op.cout_pad = _round_up(c["cout"], 128)
+                op.k_ld = _round_up(c["k"] * c["k"] * c["cin"], 128 // es)
+                path = lib.y3_conv_path(ctypes.byref(op))
+                wts = self._device_weights(od["slot"], path, bf16, dev)
+                op.cout_pad, op.k_ld = wts["cout_pad"], wts["k_ld"]
+                op.d_weight = wts["weight"].data_ptr()
+                op.d_scale = wts["scale"].data_ptr()
+                op.d_bias = wts["bias"].data_ptr()
+                cp.keep.append(wts)
+            elif kind == "maxpool":
+                op.kind = _hip.OP_MAXPOOL
+                op.ksize, op.stride = od["ksize"], od["stride"]
+            elif kind == "upsample":
+                op.kind = _hip.OP_UPSAMPLE
+                op.ksize, op.stride = 1, od["stride"]
+            elif kind == "add":
+                op.kind = _hip.OP_ADD
+                op.ksize = op.stride = 1
+            elif kind == "copy":
+                op.kind = _hip.OP_COPY
+                op.ksize = op.stride = 1
+            elif kind == "yolo":
+                op.kind = _hip.OP_YOLO
+                op.n_anchor = len(od["anchors"])
+                op.n_attr = od["n_attr"]
+                for a, (aw, ah) in enumerate(od["anchors"]):
+                    op.anchor_w[a] = float(aw)
+                    op.anchor_h[a] = float(ah)
+                op.row_offset, op.rows_total = od["row_offset"], od["rows_total"]
+                op.net_w, op.net_h = float(self.net_info["width"]), float(self.net_info["height"])
+            else:
+                raise AssertionError(kind)
+        cp.ops = ops
+        cp.n_ops = len(desc["ops"])
+        cp.desc = desc
+        # persistent output buffers: every head's decode kernel writes its row range in place
+        m = cp.rows_total
+        cp.bbox = torch.empty((batch, m, 4), dtype=torch.float32, device=dev)
+        cp.prob = torch.empty((batch, m), dtype=torch.float32, device=dev)
+        cp.cls = torch.empty((batch, m), dtype=torch.int64, device=dev)
+        for n in range(cp.n_ops):
+            if ops[n].kind == _hip.OP_YOLO:
+                ops[n].d_bbox, ops[n].d_prob, ops[n].d_cls = (
+                    cp.bbox.data_ptr(), cp.prob.data_ptr(), cp.cls.data_ptr())
+        handle = ctypes.c_void_p()
+        _hip.check(lib.y3_plan_create(ops, cp.n_ops, self._zero.data_ptr(), ctypes.byref(handle)))
+        cp.handle = handle
+        return cp
+
+    def _get_plan(self, batch, height, width, input_mode):
+        key = (batch, height, width, input_mode, self.dtype, str(self.device))
+        cp = self._plans.get(key)
+        if cp is None:
+            cp = self._compile(batch, height, width, input_mode)
+            self._plans[key] = cp
+        return cp
+
+    def _run(self, x, input_mode, timed=False, fresh=True):
+        """Launch the plan on torch's current stream.  ``fresh=False`` returns the plan's own
+        output buffers (overwritten by the next call with the same shape) -- used by
+        ``inference()`` and the benchmark, which consume them immediately."""
+        dev = self._torch_device()
+        lib = _hip.lib()
+        if input_mode == "u8":
+            batch, height, width, ch = x.shape
+        else:
+            batch, ch, height, width = x.shape
+        if ch != self.net_info["channels"]:
+            raise ValueError("input has {} channels, cfg says {}".format(ch, self.net_info["channels"]))
+        cp = self._get_plan(batch, height, width, input_mode)
+        with torch.cuda.device(dev):
+            if timed:
+                ms = (ctypes.c_float * cp.n_ops)()
+                _hip.check(lib.y3_plan_run_timed(cp.handle, x.data_ptr(), _hip.stream_ptr(), ms))
+                self.last_op_ms = list(ms)
+            else:
+                _hip.check(lib.y3_plan_run(cp.handle, x.data_ptr(), _hip.stream_ptr()))
+        self._last_plan = cp
+        if fresh:
+            return {"bbox_xywh": cp.bbox.clone(), "class_prob": cp.prob.clone(), "class_idx": cp.cls.clone()}
+        return {"bbox_xywh": cp.bbox, "class_prob": cp.prob, "class_idx": cp.cls}
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        """x: (B,3,H,W) float32 RGB in [0,1] (torch tensor, any device).  Returns the reference's
+        dict of (B,M,4) / (B,M) / (B,M) tensors on the GPU (darknet.py:401-405)."""
+        dev = self._torch_device()
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(x)
+        if x.dim() != 4:
+            raise ValueError("expected a (B,C,H,W) tensor, got shape {}".format(tuple(x.shape)))
+        x = x.to(device=dev, dtype=torch.float32).contiguous()
+        return self._run(x, "f32")
+
+    def forward_frames(self, frames_u8, fresh=True):
+        """frames_u8: (B,H,W,3) uint8 BGR (numpy or torch).  Same outputs as ``forward`` on
+        ``flip(frames)/255`` transposed to NCHW (inference.py:332-333), preprocessing fused
+        into the first conv kernel."""
+        dev = self._torch_device()
+        if not isinstance(frames_u8, torch.Tensor):
+            frames_u8 = torch.from_numpy(np.ascontiguousarray(frames_u8))
+        if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4:
+            raise ValueError("expected uint8 (B,H,W,3) frames")
+        return self._run(frames_u8.to(dev).contiguous(), "u8", fresh=fresh)
+
+    def plan_report(self):
+        """Per-op (kernel name, flops, bytes, block) of the last executed plan (for bench/profiling)."""
+        cp = self._last_plan
+        lib = _hip.lib()
+        return [dict(kernel=lib.y3_plan_op_kernel(cp.handle, i).decode(),
+                     flops=lib.y3_plan_op_flops(cp.handle, i), bytes=lib.y3_plan_op_bytes(cp.handle, i),
+                     block=int(cp.ops[i].block_idx)) for i in range(cp.n_ops)]

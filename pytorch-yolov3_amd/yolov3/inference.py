@@ -1,0 +1,157 @@
+"""Post-processing entry points with the reference's signatures, computed on the GPU.
+
+``cxywh_to_tlbr``, ``non_max_suppression`` and ``inference`` mirror
+/root/reference/yolov3/inference.py:220-368.  Differences that callers can observe:
+
+* kept indices / detections come out in a canonical order (class ascending, score
+  descending, then higher index first) instead of the reference's Python-``set`` /
+  ``argsort`` dependent order -- the *set* of kept boxes is identical;
+* ``inference()`` runs threshold, scaling, integer truncation, corner conversion and
+  per-class NMS in one device kernel per batch (libyolov3_hip ``y3_detect``) and copies
+  only the surviving detections back to the host;
+* frames that are not net-sized are resized on the host by ``preprocess.resize_bilinear_u8``
+  (the reference uses ``cv2.resize``; see that module's docstring).
+
+There is no CPU fallback: without the HIP library / a GPU these functions raise.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _hip
+from .preprocess import prepare_frames
+
+
+def _device(device=None):
+    _hip.require_gpu()
+    if device is None or str(device) == "cuda":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device(device)
+
+
+def cxywh_to_tlbr(bbox_xywh):
+    """(n, >=4) integer array [cx, cy, w, h, ...] -> [x1, y1, x2, y2, ...] with
+    ``x1 = cx - w//2`` etc. (floor division; extra columns pass through)."""
+    arr = np.asarray(bbox_xywh)
+    if arr.ndim != 2 or arr.shape[1] < 4:
+        raise ValueError("expected an (n, >=4) array")
+    if not np.issubdtype(arr.dtype, np.integer):
+        raise TypeError("cxywh_to_tlbr works on integer pixel boxes (the reference floor-divides ints)")
+    if arr.shape[0] == 0:
+        return arr.copy()
+    dev = _device()
+    src = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64)).to(dev)
+    dst = torch.empty_like(src)
+    _hip.check(_hip.lib().y3_cxywh_to_tlbr(src.data_ptr(), dst.data_ptr(), arr.shape[0], arr.shape[1],
+                                           _hip.stream_ptr()))
+    return dst.cpu().numpy().astype(arr.dtype, copy=False)
+
+
+def non_max_suppression(bbox_tlbr, class_prob, class_idx=None, iou_thresh=0.3):
+    """Greedy NMS; per class when ``class_idx`` is given.  Returns a list of kept indices.
+
+    Same decision rule as the reference (areas with +1, IoU in float64, suppress iff
+    IoU > iou_thresh, highest score first).
+    """
+    boxes = np.ascontiguousarray(np.asarray(bbox_tlbr)[:, :4] if np.asarray(bbox_tlbr).size else
+                                 np.zeros((0, 4)), dtype=np.int64)
+    prob = np.ascontiguousarray(class_prob, dtype=np.float32)
+    n = boxes.shape[0]
+    if prob.shape[0] != n:
+        raise ValueError("bbox_tlbr and class_prob disagree on the number of boxes")
+    if n == 0:
+        return []
+    dev = _device()
+    lib = _hip.lib()
+    d_box = torch.from_numpy(boxes).to(dev)
+    d_prob = torch.from_numpy(prob).to(dev)
+    d_cls = None
+    if class_idx is not None:
+        cls = np.ascontiguousarray(class_idx, dtype=np.int64)
+        if cls.shape[0] != n:
+            raise ValueError("class_idx has the wrong length")
+        d_cls = torch.from_numpy(cls).to(dev)
+    ws_bytes = lib.y3_nms_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    keep = torch.empty(n, dtype=torch.int64, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    _hip.check(lib.y3_nms(d_box.data_ptr(), d_prob.data_ptr(), d_cls.data_ptr() if d_cls is not None else None,
+                          n, float(iou_thresh), ws.data_ptr(), ws_bytes, keep.data_ptr(), count.data_ptr(),
+                          _hip.stream_ptr()))
+    k = int(count.cpu()[0])
+    return keep[:k].cpu().numpy().tolist()
+
+
+class Detector(object):
+    """Reusable device buffers for the detection tail of one (batch, rows) shape."""
+
+    def __init__(self, batch, rows, device):
+        lib = _hip.lib()
+        self.batch, self.rows, self.device = batch, rows, device
+        self.ws_bytes = lib.y3_detect_workspace_bytes(batch, rows)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.count = torch.zeros(batch, dtype=torch.int32, device=device)
+        self.tlbr = torch.empty((batch, rows, 4), dtype=torch.int64, device=device)
+        self.prob = torch.empty((batch, rows), dtype=torch.float32, device=device)
+        self.cls = torch.empty((batch, rows), dtype=torch.int64, device=device)
+        self.row = torch.empty((batch, rows), dtype=torch.int32, device=device)
+        self.orig_hw = torch.empty((batch, 2), dtype=torch.int32, device=device)
+
+    def run(self, out, orig_hw, prob_thresh, iou_thresh):
+        """out: Darknet.forward dict (device tensors).  orig_hw: (batch,2) int32 tensor/array."""
+        if not isinstance(orig_hw, torch.Tensor):
+            orig_hw = torch.from_numpy(np.ascontiguousarray(orig_hw, dtype=np.int32))
+        self.orig_hw.copy_(orig_hw, non_blocking=True)
+        bbox, prob, cls = out["bbox_xywh"], out["class_prob"], out["class_idx"]
+        _hip.check(_hip.lib().y3_detect(
+            bbox.data_ptr(), prob.data_ptr(), cls.data_ptr(), self.batch, self.rows, self.orig_hw.data_ptr(),
+            ctypes.c_float(prob_thresh), ctypes.c_double(iou_thresh), self.ws.data_ptr(), self.ws_bytes,
+            self.count.data_ptr(), self.tlbr.data_ptr(), self.prob.data_ptr(), self.cls.data_ptr(),
+            self.row.data_ptr(), _hip.stream_ptr()))
+
+    def fetch(self, return_rows=False):
+        counts = self.count.cpu().numpy()
+        results = []
+        for b in range(self.batch):
+            k = int(counts[b])
+            item = [self.tlbr[b, :k].cpu().numpy(), self.prob[b, :k].cpu().numpy(), self.cls[b, :k].cpu().numpy()]
+            if return_rows:
+                item.append(self.row[b, :k].cpu().numpy().astype(np.int64))
+            results.append(item)
+        return results
+
+
+_detectors = {}
+
+
+def get_detector(batch, rows, device):
+    key = (batch, rows, str(device))
+    det = _detectors.get(key)
+    if det is None:
+        det = Detector(batch, rows, device)
+        _detectors[key] = det
+    return det
+
+
+def inference(net, images, device="cuda", prob_thresh=0.05, nms_iou_thresh=0.3, resize=True,
+              return_rows=False):
+    """Run detection on one frame or a list of HxWx3 uint8 BGR frames.
+
+    Returns, per frame, ``[bbox_tlbr int64 (K,4), class_prob float32 (K,), class_idx int64 (K,)]``
+    (plus the prediction-row index of every detection when ``return_rows``), in original-frame
+    pixel coordinates -- same contract as the reference's ``inference()``.
+    """
+    if not isinstance(images, (list, tuple)):
+        images = [images]
+    if str(device).startswith("cuda") and not str(net.device).startswith("cuda"):
+        net.cuda(device)
+    frames, shapes = prepare_frames(list(images), net.net_info["height"], net.net_info["width"], resize)
+    dev = net._torch_device()
+    out = net.forward_frames(frames, fresh=False)
+    batch, rows = out["class_prob"].shape
+    det = get_detector(batch, rows, dev)
+    orig_hw = np.array([[s[0], s[1]] for s in shapes], dtype=np.int32)
+    with torch.cuda.device(dev):
+        det.run(out, orig_hw, float(np.float32(prob_thresh)), float(nms_iou_thresh))
+        return det.fetch(return_rows=return_rows)

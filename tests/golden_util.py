@@ -1,0 +1,87 @@
+"""Shared helpers for tests that read tests/golden/* (see tools/make_goldens.py)."""
+import hashlib
+import os
+from collections import Counter
+
+import numpy as np
+
+from yolov3 import weights as W
+from yolov3.cfgparse import parse_config
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+MODEL_DIR = os.path.join(ROOT, "pytorch-yolov3_amd", "models")
+MODELS = {m: os.path.join(MODEL_DIR, m + ".cfg") for m in ("yolov3-tiny", "yolov3", "yolov3-spp")}
+MODELS["mini"] = os.path.join(GOLDEN, "cfg", "mini.cfg")
+MODEL_DIMS = {"yolov3-tiny": 416, "yolov3": 608, "yolov3-spp": 608}
+GOLDEN_SEED = 0
+GOLDEN_OBJ_BIAS = -5.0
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def load_jpeg_bgr(name):
+    from PIL import Image
+    im = Image.open(os.path.join(GOLDEN, "images", name)).convert("RGB")
+    return np.ascontiguousarray(np.asarray(im)[:, :, ::-1])
+
+
+def golden_params(model):
+    """The procedural parameters the golden vectors were generated with."""
+    blocks, net_info = parse_config(MODELS[model])
+    calib = None if model == "mini" else W.load_calibration(model)
+    return W.synth_params(blocks, net_info, seed=GOLDEN_SEED, obj_bias=GOLDEN_OBJ_BIAS, calib=calib)
+
+
+def golden_weights_path(model, tmp_path=None):
+    """Write (once per machine) the Darknet-format file the golden run loaded, so tests exercise
+    the ordinary ``load_weights`` path."""
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "y3_golden_weights")
+    os.makedirs(cache, exist_ok=True)
+    path = os.path.join(cache, "%s_seed%d.weights" % (model, GOLDEN_SEED))
+    blocks, net_info = parse_config(MODELS[model])
+    want = 20 + 4 * W.stream_length(blocks, net_info)
+    if not (os.path.exists(path) and os.path.getsize(path) == want):
+        tmp = path + ".%d.tmp" % os.getpid()
+        W.write_darknet_weights(tmp, golden_params(model))
+        os.replace(tmp, path)
+    return path
+
+
+def compare_detections(g, prefix, det, rows=None, prob_tol=1e-5):
+    """Compare one frame's detections with the golden ones.
+
+    The golden file lists which candidates are *fragile* (a scaled coordinate within 2e-3 px of
+    an integer, or a score within 1e-5 of the threshold): for those a float difference of a few
+    ulp between two correct implementations legitimately flips the truncated pixel (and,
+    through IoU, occasionally a neighbour's fate).  Everything else must match exactly.
+    """
+    tlbr, prob, cls = det[0], det[1], det[2]
+    g_tlbr, g_prob, g_cls, g_rows = g[prefix + "tlbr"], g[prefix + "prob"], g[prefix + "cls"], g[prefix + "rows"]
+    fragile_rows = set(g[prefix + "cand_rows"][g[prefix + "cand_fragile"]].tolist())
+    budget = 3 * len(fragile_rows)
+    assert tlbr.dtype == np.int64 and cls.dtype == np.int64 and prob.dtype == np.float32
+    assert tlbr.shape == (len(prob), 4) and cls.shape == prob.shape
+    if rows is not None:
+        got = {int(r): k for k, r in enumerate(rows)}
+        want = {int(r): k for k, r in enumerate(g_rows)}
+        assert len(got) == len(rows), "duplicate rows in detections"
+        diff = set(got) ^ set(want)
+        assert len(diff) <= budget, "keep sets differ by %d rows (budget %d)" % (len(diff), budget)
+        bad = 0
+        for r in set(got) & set(want):
+            a, b = got[r], want[r]
+            assert cls[a] == g_cls[b], "class differs at row %d" % r
+            assert abs(float(prob[a]) - float(g_prob[b])) <= prob_tol, "score differs at row %d" % r
+            if not (tlbr[a] == g_tlbr[b]).all():
+                assert r in fragile_rows and np.abs(tlbr[a] - g_tlbr[b]).max() <= 1, \
+                    "box differs at non-fragile row %d: %s vs %s" % (r, tlbr[a], g_tlbr[b])
+                bad += 1
+        return len(diff), bad
+    got = Counter((int(c),) + tuple(int(v) for v in t) for c, t in zip(cls, tlbr))
+    want = Counter((int(c),) + tuple(int(v) for v in t) for c, t in zip(g_cls, g_tlbr))
+    diff = sum(((got - want) + (want - got)).values())
+    assert diff <= 2 * budget, "detections differ in %d rows (budget %d)" % (diff, 2 * budget)
+    return diff, 0

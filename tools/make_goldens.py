@@ -1,0 +1,339 @@
+"""Generate tests/golden/* by running the REAL reference on CPU in this container.
+
+Run:  python tools/make_goldens.py            (needs /root/reference; ~2 min)
+
+Nothing here travels as code to the GPU box: only the produced data files
+(tests/golden/*.npz, *.json) are committed.  The reference is imported
+read-only through tools/refshim.py (cv2 stub + np.int alias) and is fed
+
+* procedural weights (pytorch-yolov3_amd/yolov3/weights.py: synth_params,
+  written in Darknet .weights format and loaded by the reference's own
+  ``load_weights``), because real checkpoints need network access;
+* frames that tests can rebuild bit-exactly: JPEGs kept under
+  tests/golden/images (decoded with PIL) and procedural scenes
+  (yolov3/synthdata.py).  ``cv2.resize`` is replaced by this build's
+  ``resize_bilinear_u8`` so that non-net-sized frames can go through the
+  reference's ``inference()``; both sides then see the same resized pixels.
+
+Golden sets:
+  G2 parse_config.json        parse_config dumps, blocks_to_cache, absolute routes
+  G3 mini_blocks.npz          every block output of tests/golden/cfg/mini.cfg (B=2)
+  G4 yolo_layer.npz           YOLOLayer.forward on a small tensor + 1-hot probe
+  G5 forward_<model>.npz      full Darknet.forward outputs
+  G6 nms_cases.json           non_max_suppression cases (per-class, agnostic, edge cases)
+  G7 inference_<model>.npz    inference() end-to-end lists + fragility audit
+"""
+import hashlib
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, ".."))
+PKG = os.path.join(ROOT, "pytorch-yolov3_amd")
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+from refshim import load_reference  # noqa: E402
+
+ref = load_reference()
+
+
+def _load_amd(modname):
+    """Load one of OUR modules without importing our package as ``yolov3``
+    (that name is taken by the reference in this process)."""
+    pkgname = "amd_yolov3"
+    if pkgname not in sys.modules:
+        pkg = types.ModuleType(pkgname)
+        pkg.__path__ = [os.path.join(PKG, "yolov3")]
+        sys.modules[pkgname] = pkg
+    full = pkgname + "." + modname
+    if full in sys.modules:
+        return sys.modules[full]
+    spec = importlib.util.spec_from_file_location(full, os.path.join(PKG, "yolov3", modname + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[full] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+W = _load_amd("weights")
+SD = _load_amd("synthdata")
+PP = _load_amd("preprocess")
+
+import cv2  # noqa: E402  (the stub installed by refshim)
+
+
+def _resize_like_cv2(image, dsize):
+    # cv2.resize(image, dsize=(width, height)); the reference passes (net_h, net_w)
+    return PP.resize_bilinear_u8(image, dsize[1], dsize[0])
+
+
+cv2.resize = _resize_like_cv2
+
+MODELS = {
+    "yolov3-tiny": dict(dim=416, cfg=os.path.join(PKG, "models", "yolov3-tiny.cfg")),
+    "yolov3": dict(dim=608, cfg=os.path.join(PKG, "models", "yolov3.cfg")),
+    "yolov3-spp": dict(dim=608, cfg=os.path.join(PKG, "models", "yolov3-spp.cfg")),
+}
+SEED = 0
+OBJ_BIAS = -5.0
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def jsonable(o):
+    if isinstance(o, dict):
+        return {k: jsonable(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [jsonable(v) for v in o]
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    if isinstance(o, (np.floating,)):
+        return float(o)
+    return o
+
+
+def load_jpeg_bgr(name):
+    from PIL import Image
+    im = Image.open(os.path.join(GOLD, "images", name)).convert("RGB")
+    return np.ascontiguousarray(np.asarray(im)[:, :, ::-1])
+
+
+def make_net(model, calib=True, cfg=None):
+    cfg = cfg or MODELS[model]["cfg"]
+    blocks, net_info = ref.darknet.parse_config(cfg)
+    params = W.synth_params(blocks, net_info, seed=SEED, obj_bias=OBJ_BIAS,
+                            calib=W.load_calibration(model) if calib else None)
+    path = "/tmp/golden_{}.weights".format(model)
+    W.write_darknet_weights(path, params)
+    net = ref.Darknet(cfg, device="cpu")
+    net.load_weights(path)
+    net.eval()
+    return net
+
+
+# ---------------------------------------------------------------- G2
+def g2_parse_config():
+    out = {}
+    for name, cfg in [(m, MODELS[m]["cfg"]) for m in MODELS] + [("mini", os.path.join(GOLD, "cfg", "mini.cfg"))]:
+        blocks, net_info = ref.darknet.parse_config(cfg)
+        net = ref.Darknet(cfg, device="cpu")
+        out[name] = dict(
+            blocks=jsonable(blocks), net_info=jsonable(net_info),
+            blocks_after_init=jsonable(net.blocks),
+            blocks_to_cache=sorted(int(i) for i in net.blocks_to_cache),
+        )
+    with open(os.path.join(GOLD, "parse_config.json"), "w") as fh:
+        json.dump(out, fh)
+    print("G2 ok")
+
+
+# ---------------------------------------------------------------- G3
+def g3_mini_blocks():
+    net = make_net("mini", calib=False, cfg=os.path.join(GOLD, "cfg", "mini.cfg"))
+    h, w = net.net_info["height"], net.net_info["width"]
+    frames = SD.synth_frames(7, 2, h, w, rects=12)
+    x = torch.tensor(np.transpose(np.flip(frames, 3), (0, 3, 1, 2)).astype(np.float32) / 255.0)
+    ins, outs = {}, {}
+
+    def mk(i):
+        def pre(mod, inp):
+            ins[i] = inp[0].detach().clone()
+
+        def post(mod, inp, outp):
+            if isinstance(outp, torch.Tensor):
+                outs[i] = outp.detach().clone()
+        return pre, post
+    for i, m in enumerate(net.modules_):
+        pre, post = mk(i)
+        m.register_forward_pre_hook(pre)
+        m.register_forward_hook(post)
+    final = net.forward(x)
+    arrays = {"frames": frames, "input": x.numpy()}
+    for i, blk in enumerate(net.blocks):
+        t = blk["type"]
+        if t in ("convolutional", "maxpool", "upsample"):
+            arrays["block_%d" % i] = outs[i].numpy()
+        elif t in ("route", "shortcut"):
+            # output of a route/shortcut == input seen by the next hooked module
+            arrays["block_%d" % i] = ins[i + 1].numpy()
+    arrays["bbox_xywh"] = final["bbox_xywh"].detach().numpy()
+    arrays["class_prob"] = final["class_prob"].detach().numpy()
+    arrays["class_idx"] = final["class_idx"].numpy()
+    np.savez_compressed(os.path.join(GOLD, "mini_blocks.npz"), **arrays)
+    print("G3 ok", {k: v.shape for k, v in arrays.items() if k.startswith("block_")})
+
+
+# ---------------------------------------------------------------- G4
+def g4_yolo_layer():
+    anchors = [[10, 13], [16, 30], [33, 23], [30, 61], [62, 45], [59, 119], [116, 90], [156, 198], [373, 326]]
+    layer = ref.darknet.YOLOLayer(anchors, [3, 4, 5], device="cpu")
+    rs = np.random.RandomState(11)
+    x = (rs.randn(2, 255, 4, 5) * 2.0).astype(np.float32)
+    bb, p, c = layer.forward(torch.tensor(x))
+    probe = np.zeros((1, 255, 3, 4), dtype=np.float32)
+    # anchor 0, cell (y=2, x=3): tx=1, ty=0, tw=0, th=0, obj=2, class 7 strongly on
+    probe[0, 0, 2, 3] = 1.0
+    probe[0, 4, 2, 3] = 2.0
+    probe[0, 5 + 7, 2, 3] = 6.0
+    pb, pp, pc = layer.forward(torch.tensor(probe))
+    np.savez_compressed(
+        os.path.join(GOLD, "yolo_layer.npz"), x=x, bbox=bb.numpy(), prob=p.numpy(), cls=c.numpy(),
+        probe=probe, probe_bbox=pb.numpy(), probe_prob=pp.numpy(), probe_cls=pc.numpy(),
+        anchors=np.array(anchors, dtype=np.int64), mask=np.array([3, 4, 5]))
+    row = 0 * 12 + 2 * 4 + 3
+    print("G4 ok probe row", row, pb[0, row].tolist(), float(pp[0, row]), int(pc[0, row]))
+
+
+# ---------------------------------------------------------------- G5 / G7
+def net_frames(model):
+    dim = MODELS[model]["dim"]
+    jpg = load_jpeg_bgr("000000035279.jpg")
+    synth = SD.synth_frames(5, 1, dim, dim)[0]
+    return [PP.resize_bilinear_u8(jpg, dim, dim), synth]
+
+
+def cls_margin(net, x):
+    """top-1 minus top-2 softmax score per box (to excuse arg-max flips on near ties)."""
+    margins = []
+    captured = []
+
+    def hook(mod, inp, outp):
+        captured.append(inp[0].detach())
+    hs = [m.register_forward_hook(hook) for m, b in zip(net.modules_, net.blocks) if b["type"] == "yolo"]
+    net.forward(x)
+    for h in hs:
+        h.remove()
+    for t in captured:
+        b, ch, hh, ww = t.shape
+        sm = torch.softmax(t.reshape(b, 3, ch // 3, hh, ww)[:, :, 5:], dim=2)
+        top2 = torch.topk(sm, 2, dim=2).values
+        margins.append((top2[:, :, 0] - top2[:, :, 1]).reshape(b, -1))
+    return torch.cat(margins, dim=1).numpy()
+
+
+def g5_forward(model, net):
+    frames = net_frames(model)
+    inp = np.transpose(np.flip(np.stack(frames), 3), (0, 3, 1, 2)).astype(np.float32) / 255.0
+    x = torch.tensor(inp)
+    out = net.forward(x)
+    margin = cls_margin(net, x)
+    bb = out["bbox_xywh"].detach().numpy()
+    assert np.isfinite(bb).all()
+    np.savez_compressed(
+        os.path.join(GOLD, "forward_%s.npz" % model),
+        frames_sha=np.array([sha(f) for f in frames]),
+        input_sha=np.array(sha(inp)),
+        bbox_xywh=bb, class_prob=out["class_prob"].detach().numpy(),
+        class_idx=out["class_idx"].numpy().astype(np.uint8),
+        cls_margin=margin.astype(np.float32),
+        seed=SEED, obj_bias=OBJ_BIAS)
+    p = out["class_prob"].detach().numpy()
+    print("G5", model, bb.shape, "cand@0.05", (p >= 0.05).sum(1), "@0.2", (p >= 0.2).sum(1),
+          "max wh", bb[:, :, 2:].max())
+
+
+def g7_inference(model, net):
+    dim = MODELS[model]["dim"]
+    jpg_a = load_jpeg_bgr("000000229358.jpg")      # original size -> goes through resize
+    jpg_b = load_jpeg_bgr("000000393569.jpg")
+    synth = SD.synth_frames(9, 1, dim, dim)[0]     # net-sized -> resize skipped
+    frames = [jpg_a, synth, jpg_b]
+    arrays = {"frame_shapes": np.array([f.shape for f in frames]),
+              "frames_sha": np.array([sha(f) for f in frames])}
+    # raw forward outputs for the fragility audit (same preprocessing as inference())
+    resized = [PP.resize_bilinear_u8(f, dim, dim) for f in frames]
+    inp = np.transpose(np.flip(np.stack(resized), 3), (0, 3, 1, 2)).astype(np.float32) / 255.0
+    raw = net.forward(torch.tensor(inp))
+    bb = raw["bbox_xywh"].detach().numpy()
+    pr = raw["class_prob"].detach().numpy()
+    ci = raw["class_idx"].numpy()
+    for tag, pth, ith in (("a", 0.05, 0.3), ("b", 0.2, 0.3)):
+        res = ref.inference(net, list(frames), device="cpu", prob_thresh=pth, nms_iou_thresh=ith)
+        for f, (tlbr, prob, cls) in enumerate(res):
+            oh, ow = frames[f].shape[:2]
+            cand = np.where(pr[f] >= pth)[0]
+            sc = bb[f, cand].copy()
+            sc[:, [0, 2]] *= ow
+            sc[:, [1, 3]] *= oh
+            dist = np.abs(sc - np.rint(sc)).min(axis=1)
+            fragile = (dist < 2e-3) | (np.abs(pr[f, cand] - np.float32(pth)) < 1e-5)
+            # recover which candidate each kept detection is: replay the reference's own steps
+            ti = ref.cxywh_to_tlbr(sc.astype(np.int64))
+            keep = ref.non_max_suppression(ti, pr[f, cand], class_idx=ci[f, cand], iou_thresh=ith)
+            assert np.array_equal(ti[keep], tlbr) and np.array_equal(pr[f, cand][keep], prob)
+            key = "%s_f%d_" % (tag, f)
+            arrays[key + "tlbr"] = tlbr.astype(np.int64)
+            arrays[key + "prob"] = prob.astype(np.float32)
+            arrays[key + "cls"] = cls.astype(np.int64)
+            arrays[key + "rows"] = cand[keep].astype(np.int64)      # row index into the M predictions
+            arrays[key + "cand_rows"] = cand.astype(np.int64)
+            arrays[key + "cand_fragile"] = fragile
+            print("G7", model, tag, "frame", f, "cand", len(cand), "kept", len(keep),
+                  "fragile", int(fragile.sum()), "classes", len(set(cls.tolist())))
+        arrays[tag + "_thresholds"] = np.array([pth, ith])
+    np.savez_compressed(os.path.join(GOLD, "inference_%s.npz" % model), **arrays)
+
+
+# ---------------------------------------------------------------- G6
+def g6_nms():
+    cases = []
+
+    def add(name, boxes, prob, cls, thr):
+        boxes = np.array(boxes, dtype=np.int64).reshape(-1, 4)
+        prob = np.array(prob, dtype=np.float32)
+        per_class = None
+        if cls is not None:
+            cls_a = np.array(cls, dtype=np.int64)
+            per_class = [int(i) for i in ref.non_max_suppression(boxes, prob, class_idx=cls_a, iou_thresh=thr)]
+        agnostic = [int(i) for i in ref.non_max_suppression(boxes, prob, iou_thresh=thr)] if len(prob) else []
+        cases.append(dict(name=name, boxes=boxes.tolist(), prob=[float(p) for p in prob],
+                          prob_bits=[int(b) for b in prob.view(np.uint32)] if len(prob) else [],
+                          cls=cls, thr=thr, per_class=per_class, agnostic=agnostic))
+
+    add("survey", [[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10]], [.9, .8, .7, .9], [1, 1, 1, 2], 0.3)
+    add("single", [[5, 5, 9, 9]], [.5], [3], 0.3)
+    add("identical_diff_class", [[0, 0, 4, 4]] * 3, [.3, .6, .5], [0, 1, 2], 0.3)
+    add("identical_same_class", [[0, 0, 4, 4]] * 3, [.3, .6, .5], [1, 1, 1], 0.3)
+    add("touching_edge_plus1", [[0, 0, 9, 9], [9, 0, 18, 9], [10, 0, 19, 9]], [.9, .8, .7], [0, 0, 0], 0.05)
+    add("thr_exact", [[0, 0, 9, 9], [0, 0, 9, 2]], [.9, .8], [0, 0], 0.3)   # iou = 30/100 = 0.3 -> NOT > thr
+    add("negative_coords", [[-5, -5, 5, 5], [-4, -4, 6, 6], [-50, -50, -40, -40]], [.6, .7, .5], [2, 2, 2], 0.3)
+    rs = np.random.RandomState(3)
+    for n, ncls, thr in ((40, 3, 0.3), (300, 5, 0.45), (1500, 80, 0.3), (700, 1, 0.5)):
+        c = rs.randint(0, 400, size=(n, 2))
+        wh = rs.randint(2, 120, size=(n, 2))
+        boxes = np.concatenate([c - wh // 2, c + wh // 2], axis=1)
+        prob = rs.permutation(n).astype(np.float32) / n * 0.9 + 0.05      # distinct scores
+        cls = rs.randint(0, ncls, size=n).tolist()
+        add("random_n%d_c%d" % (n, ncls), boxes, prob, cls, thr)
+    with open(os.path.join(GOLD, "nms_cases.json"), "w") as fh:
+        json.dump(cases, fh)
+    # the empty case raises inside the reference's per-class path only via inference(); record behaviour
+    print("G6 ok", [(c["name"], len(c["per_class"] or []), len(c["agnostic"])) for c in cases])
+
+
+if __name__ == "__main__":
+    which = set(sys.argv[1:]) or {"g2", "g3", "g4", "g5", "g6", "g7"}
+    torch.manual_seed(0)
+    if "g2" in which:
+        g2_parse_config()
+    if "g3" in which:
+        g3_mini_blocks()
+    if "g4" in which:
+        g4_yolo_layer()
+    if "g6" in which:
+        g6_nms()
+    if "g5" in which or "g7" in which:
+        for model in MODELS:
+            net = make_net(model)
+            if "g5" in which:
+                g5_forward(model, net)
+            if "g7" in which:
+                g7_inference(model, net)
