@@ -71,7 +71,7 @@ class _CompiledPlan(object):
 
 
 class Darknet(object):
-    def __init__(self, config_fpath, device="cuda", dtype="float32"):
+    def __init__(self, config_fpath, device="cuda", dtype="float32", keep_all=False):
         """
         Args:
             config_fpath (str): Darknet .cfg file.
@@ -84,6 +84,7 @@ class Darknet(object):
         if self.net_info is None:
             raise ValueError("cfg {!r} has no [net] section".format(config_fpath))
         self.config_fpath = config_fpath
+        self.keep_all = bool(keep_all)   # debugging: no arena reuse, so block_output() works
         self.device = device
         self.header = None
         self.training = False
@@ -220,7 +221,7 @@ class Darknet(object):
         lib = _hip.lib()
         bf16 = self.dtype == "bf16"
         es = 2 if bf16 else 4
-        desc = build_plan(self.blocks, self.net_info, batch, height, width, es)
+        desc = build_plan(self.blocks, self.net_info, batch, height, width, es, reuse=not self.keep_all)
         cp = _CompiledPlan()
         cp.batch = batch
         cp.rows_total = desc["rows_total"]
@@ -374,6 +375,22 @@ class Darknet(object):
         if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4:
             raise ValueError("expected uint8 (B,H,W,3) frames")
         return self._run(frames_u8.to(dev).contiguous(), "u8", fresh=fresh)
+
+    def block_output(self, i):
+        """(B,C,H,W) float32 copy of block i's output from the last forward.  Needs
+        ``keep_all=True`` (otherwise the arena slot may have been reused)."""
+        if not self.keep_all:
+            raise RuntimeError("construct Darknet(..., keep_all=True) to inspect intermediate tensors")
+        cp = self._last_plan
+        t = cp.desc["tensor_of"][i]
+        if t is None:
+            raise ValueError("block {} is fused into its consumer and never materialised".format(i))
+        es = 4 if (t.f32 or self.dtype != "bf16") else 2
+        start = cp.desc["offsets"][t.buf]
+        nelem = cp.batch * t.h * t.w * t.ld
+        raw = cp.arena[start:start + nelem * es]
+        arr = raw.view(torch.float32 if es == 4 else torch.bfloat16).reshape(cp.batch, t.h, t.w, t.ld)
+        return arr[:, :, :, t.off:t.off + t.c].permute(0, 3, 1, 2).float().contiguous()
 
     def plan_report(self):
         """Per-op (kernel name, flops, bytes, block) of the last executed plan (for bench/profiling)."""

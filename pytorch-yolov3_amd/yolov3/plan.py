@@ -78,7 +78,7 @@ def infer_shapes(blocks, net_info, height, width):
     return shapes
 
 
-def build_plan(blocks, net_info, batch, height, width, elem_size):
+def build_plan(blocks, net_info, batch, height, width, elem_size, reuse=True):
     """Resolve the graph.  ``blocks`` must already carry absolute route indices.
 
     Returns dict(ops=[...], buffers={id: nbytes}, offsets={id: arena offset}, arena_bytes,
@@ -276,8 +276,10 @@ def build_plan(blocks, net_info, batch, height, width, elem_size):
     for t in range(len(ops)):
         for buf in by_first.get(t, []):
             offsets[buf] = alloc(nbytes[buf])
-        for buf in by_last.get(t, []):
-            release(offsets[buf], nbytes[buf])
+        if reuse:
+            for buf in by_last.get(t, []):
+                release(offsets[buf], nbytes[buf])
 
     return dict(ops=ops, buffers=nbytes, offsets=offsets, arena_bytes=max(top, ALIGN),
-                rows_total=rows_total, shapes=shapes, n_convs=conv_slot, live=(first, last))
+                rows_total=rows_total, shapes=shapes, n_convs=conv_slot, live=(first, last),
+                tensor_of=tensor_of)

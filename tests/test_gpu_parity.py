@@ -1,0 +1,220 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the golden vectors generated from
+the reference and against the CPU oracle on the same seeded inputs.  Need an MI355X: -m gpu."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import yolov3
+from oracle import darknet_oracle as orc
+from yolov3 import weights as W
+from yolov3.preprocess import resize_bilinear_u8
+from yolov3.synthdata import synth_frames
+
+from golden_util import (GOLDEN, MODELS, MODEL_DIMS, compare_detections, golden_params, golden_weights_path,
+                         load_jpeg_bgr, sha)
+
+pytestmark = pytest.mark.gpu
+
+# float32 parity bars (BASELINE.json north_star: box coords and scores within 1e-3 fp32)
+BOX_ATOL = 1e-3
+SCORE_ATOL = 1e-3
+
+
+def _net(model, dtype="float32", **kw):
+    net = yolov3.Darknet(MODELS[model], device="cuda", dtype=dtype, **kw)
+    if model == "mini":
+        net.set_params(golden_params("mini"))
+    else:
+        net.load_weights(golden_weights_path(model))
+    return net.eval()
+
+
+def test_library_reports_gfx950():
+    from yolov3 import _hip
+    assert _hip.lib().y3_device_count() >= 1
+
+
+def test_cxywh_to_tlbr_known_answer():
+    xywh = np.array([[5, 8, 10, 13, 10000], [100, 200, 30, 17, 19000]], dtype=np.int64)
+    want = np.array([[0, 2, 10, 14, 10000], [85, 192, 115, 208, 19000]])
+    assert (yolov3.cxywh_to_tlbr(xywh) == want).all()
+    neg = np.array([[-3, 4, 5, 7]], dtype=np.int64)
+    assert (yolov3.cxywh_to_tlbr(neg) == orc.cxywh_to_tlbr(neg)).all()
+
+
+def test_mini_every_block_fp32():
+    g = np.load(os.path.join(GOLDEN, "mini_blocks.npz"))
+    net = _net("mini", keep_all=True)
+    out = net.forward(torch.from_numpy(g["input"]))
+    worst = {}
+    for i, blk in enumerate(net.blocks):
+        key = "block_%d" % i
+        if key not in g.files or blk["type"] == "yolo":
+            continue
+        try:
+            got = net.block_output(i).cpu().numpy()
+        except ValueError:
+            continue  # fused away (conv feeding a shortcut)
+        err = np.abs(got - g[key]).max()
+        worst[i] = float(err)
+        np.testing.assert_allclose(got, g[key], rtol=1e-4, atol=2e-5, err_msg="%s (%s)" % (key, blk["type"]))
+    assert len(worst) >= 20
+    np.testing.assert_allclose(out["bbox_xywh"].cpu().numpy(), g["bbox_xywh"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["class_prob"].cpu().numpy(), g["class_prob"], rtol=1e-4, atol=1e-6)
+    assert out["class_idx"].dtype == torch.int64
+    assert (out["class_idx"].cpu().numpy() == g["class_idx"]).mean() > 0.999
+
+
+def test_mini_u8_frames_match_f32_input():
+    g = np.load(os.path.join(GOLDEN, "mini_blocks.npz"))
+    net = _net("mini")
+    a = net.forward(torch.from_numpy(g["input"]))
+    b = net.forward_frames(g["frames"])
+    for k in ("bbox_xywh", "class_prob", "class_idx"):
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_mini_bf16_close_to_fp32():
+    g = np.load(os.path.join(GOLDEN, "mini_blocks.npz"))
+    net = _net("mini", dtype="bf16")
+    out = net.forward(torch.from_numpy(g["input"]))
+    dp = np.abs(out["class_prob"].cpu().numpy() - g["class_prob"])
+    assert np.isfinite(out["bbox_xywh"].cpu().numpy()).all()
+    assert np.median(dp) < 5e-3 and dp.max() < 0.3
+
+
+@pytest.mark.parametrize("model", ["yolov3-tiny", "yolov3", "yolov3-spp"])
+def test_forward_golden_fp32(model):
+    g = np.load(os.path.join(GOLDEN, "forward_%s.npz" % model))
+    dim = MODEL_DIMS[model]
+    frames = np.stack([resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), dim, dim),
+                       synth_frames(5, 1, dim, dim)[0]])
+    assert [sha(f) for f in frames] == g["frames_sha"].tolist(), "input frames differ from the golden run"
+    net = _net(model)
+    out = net.forward(torch.from_numpy(orc.frames_to_input(list(frames))))
+    bb = out["bbox_xywh"].cpu().numpy()
+    pr = out["class_prob"].cpu().numpy()
+    ci = out["class_idx"].cpu().numpy()
+    assert bb.shape == g["bbox_xywh"].shape and ci.dtype == np.int64
+    print("max |dbox| %.3g  max |dscore| %.3g" % (np.abs(bb - g["bbox_xywh"]).max(), np.abs(pr - g["class_prob"]).max()))
+    np.testing.assert_allclose(bb, g["bbox_xywh"], rtol=1e-4, atol=BOX_ATOL)
+    np.testing.assert_allclose(pr, g["class_prob"], atol=SCORE_ATOL)
+    flips = (ci != g["class_idx"]) & (g["cls_margin"] >= 1e-4)
+    assert flips.sum() == 0, "%d arg-max flips on clear margins" % flips.sum()
+    # the uint8 entry point (fused preprocessing) gives the same answer
+    out8 = net.forward_frames(frames)
+    assert torch.equal(out8["class_idx"], out["class_idx"])
+    np.testing.assert_allclose(out8["bbox_xywh"].cpu().numpy(), bb, atol=1e-6)
+
+
+@pytest.mark.parametrize("model", ["yolov3-tiny", "yolov3", "yolov3-spp"])
+def test_inference_golden_fp32(model):
+    g = np.load(os.path.join(GOLDEN, "inference_%s.npz" % model))
+    dim = MODEL_DIMS[model]
+    frames = [load_jpeg_bgr("000000229358.jpg"), synth_frames(9, 1, dim, dim)[0], load_jpeg_bgr("000000393569.jpg")]
+    assert [sha(f) for f in frames] == g["frames_sha"].tolist()
+    net = _net(model)
+    for tag in ("a", "b"):
+        pth, ith = g[tag + "_thresholds"]
+        res = yolov3.inference(net, frames, device="cuda", prob_thresh=float(pth), nms_iou_thresh=float(ith),
+                               return_rows=True)
+        assert len(res) == len(frames)
+        for f in range(len(frames)):
+            ndiff, nbad = compare_detections(g, "%s_f%d_" % (tag, f), res[f][:3], rows=res[f][3], prob_tol=SCORE_ATOL)
+            print(model, tag, f, "kept", len(res[f][1]), "keep-set diff", ndiff, "fragile box diffs", nbad)
+
+
+def test_inference_single_frame_and_empty_result():
+    net = _net("yolov3-tiny")
+    frame = synth_frames(3, 1, 416, 416)[0]
+    res = yolov3.inference(net, frame, prob_thresh=0.999)   # nothing passes
+    assert len(res) == 1
+    tlbr, prob, cls = res[0]
+    assert tlbr.shape == (0, 4) and prob.shape == (0,) and cls.shape == (0,)
+    assert tlbr.dtype == np.int64 and cls.dtype == np.int64 and prob.dtype == np.float32
+
+
+def test_gpu_matches_oracle_on_fresh_input():
+    """Not a golden: same seeded input through the oracle (CPU) and the HIP path."""
+    net = _net("yolov3-tiny")
+    ref = orc.OracleDarknet(MODELS["yolov3-tiny"]).load_weights(golden_weights_path("yolov3-tiny"))
+    frames = synth_frames(21, 2, 320, 416)          # non-square, not the cfg size
+    x = torch.from_numpy(orc.frames_to_input(list(frames)))
+    want = ref.forward(x)
+    got = net.forward(x)
+    np.testing.assert_allclose(got["bbox_xywh"].cpu().numpy(), want["bbox_xywh"].numpy(), rtol=1e-4, atol=BOX_ATOL)
+    np.testing.assert_allclose(got["class_prob"].cpu().numpy(), want["class_prob"].numpy(), atol=SCORE_ATOL)
+    agree = (got["class_idx"].cpu().numpy() == want["class_idx"].numpy()).mean()
+    assert agree > 0.999
+    dets_ref = orc.postprocess(want["bbox_xywh"].numpy(), want["class_prob"].numpy(), want["class_idx"].numpy(),
+                               [f.shape for f in frames], 0.05, 0.3)
+    dets = yolov3.inference(net, list(frames), prob_thresh=0.05, nms_iou_thresh=0.3, resize=False)
+    for a, b in zip(dets, dets_ref):
+        assert abs(len(a[1]) - len(b[1])) <= 2
+
+
+def test_nms_cases_match_reference():
+    with open(os.path.join(GOLDEN, "nms_cases.json")) as fh:
+        cases = json.load(fh)
+    for c in cases:
+        boxes = np.array(c["boxes"], dtype=np.int64).reshape(-1, 4)
+        prob = np.array(c["prob_bits"], dtype=np.uint32).view(np.float32)
+        ties = len(set(prob.tolist())) != len(prob)
+        got = yolov3.non_max_suppression(boxes, prob, iou_thresh=c["thr"])
+        assert isinstance(got, list)
+        if not ties:
+            assert sorted(got) == sorted(c["agnostic"]), c["name"]
+            # class-agnostic order is pure score order in both implementations
+            assert got == c["agnostic"], c["name"]
+        if c["cls"] is not None:
+            got = yolov3.non_max_suppression(boxes, prob, class_idx=np.array(c["cls"]), iou_thresh=c["thr"])
+            if not ties:
+                assert sorted(got) == sorted(c["per_class"]), c["name"]
+    assert yolov3.non_max_suppression(np.zeros((0, 4), dtype=np.int64), np.zeros(0, dtype=np.float32)) == []
+
+
+@pytest.mark.parametrize("n,ncls", [(5000, 1), (9000, 3), (20000, 80)])
+def test_nms_large_matches_oracle(n, ncls):
+    """Sizes past the in-LDS sort limit (4096) and a single crowded class."""
+    rs = np.random.RandomState(n)
+    c = rs.randint(0, 2000, size=(n, 2))
+    wh = rs.randint(2, 200, size=(n, 2))
+    boxes = np.concatenate([c - wh // 2, c + wh // 2], axis=1).astype(np.int64)
+    prob = (rs.permutation(n).astype(np.float32) + 1) / (n + 1)
+    cls = rs.randint(0, ncls, size=n).astype(np.int64)
+    want = orc.non_max_suppression(boxes, prob, class_idx=cls, iou_thresh=0.4)
+    got = yolov3.non_max_suppression(boxes, prob, class_idx=cls, iou_thresh=0.4)
+    assert sorted(got) == sorted(int(i) for i in want)
+
+
+@pytest.mark.parametrize("model,dim,batch", [(m, d, b) for m in ("yolov3", "yolov3-tiny", "yolov3-spp")
+                                             for d in (320, 416, 608) for b in (1, 2)])
+def test_shape_sweep_bf16(model, dim, batch):
+    """The reference's own 18-case smoke sweep (tests/test_darknet.py:10-27), plus shape asserts."""
+    net = _net(model, dtype="bf16")
+    x = torch.rand(batch, 3, dim, dim, generator=torch.Generator().manual_seed(dim + batch))
+    out = net.forward(x)
+    cells = sum((dim // s) ** 2 for s in ((32, 16) if model == "yolov3-tiny" else (32, 16, 8)))
+    assert out["bbox_xywh"].shape == (batch, 3 * cells, 4)
+    assert out["class_prob"].shape == (batch, 3 * cells) and out["class_idx"].shape == (batch, 3 * cells)
+    assert torch.isfinite(out["bbox_xywh"]).all() and torch.isfinite(out["class_prob"]).all()
+    assert int(out["class_idx"].min()) >= 0 and int(out["class_idx"].max()) < 80
+
+
+def test_bf16_agreement_report_yolov3():
+    """bf16 is the throughput path, not a parity path: report (and loosely bound) its agreement
+    with the fp32 HIP path on the golden frames."""
+    g = np.load(os.path.join(GOLDEN, "forward_yolov3.npz"))
+    dim = 608
+    frames = np.stack([resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), dim, dim), synth_frames(5, 1, dim, dim)[0]])
+    out = _net("yolov3", dtype="bf16").forward_frames(frames)
+    pr = out["class_prob"].cpu().numpy()
+    ci = out["class_idx"].cpu().numpy()
+    d = np.abs(pr - g["class_prob"])
+    agree = (ci == g["class_idx"]).mean()
+    print("bf16 vs reference fp32: score |d| median %.2e p99 %.2e max %.2e; arg-max agreement %.4f" % (
+        np.median(d), np.percentile(d, 99), d.max(), agree))
+    assert np.isfinite(pr).all() and np.median(d) < 2e-2 and agree > 0.5
