@@ -46,7 +46,22 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--profile-passes", type=int, default=3)
+    ap.add_argument("--dump-ops", default=None, help="write the per-op timing table (text) to this file")
     return ap.parse_args()
+
+
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota (the GPU
+    boxes expose 256 hardware threads but grant a 16-CPU quota; 256 torch threads would thrash)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def main():
@@ -132,6 +147,15 @@ def main():
             k["flops"] += op["flops"]
             k["bytes"] += op["bytes"]
             k["launches"] += 1
+        if args.dump_ops:
+            desc = net._last_plan.desc["ops"]
+            with open(args.dump_ops, "w") as fh:
+                fh.write("%4s %5s %-28s %-34s %9s %9s %9s\n" % ("op", "block", "kernel", "shape", "ms", "TFLOP/s", "GB/s"))
+                for i, (op, ms, od) in enumerate(zip(plan, per_op, desc)):
+                    ti, to = od["inp"], od.get("out")
+                    shape = "%dx%dx%d" % (ti.h, ti.w, ti.c) + ("->%dx%dx%d k%d s%d" % (to.h, to.w, to.c, od.get("ksize", 0), od.get("stride", 0)) if to is not None else "")
+                    fh.write("%4d %5d %-28s %-34s %9.4f %9.1f %9.1f\n" % (
+                        i, op["block"], op["kernel"], shape, ms, op["flops"] / max(ms, 1e-9) / 1e9, op["bytes"] / max(ms, 1e-9) / 1e6))
         dominant = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
         dk = by_kernel[dominant]
         achieved = dk["flops"] / (dk["ms"] * 1e-3) / 1e12
@@ -143,7 +167,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import darknet_oracle as orc
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(usable_cpus())
         onet = orc.OracleDarknet(cfg).set_params(params)
         cpu_frames = [f for f in synth_frames(123, args.cpu_frames, dim, dim)]
         orc.inference(onet, cpu_frames[:1], 0.05, 0.3)           # warm-up

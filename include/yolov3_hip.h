@@ -124,6 +124,11 @@ double y3_plan_op_bytes(const y3_plan *plan, int op_index);
  * layout as 0); -1 if `op` is not a conv.  The host lays weights out accordingly.             */
 int y3_conv_path(const y3_op *op);
 
+/* process-wide tuning knob for A/B measurements: "igemm_version" (1 register-staged, 2 LDS-DMA
+ * double-buffered [default]), "igemm_bm" (0 heuristic, 256 = 8-wave 256x128 tile).  Results do not
+ * depend on the knobs beyond floating-point summation order.                                   */
+int y3_set_tuning(const char *key, int value);
+
 /* single op (unit tests): same dispatch as inside a plan */
 int y3_op_run(const y3_op *op, const void *d_input, const void *d_zero, void *stream);
 

@@ -17,6 +17,8 @@
 // LDS image per operand: [rows][128 B], 16-byte chunks XOR-swizzled by (row & 7) so that the
 // ds_read_b128 fragment reads (16 rows x one chunk column per lane group) are conflict-free.
 // Padding taps and M-tail rows read a zero page instead of branching.
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -257,6 +259,265 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v2: LDS-DMA pipeline.  Same tile geometry and LDS image as above, but
+//   * operands go global -> LDS directly (global_load_lds_dwordx4, 16 B per lane, 1 KiB per wave
+//     instruction): no staging VGPRs, no ds_write pass; the XOR swizzle is applied on the per-lane
+//     SOURCE address, the destination stays lane-linear (cdna_hip_programming.md rule 21);
+//   * two LDS stages, one barrier per K-tile: tile k+1 streams in while tile k feeds the MFMAs;
+//   * epilogue through LDS: the fp32 tile is parked in the (now idle) operand stages and written out
+//     as whole 16-byte NHWC chunks (a pixel's channels are contiguous), residual read the same way.
+// KMODE 0: Cin % BKE == 0 (one tap per K-tile)   1: any Cin % CE == 0 (per-chunk tap, slow)
+//       2: BKE % Cin == 0, Cin < BKE (several whole taps per K-tile, e.g. Cin = 32 with bf16)
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KMODE>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(IgemmArgs p) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int ES = sizeof(T);
+  constexpr int CE = 16 / ES;
+  constexpr int BKE = 128 / ES;
+  constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
+  constexpr int MI = TM / 16, NI = TN / 16;
+  constexpr int ROWS_PER_PASS = NT / 8;
+  constexpr int A_CH = BM / ROWS_PER_PASS, B_CH = BN / ROWS_PER_PASS;
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(MI >= 1 && NI >= 1 && A_CH >= 1 && B_CH >= 1, "tile too small");
+  // the fp32 output tile is written out in EP passes of RP pixel rows each (it must fit in the stages)
+  constexpr int EP = (BM * BN * 4 + 2 * STAGE - 1) / (2 * STAGE) <= 1 ? 1 : 2;
+  constexpr int RP = BM / EP;
+  static_assert(RP * BN * 4 <= 2 * STAGE && RP % TM == 0, "epilogue tile must fit in the operand stages");
+
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / p.n_tiles) * BM;
+  const int n0 = (tile % p.n_tiles) * BN;
+
+  const int slot = tid & 7;
+  const int row0 = tid >> 3;
+  const int kc = slot ^ (row0 & 7);
+
+  const char *a_base[A_CH];
+  uint32_t a_taps[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int m = m0 + row0 + ROWS_PER_PASS * i;
+    a_base[i] = p.zero;
+    a_taps[i] = 0u;
+    if (m < p.M) {
+      const int b = m / p.HoWo;
+      const int rem = m - b * p.HoWo;
+      const int oy = rem / p.Wo;
+      const int ox = rem - oy * p.Wo;
+      const int iy0 = oy * p.stride - p.pad;
+      const int ix0 = ox * p.stride - p.pad;
+      const long long pix = ((long long)b * p.H + iy0) * p.W + ix0;
+      a_base[i] = p.in + pix * p.in_ld * ES + (KMODE == 0 ? kc * 16 : 0);
+      uint32_t mask = 0u;
+      for (int ky = 0; ky < p.ks; ++ky)
+        for (int kx = 0; kx < p.ks; ++kx) {
+          const bool ok = (unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W;
+          mask |= (ok ? 1u : 0u) << (ky * p.ks + kx);
+        }
+      a_taps[i] = mask;
+    }
+  }
+  const char *b_base[B_CH];
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i)
+    b_base[i] = p.wgt + ((long long)(n0 + row0 + ROWS_PER_PASS * i) * p.k_ld) * ES + kc * 16;
+
+  // multi-tap mode: this lane's tap slot inside a K-tile and its channel offset inside the tap
+  int tl = 0, cc = 0, tpt = 1;
+  if constexpr (KMODE == 2) {
+    const int cpt = p.Cin / CE;  // chunks per tap (power of two because BKE % Cin == 0)
+    tpt = 8 / cpt;
+    tl = kc / cpt;
+    cc = kc - tl * cpt;
+  }
+
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void gbl_void;
+
+  auto issue = [&](int kt, int stage) {
+    char *sA = smem + stage * STAGE;
+    char *sB = sA + BM * 128;
+    long long tap_off;
+    int tap;
+    bool in_k = true;
+    if constexpr (KMODE == 0) {
+      tap = kt / p.ktiles_per_tap;
+      const int ci0 = (kt - tap * p.ktiles_per_tap) * BKE;
+      const int ky = tap / p.ks, kx = tap - ky * p.ks;
+      tap_off = ((long long)(ky * p.W + kx) * p.in_ld + ci0) * ES;
+    } else if constexpr (KMODE == 2) {
+      tap = kt * tpt + tl;
+      const int ky = tap / p.ks, kx = tap - ky * p.ks;
+      tap_off = ((long long)(ky * p.W + kx) * p.in_ld + cc * CE) * ES;
+      in_k = tap < p.ks * p.ks;
+    } else {
+      const int ke = kt * BKE + kc * CE;
+      tap = ke / p.Cin;
+      const int ci = ke - tap * p.Cin;
+      const int ky = tap / p.ks, kx = tap - ky * p.ks;
+      tap_off = ((long long)(ky * p.W + kx) * p.in_ld + ci) * ES;
+      in_k = ke < p.K;
+    }
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const bool ok = in_k && ((a_taps[i] >> tap) & 1u);
+      const char *src = ok ? a_base[i] + tap_off : p.zero;
+      __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(sA + wave * 1024 + i * (NT * 16)), 16, 0, 0);
+    }
+    const long long koff = (long long)kt * 128;
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void *)(b_base[i] + koff), (lds_void *)(sB + wave * 1024 + i * (NT * 16)), 16, 0, 0);
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+
+  issue(0, 0);
+  for (int kt = 0; kt < p.n_ktiles; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt has landed (this wave's pieces)
+    __syncthreads();                                   // ... everyone's; stage cur^1 is free again
+    if (kt + 1 < p.n_ktiles) issue(kt + 1, cur ^ 1);
+    const char *sA = smem + cur * STAGE;
+    const char *sB = sA + BM * 128;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      u32x4 xf[MI], wf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * TM + mi * 16 + fr;
+        xf[mi] = *reinterpret_cast<const u32x4 *>(sA + row * 128 + (((g * 4 + fq) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int row = wn * TN + ni * 16 + fr;
+        wf[ni] = *reinterpret_cast<const u32x4 *>(sB + row * 128 + (((g * 4 + fq) ^ (row & 7)) << 4));
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], wf[ni], xf[mi]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  __syncthreads();  // all MFMA operand reads done: the stages can hold the output tile
+
+  // ---- epilogue: scale/bias/activation in registers, park the fp32 tile in LDS, then write it out
+  // as whole 16-byte chunks.  Tile row = pixel (BN floats); its 16-byte chunk index is XOR-ed with
+  // the pixel so that the 16 lanes holding the same channels of 16 pixels hit different banks.
+  constexpr int CPR = BN / 4;  // 16-byte chunks per tile row
+  constexpr int SWZ = (CPR < 16 ? CPR : 16) - 1;
+  constexpr int OCT_PER_ROW = BN / 8;
+  float *sC = reinterpret_cast<float *>(smem);
+  const bool leaky = p.flags & Y3_F_LEAKY;
+  const bool has_res = p.flags & Y3_F_RESIDUAL;
+  const bool out_f32 = (p.flags & Y3_F_OUT_F32) || sizeof(T) == 4;
+#pragma unroll
+  for (int h = 0; h < EP; ++h) {
+    if (h > 0) __syncthreads();
+    if ((wm * TM) / RP == h) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int cl = wn * TN + ni * 16 + fq * 4;  // channel inside the tile (multiple of 4)
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + n0 + cl);
+        const f32x4 bi = *reinterpret_cast<const f32x4 *>(p.bias + n0 + cl);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int pl = wm * TM + mi * 16 + fr - h * RP;
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t = acc[mi][ni][r] * sc[r] + bi[r];
+            if (leaky) t = t > 0.f ? t : Y3_LEAKY_SLOPE * t;
+            v[r] = t;
+          }
+          *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = v;
+        }
+      }
+    }
+    __syncthreads();
+    for (int o = tid; o < RP * OCT_PER_ROW; o += NT) {
+      const int pl = o / OCT_PER_ROW, oc = o - pl * OCT_PER_ROW;
+      const int m = m0 + h * RP + pl;
+      const int co = n0 + oc * 8;
+      if (m >= p.M || co >= p.Cout) continue;
+      const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc) ^ (pl & SWZ)) << 2));
+      const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc + 1) ^ (pl & SWZ)) << 2));
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      const int nvalid = p.Cout - co < 8 ? p.Cout - co : 8;
+      if (has_res) {
+        const T *rp = reinterpret_cast<const T *>(p.res) + (long long)m * p.res_ld + co;
+        if (nvalid == 8 && (p.res_ld % CE) == 0) {
+          if constexpr (sizeof(T) == 2) {
+            const bf16x8 rv = *reinterpret_cast<const bf16x8 *>(rp);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+          } else {
+            const f32x4 r0 = *reinterpret_cast<const f32x4 *>(rp), r1 = *reinterpret_cast<const f32x4 *>(rp + 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+          }
+        } else {
+          for (int r = 0; r < nvalid; ++r) v[r] += y3_to_float<T>(rp[r]);
+        }
+      }
+      if (out_f32) {
+        float *op = reinterpret_cast<float *>(p.out) + (long long)m * p.out_ld + co;
+        if (nvalid == 8) {
+          *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          for (int r = 0; r < nvalid; ++r) op[r] = v[r];
+        }
+      } else {
+        T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
+        bool done = false;
+        if constexpr (sizeof(T) == 2) {
+          if (nvalid == 8 && (p.out_ld % 8) == 0) {
+            bf16x8 ov;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) ov[r] = (bf16_t)v[r];
+            *reinterpret_cast<bf16x8 *>(op) = ov;
+            done = true;
+          }
+        }
+        if (!done)
+          for (int r = 0; r < nvalid; ++r) op[r] = y3_from_float<T>(v[r]);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_cfg2(const IgemmArgs &a0, int kmode, hipStream_t s) {
+  IgemmArgs a = a0;
+  a.m_tiles = y3_ceil_div(a.M, BM);
+  a.n_tiles = y3_ceil_div(a.Cout, BN);
+  const dim3 grid(a.m_tiles * a.n_tiles), block(64 * WM * WN);
+  if (kmode == 0) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 0>), grid, block, 0, s, a);
+  else if (kmode == 2) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 2>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 1>), grid, block, 0, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const IgemmArgs &a0, bool generic, hipStream_t s) {
   IgemmArgs a = a0;
@@ -287,6 +548,18 @@ bool y3_conv_igemm_supported(const y3_op &op) {
   return true;
 }
 
+// process-wide tuning knobs (y3_set_tuning): kernel generation and tile override, for A/B runs
+static int g_igemm_version = 2;   // 1 = register-staged single buffer, 2 = LDS-DMA double buffer
+static int g_igemm_bm = 0;        // 0 = heuristic, else 128 / 256 (256 = 8-wave tile, v2 bf16 only)
+
+extern "C" int y3_set_tuning(const char *key, int value) {
+  if (!key) return Y3_ERR_INVALID;
+  if (!strcmp(key, "igemm_version")) { g_igemm_version = value; return Y3_OK; }
+  if (!strcmp(key, "igemm_bm")) { g_igemm_bm = value; return Y3_OK; }
+  y3_set_error("y3_set_tuning: unknown key %s", key);
+  return Y3_ERR_INVALID;
+}
+
 int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
                          const char **kernel_name, bool dry_run) {
   Y3_REQUIRE(y3_conv_igemm_supported(op), "conv block %d: shape not supported by the igemm kernel",
@@ -308,25 +581,53 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
   a.M = op.batch * a.HoWo;
   a.k_ld = op.k_ld;
   a.K = op.ksize * op.ksize * op.in_c;
-  const bool generic = (op.in_c % bke) != 0;
-  a.ktiles_per_tap = generic ? 0 : op.in_c / bke;
-  a.n_ktiles = generic ? y3_ceil_div(a.K, bke) : op.ksize * op.ksize * a.ktiles_per_tap;
+  // K-tiling mode: 0 one tap per tile, 2 several whole taps per tile, 1 per-chunk taps
+  int kmode = 1;
+  if (op.in_c % bke == 0) kmode = 0;
+  else if (bke % op.in_c == 0) kmode = 2;
+  a.ktiles_per_tap = kmode == 0 ? op.in_c / bke : 0;
+  if (kmode == 0) a.n_ktiles = op.ksize * op.ksize * a.ktiles_per_tap;
+  else if (kmode == 2) a.n_ktiles = y3_ceil_div(op.ksize * op.ksize, bke / op.in_c);
+  else a.n_ktiles = y3_ceil_div(a.K, bke);
+  Y3_REQUIRE(a.n_ktiles * bke <= op.k_ld, "conv block %d: k_ld %d too small for %d K-tiles", op.block_idx, op.k_ld, a.n_ktiles);
   a.m_tiles = a.n_tiles = 0;
   a.flags = op.flags;
 
   const bool bf = op.dtype == Y3_BF16;
   // channel-tile width follows Cout so narrow layers do not multiply zero padding
-  int bn = op.out_c > 64 ? 128 : (op.out_c > 32 ? 64 : 32);
-  if (bn == 128) {
-    *kernel_name = bf ? "conv_igemm_bf16_128x128" : "conv_igemm_f32_128x128";
+  const int bn = op.out_c > 64 ? 128 : (op.out_c > 32 ? 64 : 32);
+  // float32-output (detection head) convs: the direct epilogue of v1 measured faster
+  if (g_igemm_version == 1 || (g_igemm_version == 2 && bf && (op.flags & Y3_F_OUT_F32))) {
+    const bool generic = kmode != 0;
+    if (generic) a.n_ktiles = y3_ceil_div(a.K, bke);
+    if (bn == 128) {
+      *kernel_name = bf ? "conv_igemm_bf16_128x128" : "conv_igemm_f32_128x128";
+      if (dry_run) return Y3_OK;
+      return bf ? launch_cfg<bf16_t, 128, 128, 2, 2>(a, generic, s) : launch_cfg<float, 128, 128, 2, 2>(a, generic, s);
+    } else if (bn == 64) {
+      *kernel_name = bf ? "conv_igemm_bf16_128x64" : "conv_igemm_f32_128x64";
+      if (dry_run) return Y3_OK;
+      return bf ? launch_cfg<bf16_t, 128, 64, 2, 2>(a, generic, s) : launch_cfg<float, 128, 64, 2, 2>(a, generic, s);
+    }
+    *kernel_name = bf ? "conv_igemm_bf16_128x32" : "conv_igemm_f32_128x32";
     if (dry_run) return Y3_OK;
-    return bf ? launch_cfg<bf16_t, 128, 128, 2, 2>(a, generic, s) : launch_cfg<float, 128, 128, 2, 2>(a, generic, s);
-  } else if (bn == 64) {
-    *kernel_name = bf ? "conv_igemm_bf16_128x64" : "conv_igemm_f32_128x64";
-    if (dry_run) return Y3_OK;
-    return bf ? launch_cfg<bf16_t, 128, 64, 2, 2>(a, generic, s) : launch_cfg<float, 128, 64, 2, 2>(a, generic, s);
+    return bf ? launch_cfg<bf16_t, 128, 32, 4, 1>(a, generic, s) : launch_cfg<float, 128, 32, 4, 1>(a, generic, s);
   }
-  *kernel_name = bf ? "conv_igemm_bf16_128x32" : "conv_igemm_f32_128x32";
+  if (bn == 128) {
+    if (bf && g_igemm_bm == 256) {
+      *kernel_name = "conv_igemm2_bf16_256x128";
+      if (dry_run) return Y3_OK;
+      return launch_cfg2<bf16_t, 256, 128, 4, 2>(a, kmode, s);
+    }
+    *kernel_name = bf ? "conv_igemm2_bf16_128x128" : "conv_igemm2_f32_128x128";
+    if (dry_run) return Y3_OK;
+    return bf ? launch_cfg2<bf16_t, 128, 128, 2, 2>(a, kmode, s) : launch_cfg2<float, 128, 128, 2, 2>(a, kmode, s);
+  } else if (bn == 64) {
+    *kernel_name = bf ? "conv_igemm2_bf16_128x64" : "conv_igemm2_f32_128x64";
+    if (dry_run) return Y3_OK;
+    return bf ? launch_cfg2<bf16_t, 128, 64, 2, 2>(a, kmode, s) : launch_cfg2<float, 128, 64, 2, 2>(a, kmode, s);
+  }
+  *kernel_name = bf ? "conv_igemm2_bf16_128x32" : "conv_igemm2_f32_128x32";
   if (dry_run) return Y3_OK;
-  return bf ? launch_cfg<bf16_t, 128, 32, 4, 1>(a, generic, s) : launch_cfg<float, 128, 32, 4, 1>(a, generic, s);
+  return bf ? launch_cfg2<bf16_t, 128, 32, 4, 1>(a, kmode, s) : launch_cfg2<float, 128, 32, 4, 1>(a, kmode, s);
 }

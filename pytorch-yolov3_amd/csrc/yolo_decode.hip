@@ -28,42 +28,65 @@ struct YoloArgs {
 
 __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// One workgroup decodes kPix consecutive pixels (all anchors).  The pixels' channel vectors are
+// contiguous in NHWC memory, so they are staged into LDS with fully coalesced 16-byte loads
+// (one wave instruction per pixel row of 256 floats); each (pixel, anchor) box is then decoded
+// by one thread out of LDS.  The LDS pixel stride is ld+1 floats so that the per-box reads
+// (stride n_attr floats between threads) spread over the banks.
+constexpr int kPix = 32;
+
 __global__ __launch_bounds__(256) void yolo_decode_kernel(YoloArgs p) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= p.total) return;
-  const int a = (int)(idx % p.n_anchor);
-  long long cell = idx / p.n_anchor;
-  const int x = (int)(cell % p.w);
-  cell /= p.w;
-  const int y = (int)(cell % p.h);
-  const int b = (int)(cell / p.h);
-  const float *t = p.in + (((long long)b * p.h + y) * p.w + x) * p.ld + a * p.n_attr;
-
-  const float bx = (sigmoidf_ref(t[0]) + (float)x) / (float)p.w;
-  const float by = (sigmoidf_ref(t[1]) + (float)y) / (float)p.h;
-  const float bw = (expf(t[2]) * p.aw[a]) / p.net_w;
-  const float bh = (expf(t[3]) * p.ah[a]) / p.net_h;
-  const float obj = sigmoidf_ref(t[4]);
-
-  const int ncls = p.n_attr - 5;
-  float mx = -INFINITY;
-  for (int c = 0; c < ncls; ++c) mx = fmaxf(mx, t[5 + c]);
-  float sum = 0.f, best = -1.f;
-  int best_c = 0;
-  for (int c = 0; c < ncls; ++c) {
-    const float e = expf(t[5 + c] - mx);
-    sum += e;
-    if (e > best) {  // strict: first index wins ties, like torch.max
-      best = e;
-      best_c = c;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int lds_ld = p.ld + 1;
+  const long long npix = (long long)p.B * p.h * p.w;
+  const long long pix0 = (long long)blockIdx.x * kPix;
+  const int chunks_per_pix = p.ld >> 2;
+  const int nchunks = kPix * chunks_per_pix;
+  for (int c = threadIdx.x; c < nchunks; c += 256) {
+    const int pl = c / chunks_per_pix, c4 = c - pl * chunks_per_pix;
+    if (pix0 + pl < npix) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(p.in + (pix0 + pl) * p.ld + c4 * 4);
+      float *d = sm + pl * lds_ld + c4 * 4;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
     }
   }
-  const float score = (best / sum) * obj;
+  __syncthreads();
+  const int nbox = kPix * p.n_anchor;
+  for (int t = threadIdx.x; t < nbox; t += 256) {
+    const int pl = t / p.n_anchor, a = t - pl * p.n_anchor;
+    const long long pix = pix0 + pl;
+    if (pix >= npix) continue;
+    const int x = (int)(pix % p.w);
+    const int y = (int)((pix / p.w) % p.h);
+    const int b = (int)(pix / ((long long)p.w * p.h));
+    const float *t_ = sm + pl * lds_ld + a * p.n_attr;
 
-  const long long row = (long long)b * p.rows_total + p.row_offset + (long long)a * p.h * p.w + (long long)y * p.w + x;
-  *reinterpret_cast<f32x4 *>(p.bbox + row * 4) = f32x4{bx, by, bw, bh};
-  p.prob[row] = score;
-  p.cls[row] = best_c;
+    const float bx = (sigmoidf_ref(t_[0]) + (float)x) / (float)p.w;
+    const float by = (sigmoidf_ref(t_[1]) + (float)y) / (float)p.h;
+    const float bw = (expf(t_[2]) * p.aw[a]) / p.net_w;
+    const float bh = (expf(t_[3]) * p.ah[a]) / p.net_h;
+    const float obj = sigmoidf_ref(t_[4]);
+
+    const int ncls = p.n_attr - 5;
+    float mx = -INFINITY;
+    for (int c = 0; c < ncls; ++c) mx = fmaxf(mx, t_[5 + c]);
+    float sum = 0.f, best = -1.f;
+    int best_c = 0;
+    for (int c = 0; c < ncls; ++c) {
+      const float e = expf(t_[5 + c] - mx);
+      sum += e;
+      if (e > best) {  // strict: first index wins ties, like torch.max
+        best = e;
+        best_c = c;
+      }
+    }
+    const float score = (best / sum) * obj;
+
+    const long long row = (long long)b * p.rows_total + p.row_offset + (long long)a * p.h * p.w + (long long)y * p.w + x;
+    *reinterpret_cast<f32x4 *>(p.bbox + row * 4) = f32x4{bx, by, bw, bh};
+    p.prob[row] = score;
+    p.cls[row] = best_c;
+  }
 }
 
 }  // namespace
@@ -72,7 +95,8 @@ int y3_launch_yolo(const y3_op &op, const void *d_in, hipStream_t s, const char 
                    bool dry_run) {
   Y3_REQUIRE(op.n_anchor >= 1 && op.n_anchor <= 8, "yolo block %d: 1..8 anchors per head", op.block_idx);
   Y3_REQUIRE(op.n_attr > 5 && op.n_anchor * op.n_attr <= op.in_ld, "yolo block %d: bad attribute count", op.block_idx);
-  Y3_REQUIRE(op.d_bbox && op.d_prob && op.d_cls, "yolo block %d: missing output pointers", op.block_idx);
+  Y3_REQUIRE(dry_run || (op.d_bbox && op.d_prob && op.d_cls), "yolo block %d: missing output pointers", op.block_idx);
+  Y3_REQUIRE(op.in_ld % 4 == 0 && op.in_ld <= 1024, "yolo block %d: pixel stride must be a multiple of 4 floats (<= 1024)", op.block_idx);
   YoloArgs a;
   a.in = static_cast<const float *>(d_in);
   a.bbox = op.d_bbox;
@@ -86,7 +110,9 @@ int y3_launch_yolo(const y3_op &op, const void *d_in, hipStream_t s, const char 
   a.total = (long long)op.batch * op.in_h * op.in_w * op.n_anchor;
   *kernel_name = "yolo_decode_f32";
   if (dry_run) return Y3_OK;
-  hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, s, a);
+  const long long npix = (long long)op.batch * op.in_h * op.in_w;
+  const size_t lds = (size_t)kPix * (op.in_ld + 1) * sizeof(float);
+  hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)((npix + kPix - 1) / kPix)), dim3(256), lds, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }

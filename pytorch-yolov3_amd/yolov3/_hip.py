@@ -59,6 +59,7 @@ PROTOTYPES = {
     "y3_plan_op_flops": (ctypes.c_double, [ctypes.c_void_p, ctypes.c_int]),
     "y3_plan_op_bytes": (ctypes.c_double, [ctypes.c_void_p, ctypes.c_int]),
     "y3_conv_path": (ctypes.c_int, [ctypes.POINTER(Y3Op)]),
+    "y3_set_tuning": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "y3_op_run": (ctypes.c_int, [ctypes.POINTER(Y3Op), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "y3_detect_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "y3_detect": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,

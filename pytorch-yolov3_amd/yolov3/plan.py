@@ -158,7 +158,11 @@ def build_plan(blocks, net_info, batch, height, width, elem_size, reuse=True):
 
     # ---- emit ops ---------------------------------------------------------------------------
     ops = []
-    rows_total = sum(len(blocks[i]["mask"]) * shapes[i][1] * shapes[i][2] for i in range(n) if kinds[i] == "yolo")
+    def mask_of(blk):
+        m = blk["mask"]
+        return m if isinstance(m, list) else [m]      # "mask=0" parses to a bare int
+
+    rows_total = sum(len(mask_of(blocks[i])) * shapes[i][1] * shapes[i][2] for i in range(n) if kinds[i] == "yolo")
     row_offset = 0
     conv_slot = 0
     in_tensor = Tensor("input", 0, net_info["channels"], net_info["channels"], height, width)
@@ -209,10 +213,10 @@ def build_plan(blocks, net_info, batch, height, width, elem_size, reuse=True):
         elif kind == "yolo":
             src = tensor_of[i - 1]
             c, h, w = shapes[i]
-            na = len(blk["mask"])
+            na = len(mask_of(blk))
             if c % na != 0 or c // na <= 5:
                 raise ValueError("yolo block {}: {} channels do not split into {} anchors".format(i, c, na))
-            anchors = [blk["anchors"][m] for m in blk["mask"]]
+            anchors = [blk["anchors"][m] for m in mask_of(blk)]
             ops.append(dict(kind="yolo", block=i, inp=src, anchors=anchors, n_attr=c // na,
                             row_offset=row_offset, rows_total=rows_total))
             row_offset += na * h * w

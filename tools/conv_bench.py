@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the conv kernels on the Darknet-53 layer shapes (runs ON THE GPU BOX).
+
+For every (layer shape, kernel variant) it launches the single op through the C ABI (y3_op_run),
+times it with HIP events over many iterations on random data, and checks that all variants agree
+with variant 0.  Interleaved rounds in one process (cdna_hip_programming.md rule 24).
+Usage: python tools/conv_bench.py [--batch 16] [--dtype bf16] [--iters 20] [--out file]
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-yolov3_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from yolov3 import _hip  # noqa: E402
+
+# name, H(in), Cin, Cout, k, stride, residual, out_f32
+LAYERS = [
+    ("s76_128-256_k3", 76, 128, 256, 3, 1, True, False),
+    ("s38_256-512_k3", 38, 256, 512, 3, 1, True, False),
+    ("s19_512-1024_k3", 19, 512, 1024, 3, 1, True, False),
+    ("s152_64-128_k3", 152, 64, 128, 3, 1, True, False),
+    ("s304_32-64_k3", 304, 32, 64, 3, 1, True, False),
+    ("s608_32-64_k3s2", 608, 32, 64, 3, 2, False, False),
+    ("s152_128-256_k3s2", 152, 128, 256, 3, 2, False, False),
+    ("s76_256-128_k1", 76, 256, 128, 1, 1, False, False),
+    ("s38_512-256_k1", 38, 512, 256, 1, 1, False, False),
+    ("s19_1024-512_k1", 19, 1024, 512, 1, 1, False, False),
+    ("s152_128-64_k1", 152, 128, 64, 1, 1, False, False),
+    ("s76_256-255_k1_head", 76, 256, 255, 1, 1, False, True),
+]
+
+VARIANTS = [
+    ("v1_regstage", {"igemm_version": 1, "igemm_bm": 0}),
+    ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0}),
+    ("v2_ldsdma_bm256", {"igemm_version": 2, "igemm_bm": 256}),
+]
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    lib = _hip.lib()
+    _hip.require_gpu()
+    dev = torch.device("cuda:0")
+    bf = args.dtype == "bf16"
+    tdt = torch.bfloat16 if bf else torch.float32
+    es = 2 if bf else 4
+    zero = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    results = []
+    for name, h, cin, cout, k, s, res, f32out in LAYERS:
+        if args.only and args.only not in name:
+            continue
+        pad = (k - 1) // 2
+        ho = (h + 2 * pad - k) // s + 1
+        B = args.batch
+        x = (torch.rand((B, h, h, cin), generator=g) * 2 - 1).to(tdt).to(dev)
+        cout_pad = round_up(cout, 128)
+        kk = k * k * cin
+        k_ld = round_up(kk, 128 // es) + 128 // es      # one spare zero K-tile
+        w = torch.zeros((cout_pad, k_ld), dtype=torch.float32)
+        w[:cout, :kk] = (torch.rand((cout, kk), generator=g) * 2 - 1) * (2.0 / kk) ** 0.5
+        w = w.to(tdt).to(dev)
+        scale = torch.zeros(cout_pad, dtype=torch.float32)
+        bias = torch.zeros(cout_pad, dtype=torch.float32)
+        scale[:cout] = torch.rand(cout, generator=g) + 0.5
+        bias[:cout] = torch.rand(cout, generator=g) - 0.5
+        scale, bias = scale.to(dev), bias.to(dev)
+        out_ld = round_up(cout, 8)
+        r = (torch.rand((B, ho, ho, out_ld), generator=g) * 2 - 1).to(tdt).to(dev) if res else None
+        outs = []
+        for _ in VARIANTS:
+            outs.append(torch.zeros((B, ho, ho, out_ld), dtype=torch.float32 if (f32out or not bf) else tdt, device=dev))
+        op = _hip.Y3Op()
+        op.kind = _hip.OP_CONV
+        op.dtype = _hip.Y3_BF16 if bf else _hip.Y3_F32
+        op.flags = _hip.F_LEAKY | (_hip.F_RESIDUAL if res else 0) | (_hip.F_OUT_F32 if (f32out and bf) else 0)
+        op.batch = B
+        op.in_h = op.in_w = h
+        op.in_c = op.in_ld = cin
+        op.out_h = op.out_w = ho
+        op.out_c, op.out_ld = cout, out_ld
+        op.ksize, op.stride, op.pad = k, s, pad
+        op.res_ld = out_ld
+        op.k_ld, op.cout_pad = k_ld, cout_pad
+        op.d_in = x.data_ptr()
+        op.d_res = r.data_ptr() if res else None
+        op.d_weight, op.d_scale, op.d_bias = w.data_ptr(), scale.data_ptr(), bias.data_ptr()
+        flops = 2.0 * kk * cout * ho * ho * B
+        nbytes = (x.numel() + (r.numel() if res else 0)) * es + outs[0].numel() * outs[0].element_size() + kk * cout * es
+        best = [1e9] * len(VARIANTS)
+        stream = _hip.stream_ptr()
+        for rnd in range(args.rounds):
+            for vi, (vname, knobs) in enumerate(VARIANTS):
+                for key, val in knobs.items():
+                    _hip.check(lib.y3_set_tuning(key.encode(), val))
+                op.d_out = outs[vi].data_ptr()
+                for _ in range(2):
+                    _hip.check(lib.y3_op_run(ctypes.byref(op), None, zero.data_ptr(), stream))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    _hip.check(lib.y3_op_run(ctypes.byref(op), None, zero.data_ptr(), stream))
+                e1.record()
+                torch.cuda.synchronize()
+                best[vi] = min(best[vi], e0.elapsed_time(e1) / args.iters)
+        ref = outs[0].float()
+        row = dict(layer=name, gflop=flops / 1e9)
+        line = "%-22s %7.1f GF |" % (name, flops / 1e9)
+        for vi, (vname, _) in enumerate(VARIANTS):
+            diff = float((outs[vi].float() - ref).abs().max())
+            tf = flops / best[vi] / 1e9
+            row[vname] = dict(ms=best[vi], tflops=tf, gbps=nbytes / best[vi] / 1e6, maxdiff_vs_v0=diff)
+            line += " %s %.4f ms %6.1f TF %6.0f GB/s d=%.1e |" % (vname, best[vi], tf, nbytes / best[vi] / 1e6, diff)
+        print(line, flush=True)
+        results.append(row)
+    if args.out:
+        with open(args.out, "w") as fh:
+            json.dump(results, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
