@@ -125,7 +125,8 @@ double y3_plan_op_bytes(const y3_plan *plan, int op_index);
 int y3_conv_path(const y3_op *op);
 
 /* process-wide tuning knob for A/B measurements: "igemm_version" (1 register-staged, 2 LDS-DMA
- * double-buffered [default]), "igemm_bm" (0 heuristic, 256 = 8-wave 256x128 tile).  Results do not
+ * double-buffered [default]), "igemm_bm" (0 heuristic, 256 = 8-wave 256x128 tile), "conv_halo" (1 [default] =
+ * halo-reuse kernel for 3x3 stride-1 convs, 0 = implicit GEMM everywhere).  Results do not
  * depend on the knobs beyond floating-point summation order.                                   */
 int y3_set_tuning(const char *key, int value);
 

@@ -14,6 +14,9 @@ namespace {
 thread_local char g_err[512] = "";
 }
 
+int g_y3_use_halo = 1;
+
+
 void y3_set_error(const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -55,7 +58,11 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
       if (!dry_run)
         Y3_REQUIRE(op.d_weight && op.d_scale && op.d_bias, "conv block %d: missing parameters", op.block_idx);
       switch (conv_path(op)) {
-        case 0: return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run);
+        case 0: {
+          const int bm = g_y3_use_halo ? y3_conv_halo_bm(op) : 0;
+          if (bm) return y3_launch_conv_halo(op, bm, in, d_zero, s, name, dry_run);
+          return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run);
+        }
         case 1: return y3_launch_conv_small(op, in, s, name, dry_run);
         default: return y3_launch_conv_direct(op, in, s, name, dry_run);
       }

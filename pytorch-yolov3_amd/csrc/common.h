@@ -65,6 +65,40 @@ __device__ __forceinline__ float y3_from_float<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ bf16_t y3_from_float<bf16_t>(float v) { return (bf16_t)v; }
 
+// Diagnostic build only (-DY3_STAMPS, `make stamps`): per-workgroup phase timing with s_memtime.
+// Lane 0 of wave 0 adds the cycle count of each phase into g_y3_stamps[phase]; slot 7 counts
+// workgroups.  Never compiled into the shipped library.
+#ifdef Y3_STAMPS
+static __device__ unsigned long long g_y3_stamps[8];  // one copy per translation unit
+__device__ __forceinline__ unsigned long long y3_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define Y3_STAMP_DECL unsigned long long _st_prev = y3_now();
+#define Y3_STAMP(slot)                                                        \
+  do {                                                                        \
+    const unsigned long long _now = y3_now();                                 \
+    if (threadIdx.x == 0) atomicAdd(&g_y3_stamps[slot], _now - _st_prev);     \
+    _st_prev = _now;                                                          \
+  } while (0)
+#define Y3_STAMP_COUNT() do { if (threadIdx.x == 0) atomicAdd(&g_y3_stamps[7], 1ull); } while (0)
+// defines  extern "C" int NAME(unsigned long long out[8])  that reads + clears this unit's counters
+#define Y3_STAMP_READER(NAME)                                                                        \
+  extern "C" int NAME(unsigned long long *out8) {                                                    \
+    if (hipDeviceSynchronize() != hipSuccess) return Y3_ERR_HIP;                                     \
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_y3_stamps), 64) != hipSuccess) return Y3_ERR_HIP;     \
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                           \
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_y3_stamps), zero, 64) != hipSuccess) return Y3_ERR_HIP;       \
+    return Y3_OK;                                                                                    \
+  }
+#else
+#define Y3_STAMP_READER(NAME)
+#define Y3_STAMP_DECL
+#define Y3_STAMP(slot) do {} while (0)
+#define Y3_STAMP_COUNT() do {} while (0)
+#endif
+
 // launchers implemented in the .hip files; each fills *kernel_name with a static string
 int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
                          const char **kernel_name, bool dry_run);
@@ -82,5 +116,11 @@ int y3_launch_copy(const y3_op &op, const void *d_in, hipStream_t s, const char 
                    bool dry_run);
 int y3_launch_yolo(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
                    bool dry_run);
+// halo-reuse 3x3 kernel: pixel-tile height it would use for this conv (256 / 192), 0 = not applicable
+int y3_conv_halo_bm(const y3_op &op);
+int y3_launch_conv_halo(const y3_op &op, int bm, const void *d_in, const void *d_zero, hipStream_t s,
+                        const char **kernel_name, bool dry_run);
+// process-wide tuning knobs (y3_set_tuning)
+extern int g_y3_use_halo;
 // true when the MFMA implicit-GEMM kernel can take this conv
 bool y3_conv_igemm_supported(const y3_op &op);

@@ -1,0 +1,448 @@
+// 3x3 stride-1 convolution with input-halo reuse (gfx950), bf16 / fp32, NHWC.
+//
+// Same contract as conv_igemm.hip (conv -> scale/bias -> LeakyReLU -> +residual; replaces
+// /root/reference/yolov3/darknet.py:244-257 and the shortcut at :376-379), specialised for the
+// layers that carry ~75 % of Darknet-53's FLOPs: 3x3, stride 1, pad 1, Cin a multiple of the
+// K-tile (64 bf16 / 32 fp32 channels = 128 bytes).
+//
+// Why: the generic implicit GEMM re-reads every input pixel once per filter tap (9x) and every
+// weight tile once per 128-pixel tile; measured, its K loop is bound by global->LDS latency and
+// traffic (~10 TB/s of LDS-DMA at 25-30 % MFMA busy), not by the matrix cores.  Here a workgroup
+// owns BM consecutive output pixels in raster order (b, y, x flattened) and stages, per 128-byte
+// channel chunk, the BM + 2W + 2 input pixels that ALL nine taps of those outputs touch -- once.
+// Tap (ky,kx) of output pixel p is halo row  p + ky*W + kx, so the nine K-steps of a chunk read the
+// same LDS image at nine row offsets.  Row-wrap / image-border taps (the zero padding) are cleared
+// in registers with a per-pixel 9-bit mask after the fragment read.  Only the weight tile (BN x 128
+// B) changes per K-step; it streams through a 3-slot LDS ring two steps ahead.  Bytes moved per FLOP
+// drop ~3x versus the 128x128 implicit GEMM.
+//
+// Pipeline (all LDS-DMA, global_load_lds_dwordx4, counted vmcnt, one barrier per K-step):
+//   step it = chunk*9 + tap:  wait(all but the loads issued in step it-1) ; barrier ;
+//                             issue weights(it+2) [+ one slice of the next chunk's halo] ; MFMAs(it)
+// Workgroup: (BM/64) x 2 waves, wave tile 64 x 64 (4x4 MFMA 16x16 accumulators), BN = 128.
+#include "common.h"
+
+namespace {
+
+struct HaloArgs {
+  const char *in;
+  const char *wgt;
+  const float *scale;
+  const float *bias;
+  const char *res;
+  char *out;
+  const char *zero;
+  int H, W, Cin, in_ld;
+  int Cout, out_ld, res_ld;
+  int M, HW;           // B*H*W, H*W
+  int k_ld;
+  int nchunks;         // Cin / BKE
+  int n_tiles;
+  int hr_pad;          // halo rows, padded to a multiple of the loader's rows-per-pass
+  int na;              // loader passes per halo (= glds per thread per halo)
+  int a_bytes;         // hr_pad * 128
+  uint32_t mul_hw, sh_hw, mul_w, sh_w;   // n / d == (umulhi(n, mul) + n) >> sh  for n < 2^31
+  uint32_t flags;
+};
+
+template <typename T>
+struct MmaH;
+template <>
+struct MmaH<bf16_t> {
+  static __device__ __forceinline__ void run(f32x4 &acc, const u32x4 &w, const u32x4 &x) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x),
+                                                  acc, 0, 0, 0);
+  }
+};
+template <>
+struct MmaH<float> {
+  static __device__ __forceinline__ void run(f32x4 &acc, const u32x4 &w, const u32x4 &x) {
+    const f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j], xf[j], acc, 0, 0, 0);
+  }
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+}
+
+template <typename T, int BM, int NSB>
+__global__ __launch_bounds__(BM * 2) void conv_halo3x3_kernel(HaloArgs p) {
+  constexpr int BN = 128;
+  constexpr int WAVES_M = BM / 64, WAVES_N = 2;
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int ES = sizeof(T);
+  constexpr int BKE = 128 / ES;
+  constexpr int RPP = NT / 8;                         // rows filled per loader pass
+  constexpr int NB = (BN + RPP - 1) / RPP;            // weight-tile passes (glds per thread per K-step)
+  constexpr int B_ROWS = NB * RPP;
+  constexpr int B_BYTES = B_ROWS * 128;
+  constexpr int D = NSB - 2;                          // K-steps of load latency the ring tolerates
+  constexpr int MI = 4, NI = 4;
+  static_assert(NSB == 3 || NSB == 4, "weight ring has 3 or 4 slots");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *sB = smem;                                    // [NSB][B_ROWS][128]
+  char *sA = smem + NSB * B_BYTES;                    // [2][hr_pad][128]
+
+  Y3_STAMP_DECL
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / p.n_tiles) * BM;
+  const int n0 = (tile % p.n_tiles) * BN;
+
+  // ---- loader geometry -----------------------------------------------------------------------
+  const int slot = tid & 7;
+  const int row0 = tid >> 3;
+  const int kc = slot ^ (row0 & 7);                   // RPP % 8 == 0, so (row & 7) == (row0 & 7)
+  const long long q0 = (long long)m0 - p.W - 1;       // flattened input pixel of halo row 0
+
+  auto issue_halo_pass = [&](int chunk, int pass) {
+    const int row = row0 + pass * RPP;
+    const long long q = q0 + row;
+    const bool ok = q >= 0 && q < p.M;
+    const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
+    char *dst = sA + (chunk & 1) * p.a_bytes + pass * (NT * 16) + wave * 1024;
+    __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
+  };
+  const char *b_src[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int r = row0 + i * RPP;
+    b_src[i] = r < BN ? p.wgt + ((long long)(n0 + r) * p.k_ld) * ES + kc * 16 : nullptr;
+  }
+  auto issue_weights = [&](int it) {  // it = chunk*9 + tap; K offset = (tap*Cin + chunk*BKE) elements
+    const int chunk = it / 9, tap = it - chunk * 9;
+    const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
+    char *dst = sB + (it % NSB) * B_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const char *src = b_src[i] ? b_src[i] + koff : p.zero;
+      __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(dst + i * (NT * 16)), 16, 0, 0);
+    }
+  };
+
+  // ---- prologue: get the first operands moving before anything else ------------------------------
+  const int nit = p.nchunks * 9;
+  for (int pass = 0; pass < p.na; ++pass) issue_halo_pass(0, pass);
+#pragma unroll
+  for (int j = 0; j <= D; ++j)
+    if (j < nit) issue_weights(j);
+
+  // per-lane tap validity of the 4 pixels this lane feeds to the MFMAs (closed form, no loops)
+  uint32_t tapmask[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const uint32_t m = (uint32_t)(m0 + wm * 64 + mi * 16 + fr);
+    uint32_t mask = 0u;
+    if (m < (uint32_t)p.M) {
+      const uint32_t img = (__umulhi(m, p.mul_hw) + m) >> p.sh_hw;
+      const uint32_t rem = m - img * (uint32_t)p.HW;
+      const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
+      const uint32_t ox = rem - oy * (uint32_t)p.W;
+      const uint32_t vx = (ox >= 1u ? 1u : 0u) | 2u | (ox + 1u < (uint32_t)p.W ? 4u : 0u);
+      mask = (oy >= 1u ? vx : 0u) | (vx << 3) | (oy + 1u < (uint32_t)p.H ? vx << 6 : 0u);
+    }
+    tapmask[mi] = mask;
+  }
+  const int oc_mine = tid & 15;  // this thread's 8-channel group in the write-out phase
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing: lane (fr, fq) reads 16-byte chunk (g*4 + fq) of row (base + fr [+ shift]);
+  // mi / ni steps are +16 rows = +2048 bytes and do not change (row & 7), so they are immediates
+  const int a_lane_row = wm * 64 + fr;
+  const int b_lane_row = wn * 64 + fr;
+  const int b_off0 = b_lane_row * 128 + (((0 + fq) ^ (b_lane_row & 7)) << 4);
+  const int b_off1 = b_lane_row * 128 + (((4 + fq) ^ (b_lane_row & 7)) << 4);
+
+  auto read_frags = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], const char *aBuf, const char *bBuf, int a_shift, int g) {
+    const int r0 = a_lane_row + a_shift;
+    const char *ap = aBuf + r0 * 128 + (((g * 4 + fq) ^ (r0 & 7)) << 4);
+    const char *bp = bBuf + (g ? b_off1 : b_off0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const u32x4 *>(ap + mi * 2048);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
+  };
+  auto mma_all = [&](u32x4 (&xf)[MI], const u32x4 (&wf)[NI], int tap) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      if (!((tapmask[mi] >> tap) & 1u)) xf[mi] = u32x4{0u, 0u, 0u, 0u};
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) MmaH<T>::run(acc[mi][ni], wf[ni], xf[mi]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- first operands: halo(0), weights(0), weights(1) must have landed ----------------------------
+  Y3_STAMP(0);
+  if (D == 2 && nit > 2) wait_vmcnt<NB>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  Y3_STAMP(1);
+  u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
+  read_frags(xf0, wf0, sA, sB, 0, 0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+
+  // LDS-DMA instructions this thread issued in the previous step (step "-1" = the prologue, whose
+  // only possibly unfinished loads are weights(2) of the 4-slot ring)
+  int issued_prev = (D == 2 && nit > 2) ? NB : 0;
+  int tap = 0, chunk = 0;
+#pragma unroll 1
+  for (int it = 0; it < nit; ++it) {
+    {
+      // weights(it+1) -- and the next chunk's halo when the next step starts it -- must have landed
+      // before this barrier; with the 4-slot ring only the loads of step it-1 may still be in flight.
+      // (Step 0 repeats the prologue's barrier on purpose: every trip then enters with the same
+      // "fragment set 0 complete" state and hipcc emits counted LDS waits inside the loop.)
+      if (D == 2) {
+        if (issued_prev == NB + 1) wait_vmcnt<NB + 1>();
+        else if (issued_prev == NB) wait_vmcnt<NB>();
+        else if (issued_prev == 1) wait_vmcnt<1>();
+        else wait_vmcnt<0>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    // halo slice first, weights second: only later steps' loads are younger than these weights
+    issued_prev = 0;
+    if (chunk + 1 < p.nchunks && tap < p.na) { issue_halo_pass(chunk + 1, tap); issued_prev += 1; }
+    if (it + 1 + D < nit) { issue_weights(it + 1 + D); issued_prev += NB; }
+
+    const char *aBuf = sA + (chunk & 1) * p.a_bytes;
+    const int ky = (tap * 11) >> 5, kx = tap - ky * 3;         // tap / 3, tap % 3 for tap in 0..8
+    read_frags(xf1, wf1, aBuf, sB + (it % NSB) * B_BYTES, ky * p.W + kx, 1);   // second half of this step ...
+    __builtin_amdgcn_sched_barrier(0);
+    mma_all(xf0, wf0, tap);                                    // ... flies under the first half's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // second-half fragments (16 MFMAs old); keeps <= 8 LDS reads in flight
+    const int tap_n = tap == 8 ? 0 : tap + 1;
+    const int chunk_n = tap == 8 ? chunk + 1 : chunk;
+    {                                                          // first half of the next step (harmless
+      const int ky_n = (tap_n * 11) >> 5, kx_n = tap_n - ky_n * 3;   // in-bounds read after the last one)
+      read_frags(xf0, wf0, sA + (chunk_n & 1) * p.a_bytes, sB + ((it + 1) % NSB) * B_BYTES, ky_n * p.W + kx_n, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma_all(xf1, wf1, tap);
+    __builtin_amdgcn_sched_barrier(0);
+    // the prefetched fragments have had 16 MFMAs of time; retiring them here (lgkmcnt(0) only, in a form
+    // hipcc's wait-count pass understands) lets it issue the next step's first MFMAs without a wait
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    tap = tap_n;
+    chunk = chunk_n;
+  }
+  __syncthreads();  // all operand reads done: LDS can hold the output tile
+  Y3_STAMP(2);  // main loop
+
+  // ---- epilogue: raw fp32 accumulators -> LDS (pixel rows, XOR-swizzled 16-byte chunks) -> every thread
+  // finishes 8 consecutive channels of one pixel: scale/bias/LeakyReLU, + residual, one 16-byte store
+  constexpr int SWZ = 15;
+  constexpr int OCT_PER_ROW = BN / 8;
+  constexpr int WR = BM * OCT_PER_ROW / NT;   // write-out steps per thread (8)
+  float *sC = reinterpret_cast<float *>(smem);
+  const bool leaky = p.flags & Y3_F_LEAKY;
+  const bool has_res = p.flags & Y3_F_RESIDUAL;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int cl = wn * 64 + ni * 16 + fq * 4;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int pl = wm * 64 + mi * 16 + fr;
+      *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
+    }
+  }
+  const int co = n0 + oc_mine * 8;
+  const f32x4 sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
+  const f32x4 sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+  const f32x4 bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
+  const f32x4 bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+  u32x4 resv[WR];
+  if (has_res) {
+#pragma unroll
+    for (int j = 0; j < WR; ++j) {
+      const int m = m0 + (tid >> 4) + j * (NT / 16);
+      const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
+      if constexpr (sizeof(T) == 2) {
+        resv[j] = m < p.M ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < WR; ++j) {
+    const int pl = (tid >> 4) + j * (NT / 16);
+    const int m = m0 + pl;
+    if (m >= p.M) continue;
+    const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
+    const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = lo[r] * sc_lo[r] + bi_lo[r];
+      v[4 + r] = hi[r] * sc_hi[r] + bi_hi[r];
+    }
+    if (leaky) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : Y3_LEAKY_SLOPE * v[r];
+    }
+    if (has_res) {
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[j]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+      } else {
+        const float *rp = reinterpret_cast<const float *>(p.res) + (long long)m * p.res_ld + co;
+        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(rp), r1 = *reinterpret_cast<const f32x4 *>(rp + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+      }
+    }
+    T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
+    if constexpr (sizeof(T) == 2) {
+      bf16x8 ov;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ov[r] = (bf16_t)v[r];
+      *reinterpret_cast<bf16x8 *>(op) = ov;
+    } else {
+      *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+  Y3_STAMP(3);  // epilogue
+  Y3_STAMP_COUNT();
+}
+
+// n / d == (umulhi(n, mul) + n) >> sh for 0 <= n < 2^31 (round-up method, d >= 1)
+void fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
+  if (d <= 1) { mul = 0; sh = 0; return; }
+  sh = 0;
+  while ((1u << sh) < d) ++sh;
+  mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
+}
+
+struct HaloGeom { int na, hr_pad, a_bytes, nsb; size_t lds; };
+
+// geometry / LDS budget of one tile configuration; nsb == 0: does not fit
+HaloGeom halo_geom(int bm, int w) {
+  HaloGeom g = {0, 0, 0, 0, 0};
+  const int nt = bm * 2, rpp = nt / 8, nb = (128 + rpp - 1) / rpp;
+  const int hr = bm + 2 * w + 2;
+  g.na = (hr + rpp - 1) / rpp;
+  g.hr_pad = g.na * rpp;
+  g.a_bytes = g.hr_pad * 128;
+  const size_t epi = (size_t)bm * 128 * 4;
+  for (int nsb = 4; nsb >= 3; --nsb) {
+    // the next chunk's halo slices go out at taps 0..na-1 and must be older than the last allowed loads
+    if (g.na > (nsb == 4 ? 7 : 8)) continue;
+    size_t lds = (size_t)nsb * nb * rpp * 128 + (size_t)2 * g.a_bytes;
+    if (lds < epi) lds = epi;
+    if (lds <= 160 * 1024) { g.nsb = nsb; g.lds = lds; return g; }
+  }
+  return g;
+}
+
+template <typename T, int BM, int NSB>
+int launch_halo(const HaloArgs &a0, const HaloGeom &g, hipStream_t s) {
+  HaloArgs a = a0;
+  a.na = g.na; a.hr_pad = g.hr_pad; a.a_bytes = g.a_bytes;
+  const int m_tiles = y3_ceil_div(a.M, BM);
+  static bool attr_set = false;
+  if (!attr_set) {
+    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo3x3_kernel<T, BM, NSB>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_halo3x3_kernel<T, BM, NSB>), dim3(m_tiles * a.n_tiles), dim3(BM * 2), g.lds, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+}  // namespace
+
+// picks the pixel-tile height (256 or 192) that wastes the fewest CU rounds; 0 = not applicable
+int y3_conv_halo_bm(const y3_op &op) {
+  const int es = y3_elem_size(op.dtype);
+  const int bke = 128 / es;
+  if (op.ksize != 3 || op.stride != 1 || op.pad != 1) return 0;
+  if (op.flags & (Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR)) return 0;
+  if (op.in_c % bke != 0 || op.in_c / bke < 2) return 0;
+  if (op.out_c % 128 != 0 || op.out_ld % 8 != 0 || op.in_ld % (16 / es) != 0) return 0;
+  if ((op.flags & Y3_F_RESIDUAL) && op.res_ld % 8 != 0) return 0;
+  if (op.k_ld < 9 * op.in_c) return 0;
+  const long long m = (long long)op.batch * op.out_h * op.out_w;
+  const int n_tiles = op.out_c / 128;
+  int best = 0;
+  double best_eff = 0.0;
+  const int cands[2] = {256, 192};
+  for (int bm : cands) {
+    const HaloGeom g = halo_geom(bm, op.in_w);
+    if (g.nsb == 0) continue;
+    const double blocks = (double)((m + bm - 1) / bm) * n_tiles;
+    const double rounds = blocks / 256.0;
+    const double eff = rounds / (double)(long long)(rounds + 0.999999);
+    const double score = eff * (bm == 256 ? 1.04 : 1.0) * (g.nsb == 4 ? 1.03 : 1.0);
+    if (score > best_eff) { best_eff = score; best = bm; }
+  }
+  return best;
+}
+
+int y3_launch_conv_halo(const y3_op &op, int bm, const void *d_in, const void *d_zero, hipStream_t s,
+                        const char **kernel_name, bool dry_run) {
+  const int es = y3_elem_size(op.dtype);
+  const bool bf = op.dtype == Y3_BF16;
+  Y3_REQUIRE(bm == 256 || bm == 192, "conv block %d: bad halo tile %d", op.block_idx, bm);
+  if (bm == 256) *kernel_name = bf ? "conv_halo3x3_bf16_256x128" : "conv_halo3x3_f32_256x128";
+  else *kernel_name = bf ? "conv_halo3x3_bf16_192x128" : "conv_halo3x3_f32_192x128";
+  if (dry_run) return Y3_OK;
+  HaloArgs a;
+  a.in = static_cast<const char *>(d_in);
+  a.wgt = static_cast<const char *>(op.d_weight);
+  a.scale = op.d_scale; a.bias = op.d_bias;
+  a.res = static_cast<const char *>(op.d_res);
+  a.out = static_cast<char *>(op.d_out);
+  a.zero = static_cast<const char *>(d_zero);
+  a.H = op.in_h; a.W = op.in_w; a.Cin = op.in_c; a.in_ld = op.in_ld;
+  a.Cout = op.out_c; a.out_ld = op.out_ld; a.res_ld = op.res_ld;
+  a.HW = op.in_h * op.in_w;
+  a.M = op.batch * a.HW;
+  a.k_ld = op.k_ld;
+  a.nchunks = op.in_c / (128 / es);
+  a.n_tiles = op.out_c / 128;
+  a.hr_pad = a.na = a.a_bytes = 0;
+  fast_div((uint32_t)a.HW, a.mul_hw, a.sh_hw);
+  fast_div((uint32_t)a.W, a.mul_w, a.sh_w);
+  a.flags = op.flags;
+  Y3_REQUIRE((long long)op.batch * a.HW < (1ll << 31), "conv block %d: too many pixels for the 32-bit tile index", op.block_idx);
+  const HaloGeom g = halo_geom(bm, op.in_w);
+  Y3_REQUIRE(g.nsb != 0, "conv block %d: halo tile does not fit in LDS", op.block_idx);
+  if (bf) {
+    if (bm == 256) return g.nsb == 4 ? launch_halo<bf16_t, 256, 4>(a, g, s) : launch_halo<bf16_t, 256, 3>(a, g, s);
+    return g.nsb == 4 ? launch_halo<bf16_t, 192, 4>(a, g, s) : launch_halo<bf16_t, 192, 3>(a, g, s);
+  }
+  if (bm == 256) return g.nsb == 4 ? launch_halo<float, 256, 4>(a, g, s) : launch_halo<float, 256, 3>(a, g, s);
+  return g.nsb == 4 ? launch_halo<float, 192, 4>(a, g, s) : launch_halo<float, 192, 3>(a, g, s);
+}
+
+Y3_STAMP_READER(y3_debug_stamps_halo)

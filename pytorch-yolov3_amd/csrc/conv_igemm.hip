@@ -289,6 +289,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
 
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
+  Y3_STAMP_DECL
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -388,11 +389,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
 
   const int fr = lane & 15, fq = lane >> 4;
 
+  Y3_STAMP(0);
   issue(0, 0);
   for (int kt = 0; kt < p.n_ktiles; ++kt) {
     const int cur = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt has landed (this wave's pieces)
     __syncthreads();                                   // ... everyone's; stage cur^1 is free again
+    if (kt == 0) Y3_STAMP(1);
     if (kt + 1 < p.n_ktiles) issue(kt + 1, cur ^ 1);
     const char *sA = smem + cur * STAGE;
     const char *sB = sA + BM * 128;
@@ -418,6 +421,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
     }
   }
   __syncthreads();  // all MFMA operand reads done: the stages can hold the output tile
+  Y3_STAMP(2);
 
   // ---- epilogue: scale/bias/activation in registers, park the fp32 tile in LDS, then write it out
   // as whole 16-byte chunks.  Tile row = pixel (BN floats); its 16-byte chunk index is XOR-ed with
@@ -503,6 +507,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
       }
     }
   }
+  Y3_STAMP(3);
+  Y3_STAMP_COUNT();
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -556,6 +562,7 @@ extern "C" int y3_set_tuning(const char *key, int value) {
   if (!key) return Y3_ERR_INVALID;
   if (!strcmp(key, "igemm_version")) { g_igemm_version = value; return Y3_OK; }
   if (!strcmp(key, "igemm_bm")) { g_igemm_bm = value; return Y3_OK; }
+  if (!strcmp(key, "conv_halo")) { g_y3_use_halo = value; return Y3_OK; }
   y3_set_error("y3_set_tuning: unknown key %s", key);
   return Y3_ERR_INVALID;
 }
@@ -631,3 +638,5 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
   if (dry_run) return Y3_OK;
   return bf ? launch_cfg2<bf16_t, 128, 32, 4, 1>(a, kmode, s) : launch_cfg2<float, 128, 32, 4, 1>(a, kmode, s);
 }
+
+Y3_STAMP_READER(y3_debug_stamps_igemm)

@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401  (must be loaded before libyolov3_hip.so, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "..", "lib", "libyolov3_hip.so")
+# Y3_HIP_LIB: developer override (e.g. the diagnostic build with in-kernel phase stamps)
+LIB_PATH = os.environ.get("Y3_HIP_LIB") or os.path.join(_HERE, "..", "lib", "libyolov3_hip.so")
 
 Y3_F32, Y3_BF16 = 0, 1
 OP_CONV, OP_MAXPOOL, OP_UPSAMPLE, OP_ADD, OP_COPY, OP_YOLO = 1, 2, 3, 4, 5, 6

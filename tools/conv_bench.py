@@ -26,6 +26,8 @@ LAYERS = [
     ("s38_256-512_k3", 38, 256, 512, 3, 1, True, False),
     ("s19_512-1024_k3", 19, 512, 1024, 3, 1, True, False),
     ("s152_64-128_k3", 152, 64, 128, 3, 1, True, False),
+    ("s76_128-256_k3_nores", 76, 128, 256, 3, 1, False, False),
+    ("s38_256-512_k3_b3", 38, 256, 512, 3, 1, True, False),
     ("s304_32-64_k3", 304, 32, 64, 3, 1, True, False),
     ("s608_32-64_k3s2", 608, 32, 64, 3, 2, False, False),
     ("s152_128-256_k3s2", 152, 128, 256, 3, 2, False, False),
@@ -37,9 +39,9 @@ LAYERS = [
 ]
 
 VARIANTS = [
-    ("v1_regstage", {"igemm_version": 1, "igemm_bm": 0}),
-    ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0}),
-    ("v2_ldsdma_bm256", {"igemm_version": 2, "igemm_bm": 256}),
+    ("v1_regstage", {"igemm_version": 1, "igemm_bm": 0, "conv_halo": 0}),
+    ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0}),
+    ("halo", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1}),
 ]
 
 
@@ -55,6 +57,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--only", default=None)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--stamps", action="store_true", help="library built with `make stamps`: print phase cycles")
     args = ap.parse_args()
     lib = _hip.lib()
     _hip.require_gpu()
@@ -121,6 +124,15 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 best[vi] = min(best[vi], e0.elapsed_time(e1) / args.iters)
+                if args.stamps and rnd == args.rounds - 1:
+                    import ctypes as C
+                    for rd in ("y3_debug_stamps_halo", "y3_debug_stamps_igemm"):
+                        buf = (C.c_ulonglong * 8)()
+                        getattr(lib, rd)(buf)
+                        if buf[7]:
+                            n = float(buf[7])
+                            print("    [%s %s] blocks/launch %.0f  cycles/block: setup %.0f  first-wait %.0f  mainloop %.0f  "
+                                  "epilogue %.0f" % (vname, rd[16:], n / (args.iters + 2), buf[0] / n, buf[1] / n, buf[2] / n, buf[3] / n))
         ref = outs[0].float()
         row = dict(layer=name, gflop=flops / 1e9)
         line = "%-22s %7.1f GF |" % (name, flops / 1e9)
