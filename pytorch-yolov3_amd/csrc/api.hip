@@ -14,7 +14,7 @@ namespace {
 thread_local char g_err[512] = "";
 }
 
-int g_y3_use_halo = 1;
+int g_y3_use_halo = 0;   // experimental halo-reuse 3x3 kernels (conv_halo.hip); off: the implicit GEMM measured as fast
 
 
 void y3_set_error(const char *fmt, ...) {

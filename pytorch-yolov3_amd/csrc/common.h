@@ -122,5 +122,7 @@ int y3_launch_conv_halo(const y3_op &op, int bm, const void *d_in, const void *d
                         const char **kernel_name, bool dry_run);
 // process-wide tuning knobs (y3_set_tuning)
 extern int g_y3_use_halo;
+extern int g_y3_halo_pp;
+extern int g_y3_halo_bm;   // 0 = heuristic, 256 / 192 = forced
 // true when the MFMA implicit-GEMM kernel can take this conv
 bool y3_conv_igemm_supported(const y3_op &op);

@@ -334,6 +334,255 @@ __global__ __launch_bounds__(BM * 2) void conv_halo3x3_kernel(HaloArgs p) {
   Y3_STAMP_COUNT();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ping-pong variant (BM = 256, 8 waves = 2 per SIMD).  Measured on the kernel above: the two waves of
+// a SIMD run in lockstep -- both issue LDS-DMA / LDS reads, then both want the matrix pipe -- so a
+// K-step costs ~2100 cycles for 1024 cycles of MFMA.  Here every wave alternates a LOAD segment
+// (its share of the LDS-DMA for step s+2, then the 16 fragment reads of step s into registers)
+// with a COMPUTE segment (32 MFMAs of step s, operands already in registers); waves 4-7 run one
+// segment behind waves 0-3 (they share SIMDs pairwise), and one workgroup barrier per segment keeps
+// the alternation, so on every SIMD one wave feeds the matrix pipe while its partner loads.
+// Ring: 3 weight slots; weights(s+2) are issued in load segment s; every wave drains its older loads
+// at the end of each odd half-step (group 0: after compute(s), group 1: after load(s)).
+template <typename T>
+__global__ __launch_bounds__(512) void conv_halo3x3_pp_kernel(HaloArgs p) {
+  constexpr int BM = 256, BN = 128, NT = 512, NSB = 3;
+  constexpr int ES = sizeof(T);
+  constexpr int BKE = 128 / ES;
+  constexpr int RPP = NT / 8;
+  constexpr int NB = BN / RPP;                        // 2 LDS-DMA instructions per thread per weight tile
+  constexpr int B_BYTES = BN * 128;
+  constexpr int MI = 4, NI = 4;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *sB = smem;                                    // [NSB][128][128]
+  char *sA = smem + NSB * B_BYTES;                    // [2][hr_pad][128]
+
+  Y3_STAMP_DECL
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  // waves w and w+4 share a SIMD; readfirstlane makes the group id provably wave-uniform, so the
+  // group-dependent barriers below are real scalar branches (never executed under an empty EXEC mask)
+  const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / p.n_tiles) * BM;
+  const int n0 = (tile % p.n_tiles) * BN;
+
+  const int slot = tid & 7;
+  const int row0 = tid >> 3;
+  const int kc = slot ^ (row0 & 7);
+  const long long q0 = (long long)m0 - p.W - 1;
+
+  auto issue_halo_pass = [&](int chunk, int pass) {
+    const long long q = q0 + row0 + pass * RPP;
+    const bool ok = q >= 0 && q < p.M;
+    const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
+    char *dst = sA + (chunk & 1) * p.a_bytes + pass * (NT * 16) + wave * 1024;
+    __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
+  };
+  const char *b_src0 = p.wgt + ((long long)(n0 + row0) * p.k_ld) * ES + kc * 16;
+  const char *b_src1 = b_src0 + (long long)RPP * p.k_ld * ES;
+  auto issue_weights = [&](int chunk, int tap, int slot_idx) {
+    const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
+    char *dst = sB + slot_idx * B_BYTES + wave * 1024;
+    __builtin_amdgcn_global_load_lds((gbl_void *)(b_src0 + koff), (lds_void *)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void *)(b_src1 + koff), (lds_void *)(dst + NT * 16), 16, 0, 0);
+  };
+
+  const int nit = p.nchunks * 9;
+  for (int pass = 0; pass < p.na; ++pass) issue_halo_pass(0, pass);
+  issue_weights(0, 0, 0);
+  issue_weights(0, 1, 1);   // nit >= 18: the launcher requires at least two channel chunks
+
+  uint32_t tapmask[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const uint32_t m = (uint32_t)(m0 + wm * 64 + mi * 16 + fr);
+    uint32_t mask = 0u;
+    if (m < (uint32_t)p.M) {
+      const uint32_t img = (__umulhi(m, p.mul_hw) + m) >> p.sh_hw;
+      const uint32_t rem = m - img * (uint32_t)p.HW;
+      const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
+      const uint32_t ox = rem - oy * (uint32_t)p.W;
+      const uint32_t vx = (ox >= 1u ? 1u : 0u) | 2u | (ox + 1u < (uint32_t)p.W ? 4u : 0u);
+      mask = (oy >= 1u ? vx : 0u) | (vx << 3) | (oy + 1u < (uint32_t)p.H ? vx << 6 : 0u);
+    }
+    tapmask[mi] = mask;
+  }
+  // wave-uniform: does any of the 64 lanes need masking for this 16-pixel group at all?
+  bool need_mask[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) need_mask[mi] = __any(tapmask[mi] != 0x1FFu);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int a_lane_row = wm * 64 + fr;
+  const int b_lane_row = wn * 64 + fr;
+  const int b_off0 = b_lane_row * 128 + (((0 + fq) ^ (b_lane_row & 7)) << 4);
+  const int b_off1 = b_lane_row * 128 + (((4 + fq) ^ (b_lane_row & 7)) << 4);
+
+  Y3_STAMP(0);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  Y3_STAMP(1);
+  if (grp) __builtin_amdgcn_s_barrier();              // group 1 runs one segment behind group 0
+
+  // write-out role of this thread (epilogue): 8 channels [co, co+8) of pixels (tid>>4) + 32*j
+  constexpr int WR = BM * (BN / 8) / NT;
+  const int oc_mine = tid & 15;
+  const int co = n0 + oc_mine * 8;
+  const bool has_res = p.flags & Y3_F_RESIDUAL;
+  u32x4 resv[WR];
+  f32x4 sc_lo, sc_hi, bi_lo, bi_hi;
+
+  u32x4 xf[2][MI], wf[2][NI];
+  int tap = 0, chunk = 0;        // step s
+  int tap2 = 2, chunk2 = 0;      // step s + 2 (whose weights are issued in load segment s)
+#pragma unroll 1
+  for (int s = 0; s < nit; ++s) {
+    // ================= load segment =================
+    const char *aBuf = sA + (chunk & 1) * p.a_bytes;
+    const char *bBuf = sB + (s % NSB) * B_BYTES;
+    const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+    const int r0 = a_lane_row + ky * p.W + kx;
+    const char *ap0 = aBuf + r0 * 128 + (((0 + fq) ^ (r0 & 7)) << 4);
+    const char *ap1 = aBuf + r0 * 128 + (((4 + fq) ^ (r0 & 7)) << 4);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) xf[0][mi] = *reinterpret_cast<const u32x4 *>(ap0 + mi * 2048);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) wf[0][ni] = *reinterpret_cast<const u32x4 *>(bBuf + b_off0 + ni * 2048);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) xf[1][mi] = *reinterpret_cast<const u32x4 *>(ap1 + mi * 2048);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) wf[1][ni] = *reinterpret_cast<const u32x4 *>(bBuf + b_off1 + ni * 2048);
+    if (s == nit - 1) {
+      // last step: no LDS-DMA left to issue; start the epilogue's global reads now so that their latency
+      // hides under this step's MFMAs (every counted vmcnt wait below is skipped for this step)
+      sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
+      sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+      bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
+      bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+      if (has_res) {
+#pragma unroll
+        for (int j = 0; j < WR; ++j) {
+          const int m = m0 + (tid >> 4) + j * (NT / 16);
+          const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
+          resv[j] = m < p.M ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+    }
+    // the fragment reads' latency hides under the LDS-DMA issue below
+    int issued = 0;
+    if (chunk + 1 < p.nchunks && tap < p.na) { issue_halo_pass(chunk + 1, tap); issued += 1; }
+    if (s + 2 < nit) { issue_weights(chunk2, tap2, (s + 2) % NSB); issued += NB; }
+    if (grp == 1 && s != nit - 1) {                   // end of an odd half-step for group 1
+      if (issued == NB + 1) wait_vmcnt<NB + 1>();
+      else if (issued == NB) wait_vmcnt<NB>();
+      else if (issued == 1) wait_vmcnt<1>();
+      else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    // ================= compute segment =================
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      if (need_mask[mi]) {   // scalar branch: interior pixel groups skip the 8 v_cndmask
+        const bool dead = !((tapmask[mi] >> tap) & 1u);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          if (dead) xf[g][mi] = u32x4{0u, 0u, 0u, 0u};
+      }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) MmaH<T>::run(acc[mi][ni], wf[g][ni], xf[g][mi]);
+    __builtin_amdgcn_s_setprio(0);
+    if (grp == 0 && s != nit - 1) {                   // end of an odd half-step for group 0
+      if (issued == NB + 1) wait_vmcnt<NB + 1>();
+      else if (issued == NB) wait_vmcnt<NB>();
+      else if (issued == 1) wait_vmcnt<1>();
+      else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    tap = tap == 8 ? 0 : tap + 1;
+    chunk += tap == 0 ? 1 : 0;
+    tap2 = tap2 == 8 ? 0 : tap2 + 1;
+    chunk2 += tap2 == 0 ? 1 : 0;
+  }
+  if (!grp) __builtin_amdgcn_s_barrier();             // balance group 1's extra barrier
+  __syncthreads();
+  Y3_STAMP(2);
+
+  // ---- epilogue (as above): raw fp32 tile -> LDS -> 8 channels of one pixel per thread-step ----------
+  constexpr int SWZ = 15;
+  constexpr int OCT_PER_ROW = BN / 8;
+  float *sC = reinterpret_cast<float *>(smem);
+  const bool leaky = p.flags & Y3_F_LEAKY;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int cl = wn * 64 + ni * 16 + fq * 4;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int pl = wm * 64 + mi * 16 + fr;
+      *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < WR; ++j) {
+    const int pl = (tid >> 4) + j * (NT / 16);
+    const int m = m0 + pl;
+    if (m >= p.M) continue;
+    const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
+    const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = lo[r] * sc_lo[r] + bi_lo[r];
+      v[4 + r] = hi[r] * sc_hi[r] + bi_hi[r];
+    }
+    if (leaky) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : Y3_LEAKY_SLOPE * v[r];
+    }
+    if (has_res) {
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[j]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+      } else {
+        const float *rp = reinterpret_cast<const float *>(p.res) + (long long)m * p.res_ld + co;
+        const f32x4 r0v = __builtin_bit_cast(f32x4, resv[j]), r1v = *reinterpret_cast<const f32x4 *>(rp + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] += r0v[r]; v[4 + r] += r1v[r]; }
+      }
+    }
+    T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
+    if constexpr (sizeof(T) == 2) {
+      bf16x8 ov;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ov[r] = (bf16_t)v[r];
+      *reinterpret_cast<bf16x8 *>(op) = ov;
+    } else {
+      *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+  Y3_STAMP(3);
+  Y3_STAMP_COUNT();
+}
+
 // n / d == (umulhi(n, mul) + n) >> sh for 0 <= n < 2^31 (round-up method, d >= 1)
 void fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
   if (d <= 1) { mul = 0; sh = 0; return; }
@@ -379,7 +628,31 @@ int launch_halo(const HaloArgs &a0, const HaloGeom &g, hipStream_t s) {
   return Y3_OK;
 }
 
+template <typename T>
+int launch_halo_pp(const HaloArgs &a0, hipStream_t s) {
+  HaloArgs a = a0;
+  const int hr = 256 + 2 * a.W + 2;
+  a.na = y3_ceil_div(hr, 64);
+  a.hr_pad = a.na * 64;
+  a.a_bytes = a.hr_pad * 128;
+  size_t lds = (size_t)3 * 128 * 128 + (size_t)2 * a.a_bytes;
+  if (lds < (size_t)256 * 128 * 4) lds = (size_t)256 * 128 * 4;
+  Y3_REQUIRE(a.na <= 8 && lds <= 160 * 1024, "halo ping-pong kernel: row width %d does not fit", a.W);
+  static bool attr_set = false;
+  if (!attr_set) {
+    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo3x3_pp_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_halo3x3_pp_kernel<T>), dim3(y3_ceil_div(a.M, 256) * a.n_tiles), dim3(512), lds, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
 }  // namespace
+
+int g_y3_halo_pp = 1;
+int g_y3_halo_bm = 0;   // tuning knob "halo_pp": use the ping-pong schedule for 256-pixel tiles
 
 // picks the pixel-tile height (256 or 192) that wastes the fewest CU rounds; 0 = not applicable
 int y3_conv_halo_bm(const y3_op &op) {
@@ -396,13 +669,18 @@ int y3_conv_halo_bm(const y3_op &op) {
   int best = 0;
   double best_eff = 0.0;
   const int cands[2] = {256, 192};
+  const bool pp_only = g_y3_halo_pp && !g_y3_halo_bm;   // default: only the ping-pong 256-pixel tile, and only
+                                                         // where it fills the 256 CUs evenly (else implicit GEMM)
   for (int bm : cands) {
     const HaloGeom g = halo_geom(bm, op.in_w);
     if (g.nsb == 0) continue;
+    if (g_y3_halo_bm && bm != g_y3_halo_bm) continue;
+    if (pp_only && bm != 256) continue;
     const double blocks = (double)((m + bm - 1) / bm) * n_tiles;
     const double rounds = blocks / 256.0;
     const double eff = rounds / (double)(long long)(rounds + 0.999999);
     const double score = eff * (bm == 256 ? 1.04 : 1.0) * (g.nsb == 4 ? 1.03 : 1.0);
+    if (pp_only && eff < 0.9) continue;
     if (score > best_eff) { best_eff = score; best = bm; }
   }
   return best;
@@ -437,6 +715,7 @@ int y3_launch_conv_halo(const y3_op &op, int bm, const void *d_in, const void *d
   Y3_REQUIRE((long long)op.batch * a.HW < (1ll << 31), "conv block %d: too many pixels for the 32-bit tile index", op.block_idx);
   const HaloGeom g = halo_geom(bm, op.in_w);
   Y3_REQUIRE(g.nsb != 0, "conv block %d: halo tile does not fit in LDS", op.block_idx);
+  if (bm == 256 && g_y3_halo_pp) return bf ? launch_halo_pp<bf16_t>(a, s) : launch_halo_pp<float>(a, s);
   if (bf) {
     if (bm == 256) return g.nsb == 4 ? launch_halo<bf16_t, 256, 4>(a, g, s) : launch_halo<bf16_t, 256, 3>(a, g, s);
     return g.nsb == 4 ? launch_halo<bf16_t, 192, 4>(a, g, s) : launch_halo<bf16_t, 192, 3>(a, g, s);

@@ -38,6 +38,7 @@ struct IgemmArgs {
   int k_ld, K;
   int n_ktiles, ktiles_per_tap;
   int m_tiles, n_tiles;
+  uint32_t mul_hw, sh_hw, mul_w, sh_w;   // n / d == (umulhi(n, mul) + n) >> sh  for n < 2^31 (d = HoWo, Wo)
   uint32_t flags;
 };
 
@@ -311,20 +312,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
     a_base[i] = p.zero;
     a_taps[i] = 0u;
     if (m < p.M) {
-      const int b = m / p.HoWo;
-      const int rem = m - b * p.HoWo;
-      const int oy = rem / p.Wo;
-      const int ox = rem - oy * p.Wo;
-      const int iy0 = oy * p.stride - p.pad;
-      const int ix0 = ox * p.stride - p.pad;
+      const uint32_t um = (uint32_t)m;
+      const uint32_t b = (__umulhi(um, p.mul_hw) + um) >> p.sh_hw;
+      const uint32_t rem = um - b * (uint32_t)p.HoWo;
+      const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
+      const uint32_t ox = rem - oy * (uint32_t)p.Wo;
+      const int iy0 = (int)oy * p.stride - p.pad;
+      const int ix0 = (int)ox * p.stride - p.pad;
       const long long pix = ((long long)b * p.H + iy0) * p.W + ix0;
       a_base[i] = p.in + pix * p.in_ld * ES + (KMODE == 0 ? kc * 16 : 0);
-      uint32_t mask = 0u;
+      // tap (ky,kx) is inside the image iff row ky and column kx both are: build the ks*ks mask from
+      // two ks-bit masks (2*ks compares instead of ks*ks)
+      uint32_t vx = 0u, mask = 0u;
+      for (int kx = 0; kx < p.ks; ++kx) vx |= ((unsigned)(ix0 + kx) < (unsigned)p.W ? 1u : 0u) << kx;
       for (int ky = 0; ky < p.ks; ++ky)
-        for (int kx = 0; kx < p.ks; ++kx) {
-          const bool ok = (unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W;
-          mask |= (ok ? 1u : 0u) << (ky * p.ks + kx);
-        }
+        if ((unsigned)(iy0 + ky) < (unsigned)p.H) mask |= vx << (ky * p.ks);
       a_taps[i] = mask;
     }
   }
@@ -389,6 +391,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
 
   const int fr = lane & 15, fq = lane >> 4;
 
+  // write-out role of this thread (epilogue): 8 channels [co, co+8) of pixels (tid / OCT_PER_ROW) + k*(NT / OCT_PER_ROW)
+  constexpr int OCT_PER_ROW = BN / 8;
+  constexpr int WR = RP * OCT_PER_ROW / NT;          // write-out steps per thread and pass
+  static_assert(WR * NT == RP * OCT_PER_ROW && NT % OCT_PER_ROW == 0, "write-out must tile evenly");
+  const int oc_mine = tid % OCT_PER_ROW;
+  const int co = n0 + oc_mine * 8;
+  const bool has_res = p.flags & Y3_F_RESIDUAL;
+  // residual prefetch (16 bytes per step) only for the single-pass bf16 layout it was written for
+  const bool res_fast = has_res && EP == 1 && sizeof(T) == 2 && (p.res_ld % 8) == 0 && co + 8 <= p.Cout;
+  u32x4 resv[WR];
+  f32x4 sc_lo, sc_hi, bi_lo, bi_hi;
+
   Y3_STAMP(0);
   issue(0, 0);
   for (int kt = 0; kt < p.n_ktiles; ++kt) {
@@ -420,19 +434,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
       __builtin_amdgcn_s_setprio(0);
     }
   }
-  __syncthreads();  // all MFMA operand reads done: the stages can hold the output tile
+  // the epilogue's global reads go out first; a raw barrier (no vmcnt drain) lets them fly while the
+  // accumulators are parked in LDS
+  sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
+  sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+  bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
+  bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+  if (res_fast) {
+#pragma unroll
+    for (int j = 0; j < WR; ++j) {
+      const int m = m0 + (tid / OCT_PER_ROW) + j * (NT / OCT_PER_ROW);
+      const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
+      resv[j] = (m < p.M && co < p.Cout) ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // this wave's fragment reads are done ...
+  __builtin_amdgcn_s_barrier();         // ... and everyone's: the stages can hold the output tile
   Y3_STAMP(2);
 
-  // ---- epilogue: scale/bias/activation in registers, park the fp32 tile in LDS, then write it out
-  // as whole 16-byte chunks.  Tile row = pixel (BN floats); its 16-byte chunk index is XOR-ed with
-  // the pixel so that the 16 lanes holding the same channels of 16 pixels hit different banks.
+  // ---- epilogue: raw fp32 accumulators -> LDS (pixel rows, 16-byte chunks XOR-swizzled with the pixel so
+  // the 16 lanes holding the same channels of 16 pixels hit different banks); then every thread finishes 8
+  // consecutive channels of one pixel per step: scale/bias, LeakyReLU, + residual, one 16-byte store.
   constexpr int CPR = BN / 4;  // 16-byte chunks per tile row
   constexpr int SWZ = (CPR < 16 ? CPR : 16) - 1;
-  constexpr int OCT_PER_ROW = BN / 8;
   float *sC = reinterpret_cast<float *>(smem);
   const bool leaky = p.flags & Y3_F_LEAKY;
-  const bool has_res = p.flags & Y3_F_RESIDUAL;
   const bool out_f32 = (p.flags & Y3_F_OUT_F32) || sizeof(T) == 4;
+  const int nvalid = p.Cout - co < 8 ? p.Cout - co : 8;   // <= 0: this thread's channels are padding
 #pragma unroll
   for (int h = 0; h < EP; ++h) {
     if (h > 0) __syncthreads();
@@ -440,45 +468,41 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int cl = wn * TN + ni * 16 + fq * 4;  // channel inside the tile (multiple of 4)
-        const f32x4 sc = *reinterpret_cast<const f32x4 *>(p.scale + n0 + cl);
-        const f32x4 bi = *reinterpret_cast<const f32x4 *>(p.bias + n0 + cl);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           const int pl = wm * TM + mi * 16 + fr - h * RP;
-          f32x4 v;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float t = acc[mi][ni][r] * sc[r] + bi[r];
-            if (leaky) t = t > 0.f ? t : Y3_LEAKY_SLOPE * t;
-            v[r] = t;
-          }
-          *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = v;
+          *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
         }
       }
     }
     __syncthreads();
-    for (int o = tid; o < RP * OCT_PER_ROW; o += NT) {
-      const int pl = o / OCT_PER_ROW, oc = o - pl * OCT_PER_ROW;
+    if (nvalid <= 0) continue;
+#pragma unroll
+    for (int j = 0; j < WR; ++j) {
+      const int pl = (tid / OCT_PER_ROW) + j * (NT / OCT_PER_ROW);
       const int m = m0 + h * RP + pl;
-      const int co = n0 + oc * 8;
-      if (m >= p.M || co >= p.Cout) continue;
-      const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc) ^ (pl & SWZ)) << 2));
-      const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc + 1) ^ (pl & SWZ)) << 2));
-      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      const int nvalid = p.Cout - co < 8 ? p.Cout - co : 8;
+      if (m >= p.M) continue;
+      const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
+      const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = lo[r] * sc_lo[r] + bi_lo[r];
+        v[4 + r] = hi[r] * sc_hi[r] + bi_hi[r];
+      }
+      if (leaky) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : Y3_LEAKY_SLOPE * v[r];
+      }
       if (has_res) {
-        const T *rp = reinterpret_cast<const T *>(p.res) + (long long)m * p.res_ld + co;
-        if (nvalid == 8 && (p.res_ld % CE) == 0) {
+        if (res_fast) {
           if constexpr (sizeof(T) == 2) {
-            const bf16x8 rv = *reinterpret_cast<const bf16x8 *>(rp);
+            const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[j]);
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
-          } else {
-            const f32x4 r0 = *reinterpret_cast<const f32x4 *>(rp), r1 = *reinterpret_cast<const f32x4 *>(rp + 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
           }
         } else {
+          const T *rp = reinterpret_cast<const T *>(p.res) + (long long)m * p.res_ld + co;
           for (int r = 0; r < nvalid; ++r) v[r] += y3_to_float<T>(rp[r]);
         }
       }
@@ -554,6 +578,14 @@ bool y3_conv_igemm_supported(const y3_op &op) {
   return true;
 }
 
+// n / d == (umulhi(n, mul) + n) >> sh for 0 <= n < 2^31 (round-up method, d >= 1)
+static void igemm_fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
+  if (d <= 1) { mul = 0; sh = 0; return; }
+  sh = 0;
+  while ((1u << sh) < d) ++sh;
+  mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
+}
+
 // process-wide tuning knobs (y3_set_tuning): kernel generation and tile override, for A/B runs
 static int g_igemm_version = 2;   // 1 = register-staged single buffer, 2 = LDS-DMA double buffer
 static int g_igemm_bm = 0;        // 0 = heuristic, else 128 / 256 (256 = 8-wave tile, v2 bf16 only)
@@ -563,6 +595,8 @@ extern "C" int y3_set_tuning(const char *key, int value) {
   if (!strcmp(key, "igemm_version")) { g_igemm_version = value; return Y3_OK; }
   if (!strcmp(key, "igemm_bm")) { g_igemm_bm = value; return Y3_OK; }
   if (!strcmp(key, "conv_halo")) { g_y3_use_halo = value; return Y3_OK; }
+  if (!strcmp(key, "halo_pp")) { g_y3_halo_pp = value; return Y3_OK; }
+  if (!strcmp(key, "halo_bm")) { g_y3_halo_bm = value; return Y3_OK; }
   y3_set_error("y3_set_tuning: unknown key %s", key);
   return Y3_ERR_INVALID;
 }
@@ -599,6 +633,9 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
   Y3_REQUIRE(a.n_ktiles * bke <= op.k_ld, "conv block %d: k_ld %d too small for %d K-tiles", op.block_idx, op.k_ld, a.n_ktiles);
   a.m_tiles = a.n_tiles = 0;
   a.flags = op.flags;
+  Y3_REQUIRE((long long)op.batch * a.HoWo < (1ll << 31), "conv block %d: too many output pixels for the 32-bit tile index", op.block_idx);
+  igemm_fast_div((uint32_t)a.HoWo, a.mul_hw, a.sh_hw);
+  igemm_fast_div((uint32_t)a.Wo, a.mul_w, a.sh_w);
 
   const bool bf = op.dtype == Y3_BF16;
   // channel-tile width follows Cout so narrow layers do not multiply zero padding

@@ -39,9 +39,9 @@ LAYERS = [
 ]
 
 VARIANTS = [
-    ("v1_regstage", {"igemm_version": 1, "igemm_bm": 0, "conv_halo": 0}),
-    ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0}),
-    ("halo", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1}),
+    ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 0, "halo_bm": 0}),
+    ("halo", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 0, "halo_bm": 0}),
+    ("halo_pp256", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 1, "halo_bm": 256}),
 ]
 
 
