@@ -75,14 +75,23 @@ __device__ __forceinline__ unsigned long long y3_now() {
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   return t;
 }
-#define Y3_STAMP_DECL unsigned long long _st_prev = y3_now();
-#define Y3_STAMP(slot)                                                        \
-  do {                                                                        \
-    const unsigned long long _now = y3_now();                                 \
-    if (threadIdx.x == 0) atomicAdd(&g_y3_stamps[slot], _now - _st_prev);     \
-    _st_prev = _now;                                                          \
+#define Y3_STAMP_DECL                                \
+  unsigned long long _st_acc[7] = {0, 0, 0, 0, 0, 0, 0}; \
+  unsigned long long _st_prev = y3_now();
+// accumulate in registers; nothing touches memory until the kernel's last instruction
+#define Y3_STAMP(slot)                            \
+  do {                                            \
+    const unsigned long long _now = y3_now();     \
+    _st_acc[slot] += _now - _st_prev;             \
+    _st_prev = _now;                              \
   } while (0)
-#define Y3_STAMP_COUNT() do { if (threadIdx.x == 0) atomicAdd(&g_y3_stamps[7], 1ull); } while (0)
+#define Y3_STAMP_COUNT()                                                         \
+  do {                                                                           \
+    if (threadIdx.x == 0) {                                                      \
+      for (int _i = 0; _i < 7; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]);   \
+      atomicAdd(&g_y3_stamps[7], 1ull);                                          \
+    }                                                                            \
+  } while (0)
 // defines  extern "C" int NAME(unsigned long long out[8])  that reads + clears this unit's counters
 #define Y3_STAMP_READER(NAME)                                                                        \
   extern "C" int NAME(unsigned long long *out8) {                                                    \

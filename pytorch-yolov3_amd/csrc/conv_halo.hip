@@ -483,6 +483,7 @@ __global__ __launch_bounds__(512) void conv_halo3x3_pp_kernel(HaloArgs p) {
     int issued = 0;
     if (chunk + 1 < p.nchunks && tap < p.na) { issue_halo_pass(chunk + 1, tap); issued += 1; }
     if (s + 2 < nit) { issue_weights(chunk2, tap2, (s + 2) % NSB); issued += NB; }
+    Y3_STAMP(4);   // load segment: reads + LDS-DMA issue
     if (grp == 1 && s != nit - 1) {                   // end of an odd half-step for group 1
       if (issued == NB + 1) wait_vmcnt<NB + 1>();
       else if (issued == NB) wait_vmcnt<NB>();
@@ -491,6 +492,7 @@ __global__ __launch_bounds__(512) void conv_halo3x3_pp_kernel(HaloArgs p) {
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
+    Y3_STAMP(5);   // waits + barrier that end the load segment
     // ================= compute segment =================
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -508,6 +510,7 @@ __global__ __launch_bounds__(512) void conv_halo3x3_pp_kernel(HaloArgs p) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) MmaH<T>::run(acc[mi][ni], wf[g][ni], xf[g][mi]);
     __builtin_amdgcn_s_setprio(0);
+    Y3_STAMP(6);   // compute segment: masks + 32 MFMAs issued
     if (grp == 0 && s != nit - 1) {                   // end of an odd half-step for group 0
       if (issued == NB + 1) wait_vmcnt<NB + 1>();
       else if (issued == NB) wait_vmcnt<NB>();

@@ -271,7 +271,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
 //     as whole 16-byte NHWC chunks (a pixel's channels are contiguous), residual read the same way.
 // KMODE 0: Cin % BKE == 0 (one tap per K-tile)   1: any Cin % CE == 0 (per-chunk tap, slow)
 //       2: BKE % Cin == 0, Cin < BKE (several whole taps per K-tile, e.g. Cin = 32 with bf16)
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KMODE>
+// ST: 0 = LDS-DMA, two stages (default);  1 = register-staged, ONE stage (half the LDS -> more workgroups per CU)
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, int ST>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(IgemmArgs p) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int ES = sizeof(T);
@@ -284,11 +285,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
   constexpr int STAGE = (BM + BN) * 128;
   static_assert(MI >= 1 && NI >= 1 && A_CH >= 1 && B_CH >= 1, "tile too small");
   // the fp32 output tile is written out in EP passes of RP pixel rows each (it must fit in the stages)
-  constexpr int EP = (BM * BN * 4 + 2 * STAGE - 1) / (2 * STAGE) <= 1 ? 1 : 2;
+  constexpr int LDS_BYTES = (ST == 0 ? 2 : 1) * STAGE;
+  constexpr int EP = (BM * BN * 4 + LDS_BYTES - 1) / LDS_BYTES <= 1 ? 1 : ((BM * BN * 4 + LDS_BYTES - 1) / LDS_BYTES <= 2 ? 2 : 4);
   constexpr int RP = BM / EP;
-  static_assert(RP * BN * 4 <= 2 * STAGE && RP % TM == 0, "epilogue tile must fit in the operand stages");
+  static_assert(RP * BN * 4 <= LDS_BYTES && (RP % TM == 0 || TM % RP == 0), "epilogue tile must fit in the operand stages");
 
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
   Y3_STAMP_DECL
   const int tid = threadIdx.x;
@@ -347,9 +349,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void gbl_void;
 
-  auto issue = [&](int kt, int stage) {
-    char *sA = smem + stage * STAGE;
-    char *sB = sA + BM * 128;
+  // source address of this thread's i-th A chunk of K-tile kt (zero page for padding / tail rows)
+  auto a_sources = [&](int kt, const char *(&src)[A_CH]) {
     long long tap_off;
     int tap;
     bool in_k = true;
@@ -374,13 +375,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const bool ok = in_k && ((a_taps[i] >> tap) & 1u);
-      const char *src = ok ? a_base[i] + tap_off : p.zero;
-      __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(sA + wave * 1024 + i * (NT * 16)), 16, 0, 0);
+      src[i] = ok ? a_base[i] + tap_off : p.zero;
     }
+  };
+  auto issue = [&](int kt, int stage) {   // ST == 0: straight into LDS
+    char *sA = smem + stage * STAGE;
+    char *sB = sA + BM * 128;
+    const char *src[A_CH];
+    a_sources(kt, src);
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void *)src[i], (lds_void *)(sA + wave * 1024 + i * (NT * 16)), 16, 0, 0);
     const long long koff = (long long)kt * 128;
 #pragma unroll
     for (int i = 0; i < B_CH; ++i)
       __builtin_amdgcn_global_load_lds((gbl_void *)(b_base[i] + koff), (lds_void *)(sB + wave * 1024 + i * (NT * 16)), 16, 0, 0);
+  };
+  u32x4 a_reg[ST == 1 ? A_CH : 1], b_reg[ST == 1 ? B_CH : 1];
+  auto fetch = [&](int kt) {              // ST == 1: into registers, written to LDS one step later
+    if constexpr (ST == 1) {
+      const char *src[A_CH];
+      a_sources(kt, src);
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) a_reg[i] = *reinterpret_cast<const u32x4 *>(src[i]);
+      const long long koff = (long long)kt * 128;
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) b_reg[i] = *reinterpret_cast<const u32x4 *>(b_base[i] + koff);
+    }
   };
 
   f32x4 acc[MI][NI];
@@ -403,16 +424,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
   u32x4 resv[WR];
   f32x4 sc_lo, sc_hi, bi_lo, bi_hi;
 
-  Y3_STAMP(0);
-  issue(0, 0);
-  for (int kt = 0; kt < p.n_ktiles; ++kt) {
-    const int cur = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt has landed (this wave's pieces)
-    __syncthreads();                                   // ... everyone's; stage cur^1 is free again
-    if (kt == 0) Y3_STAMP(1);
-    if (kt + 1 < p.n_ktiles) issue(kt + 1, cur ^ 1);
-    const char *sA = smem + cur * STAGE;
-    const char *sB = sA + BM * 128;
+  auto compute = [&](const char *sA, const char *sB) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       u32x4 xf[MI], wf[NI];
@@ -432,6 +444,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], wf[ni], xf[mi]);
       __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
+  Y3_STAMP(0);
+  if constexpr (ST == 0) {
+    issue(0, 0);
+    for (int kt = 0; kt < p.n_ktiles; ++kt) {
+      const int cur = kt & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt has landed (this wave's pieces)
+      __syncthreads();                                   // ... everyone's; stage cur^1 is free again
+      if (kt == 0) Y3_STAMP(1);
+      if (kt + 1 < p.n_ktiles) issue(kt + 1, cur ^ 1);
+      compute(smem + cur * STAGE, smem + cur * STAGE + BM * 128);
+    }
+  } else {
+    fetch(0);
+    for (int kt = 0; kt < p.n_ktiles; ++kt) {
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4 *>(smem + tid * 16 + i * (NT * 16)) = a_reg[i];
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4 *>(smem + BM * 128 + tid * 16 + i * (NT * 16)) = b_reg[i];
+      __syncthreads();
+      if (kt == 0) Y3_STAMP(1);
+      if (kt + 1 < p.n_ktiles) fetch(kt + 1);            // next tile's loads fly during the MFMAs
+      compute(smem, smem + BM * 128);
+      __syncthreads();
     }
   }
   // the epilogue's global reads go out first; a raw barrier (no vmcnt drain) lets them fly while the
@@ -464,13 +502,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
 #pragma unroll
   for (int h = 0; h < EP; ++h) {
     if (h > 0) __syncthreads();
-    if ((wm * TM) / RP == h) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int cl = wn * TN + ni * 16 + fq * 4;  // channel inside the tile (multiple of 4)
+    for (int ni = 0; ni < NI; ++ni) {
+      const int cl = wn * TN + ni * 16 + fq * 4;  // channel inside the tile (multiple of 4)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int pl = wm * TM + mi * 16 + fr - h * RP;
+      for (int mi = 0; mi < MI; ++mi) {
+        const int prow = wm * TM + mi * 16;       // first pixel row of this 16-row fragment (compile-time per wm)
+        if (prow / RP == h) {
+          const int pl = prow + fr - h * RP;
           *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
         }
       }
@@ -535,15 +574,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
   Y3_STAMP_COUNT();
 }
 
+static int g_igemm_staging = 0;    // 0 = LDS-DMA two stages, 1 = register-staged one stage
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg2(const IgemmArgs &a0, int kmode, hipStream_t s) {
   IgemmArgs a = a0;
   a.m_tiles = y3_ceil_div(a.M, BM);
   a.n_tiles = y3_ceil_div(a.Cout, BN);
   const dim3 grid(a.m_tiles * a.n_tiles), block(64 * WM * WN);
-  if (kmode == 0) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 0>), grid, block, 0, s, a);
-  else if (kmode == 2) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 2>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 1>), grid, block, 0, s, a);
+  if (g_igemm_staging == 1 && BM == 128) {
+    if (kmode == 0) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 0, 1>), grid, block, 0, s, a);
+    else if (kmode == 2) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 2, 1>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 1, 1>), grid, block, 0, s, a);
+    Y3_HIP_CHECK(hipGetLastError());
+    return Y3_OK;
+  }
+  if (kmode == 0) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 0, 0>), grid, block, 0, s, a);
+  else if (kmode == 2) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 2, 0>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 1, 0>), grid, block, 0, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -594,6 +642,7 @@ extern "C" int y3_set_tuning(const char *key, int value) {
   if (!key) return Y3_ERR_INVALID;
   if (!strcmp(key, "igemm_version")) { g_igemm_version = value; return Y3_OK; }
   if (!strcmp(key, "igemm_bm")) { g_igemm_bm = value; return Y3_OK; }
+  if (!strcmp(key, "igemm_staging")) { g_igemm_staging = value; return Y3_OK; }
   if (!strcmp(key, "conv_halo")) { g_y3_use_halo = value; return Y3_OK; }
   if (!strcmp(key, "halo_pp")) { g_y3_halo_pp = value; return Y3_OK; }
   if (!strcmp(key, "halo_bm")) { g_y3_halo_bm = value; return Y3_OK; }

@@ -320,15 +320,17 @@ class Darknet(object):
         cp.handle = handle
         return cp
 
-    def _get_plan(self, batch, height, width, input_mode):
-        key = (batch, height, width, input_mode, self.dtype, str(self.device))
+    def _get_plan(self, batch, height, width, input_mode, slot=0):
+        # `slot` selects an independent arena + output buffers (one per in-flight batch when the caller
+        # pipelines batches over several HIP streams)
+        key = (batch, height, width, input_mode, self.dtype, str(self.device), slot)
         cp = self._plans.get(key)
         if cp is None:
             cp = self._compile(batch, height, width, input_mode)
             self._plans[key] = cp
         return cp
 
-    def _run(self, x, input_mode, timed=False, fresh=True):
+    def _run(self, x, input_mode, timed=False, fresh=True, slot=0):
         """Launch the plan on torch's current stream.  ``fresh=False`` returns the plan's own
         output buffers (overwritten by the next call with the same shape) -- used by
         ``inference()`` and the benchmark, which consume them immediately."""
@@ -340,7 +342,7 @@ class Darknet(object):
             batch, ch, height, width = x.shape
         if ch != self.net_info["channels"]:
             raise ValueError("input has {} channels, cfg says {}".format(ch, self.net_info["channels"]))
-        cp = self._get_plan(batch, height, width, input_mode)
+        cp = self._get_plan(batch, height, width, input_mode, slot)
         with torch.cuda.device(dev):
             if timed:
                 ms = (ctypes.c_float * cp.n_ops)()
@@ -365,7 +367,7 @@ class Darknet(object):
         x = x.to(device=dev, dtype=torch.float32).contiguous()
         return self._run(x, "f32")
 
-    def forward_frames(self, frames_u8, fresh=True):
+    def forward_frames(self, frames_u8, fresh=True, slot=0):
         """frames_u8: (B,H,W,3) uint8 BGR (numpy or torch).  Same outputs as ``forward`` on
         ``flip(frames)/255`` transposed to NCHW (inference.py:332-333), preprocessing fused
         into the first conv kernel."""
@@ -374,7 +376,7 @@ class Darknet(object):
             frames_u8 = torch.from_numpy(np.ascontiguousarray(frames_u8))
         if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4:
             raise ValueError("expected uint8 (B,H,W,3) frames")
-        return self._run(frames_u8.to(dev).contiguous(), "u8", fresh=fresh)
+        return self._run(frames_u8.to(dev).contiguous(), "u8", fresh=fresh, slot=slot)
 
     def block_output(self, i):
         """(B,C,H,W) float32 copy of block i's output from the last forward.  Needs

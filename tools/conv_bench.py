@@ -39,9 +39,9 @@ LAYERS = [
 ]
 
 VARIANTS = [
-    ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 0, "halo_bm": 0}),
-    ("halo", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 0, "halo_bm": 0}),
-    ("halo_pp256", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 1, "halo_bm": 256}),
+    ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0}),
+    ("v2_regstage1", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 1}),
+    ("halo_pp256", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 1, "halo_bm": 256, "igemm_staging": 0}),
 ]
 
 
@@ -132,7 +132,9 @@ def main():
                         if buf[7]:
                             n = float(buf[7])
                             print("    [%s %s] blocks/launch %.0f  cycles/block: setup %.0f  first-wait %.0f  mainloop %.0f  "
-                                  "epilogue %.0f" % (vname, rd[16:], n / (args.iters + 2), buf[0] / n, buf[1] / n, buf[2] / n, buf[3] / n))
+                                  "epilogue %.0f | per-block sums: s4 %.0f s5 %.0f s6 %.0f" % (
+                                      vname, rd[16:], n / (args.iters + 2), buf[0] / n, buf[1] / n, buf[2] / n, buf[3] / n,
+                                      buf[4] / n, buf[5] / n, buf[6] / n))
         ref = outs[0].float()
         row = dict(layer=name, gflop=flops / 1e9)
         line = "%-22s %7.1f GF |" % (name, flops / 1e9)
