@@ -121,7 +121,9 @@ double y3_plan_op_bytes(const y3_plan *plan, int op_index);
 
 /* kernel family a Y3_OP_CONV op dispatches to: 0 = MFMA implicit GEMM (weights [cout_pad][k_ld] in
  * the op dtype), 1 = 3-channel stem (weights float32 [27][cout_pad]), 2 = direct fallback (same
- * layout as 0); -1 if `op` is not a conv.  The host lays weights out accordingly.             */
+ * layout as 0), 3 = MFMA stem for uint8 BGR frames -> bf16 (weights bf16 [32][32], k = ky*9 + kx*3 +
+ * byte-channel, zero padded; scale/bias 32 floats); -1 if `op` is not a conv.  The host lays weights
+ * out accordingly.                                                                              */
 int y3_conv_path(const y3_op *op);
 
 /* process-wide tuning knob for A/B measurements: "igemm_version" (1 register-staged, 2 LDS-DMA

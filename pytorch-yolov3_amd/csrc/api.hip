@@ -33,9 +33,10 @@ struct y3_plan {
 
 namespace {
 
-// 0 = MFMA implicit GEMM, 1 = 3-channel stem kernel, 2 = direct fallback
+// 0 = MFMA implicit GEMM, 1 = 3-channel stem kernel (VALU), 2 = direct fallback, 3 = MFMA stem (uint8 -> bf16)
 int conv_path(const y3_op &op) {
   const bool net_input = op.flags & (Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR);
+  if (y3_conv_stem_mfma_supported(op)) return 3;
   if (net_input && op.in_c == 3 && op.ksize == 3 && !(op.flags & Y3_F_RESIDUAL)) return 1;
   if (!net_input && y3_conv_igemm_supported(op)) return 0;
   return 2;
@@ -64,6 +65,7 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
           return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run);
         }
         case 1: return y3_launch_conv_small(op, in, s, name, dry_run);
+        case 3: return y3_launch_conv_stem_mfma(op, in, s, name, dry_run);
         default: return y3_launch_conv_direct(op, in, s, name, dry_run);
       }
     }

@@ -115,6 +115,9 @@ int y3_launch_conv_small(const y3_op &op, const void *d_in, hipStream_t s, const
                          bool dry_run);
 int y3_launch_conv_direct(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
                           bool dry_run);
+bool y3_conv_stem_mfma_supported(const y3_op &op);
+int y3_launch_conv_stem_mfma(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
+                             bool dry_run);
 int y3_launch_maxpool(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
                       bool dry_run);
 int y3_launch_upsample(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,

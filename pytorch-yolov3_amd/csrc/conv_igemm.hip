@@ -272,17 +272,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
 // KMODE 0: Cin % BKE == 0 (one tap per K-tile)   1: any Cin % CE == 0 (per-chunk tap, slow)
 //       2: BKE % Cin == 0, Cin < BKE (several whole taps per K-tile, e.g. Cin = 32 with bf16)
 // ST: 0 = LDS-DMA, two stages (default);  1 = register-staged, ONE stage (half the LDS -> more workgroups per CU)
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, int ST>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(IgemmArgs p) {
+// RB: bytes of K per tile row: 128 (default) or 64 (half the LDS per workgroup -> 3 workgroups per CU; the LDS image
+// then swizzles 16-byte chunks with (row >> 1) & 3, conflict-free for the 16-rows x 4-chunks fragment read)
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, int ST, int RB>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RB == 64 ? 3 : 1) void conv_igemm2_kernel(IgemmArgs p) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int ES = sizeof(T);
   constexpr int CE = 16 / ES;
-  constexpr int BKE = 128 / ES;
+  constexpr int BKE = RB / ES;
+  constexpr int CPRW = RB / 16;                      // 16-byte chunks per tile row
+  constexpr int G = RB / 64;                         // 64-byte fragment groups per row
   constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
   constexpr int MI = TM / 16, NI = TN / 16;
-  constexpr int ROWS_PER_PASS = NT / 8;
+  constexpr int ROWS_PER_PASS = NT / CPRW;
   constexpr int A_CH = BM / ROWS_PER_PASS, B_CH = BN / ROWS_PER_PASS;
-  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int STAGE = (BM + BN) * RB;
   static_assert(MI >= 1 && NI >= 1 && A_CH >= 1 && B_CH >= 1, "tile too small");
   // the fp32 output tile is written out in EP passes of RP pixel rows each (it must fit in the stages)
   constexpr int LDS_BYTES = (ST == 0 ? 2 : 1) * STAGE;
@@ -302,9 +306,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
   const int m0 = (tile / p.n_tiles) * BM;
   const int n0 = (tile % p.n_tiles) * BN;
 
-  const int slot = tid & 7;
-  const int row0 = tid >> 3;
-  const int kc = slot ^ (row0 & 7);
+  const int slot = tid % CPRW;
+  const int row0 = tid / CPRW;
+  // logical chunk held at this LDS position (source-side swizzle); rows of later passes keep the same low bits
+  const int kc = RB == 128 ? (slot ^ (row0 & 7)) : (slot ^ ((row0 >> 1) & 3));
 
   const char *a_base[A_CH];
   uint32_t a_taps[A_CH];
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
   int tl = 0, cc = 0, tpt = 1;
   if constexpr (KMODE == 2) {
     const int cpt = p.Cin / CE;  // chunks per tap (power of two because BKE % Cin == 0)
-    tpt = 8 / cpt;
+    tpt = CPRW / cpt;
     tl = kc / cpt;
     cc = kc - tl * cpt;
   }
@@ -380,13 +385,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
   };
   auto issue = [&](int kt, int stage) {   // ST == 0: straight into LDS
     char *sA = smem + stage * STAGE;
-    char *sB = sA + BM * 128;
+    char *sB = sA + BM * RB;
     const char *src[A_CH];
     a_sources(kt, src);
 #pragma unroll
     for (int i = 0; i < A_CH; ++i)
       __builtin_amdgcn_global_load_lds((gbl_void *)src[i], (lds_void *)(sA + wave * 1024 + i * (NT * 16)), 16, 0, 0);
-    const long long koff = (long long)kt * 128;
+    const long long koff = (long long)kt * RB;
 #pragma unroll
     for (int i = 0; i < B_CH; ++i)
       __builtin_amdgcn_global_load_lds((gbl_void *)(b_base[i] + koff), (lds_void *)(sB + wave * 1024 + i * (NT * 16)), 16, 0, 0);
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
       a_sources(kt, src);
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) a_reg[i] = *reinterpret_cast<const u32x4 *>(src[i]);
-      const long long koff = (long long)kt * 128;
+      const long long koff = (long long)kt * RB;
 #pragma unroll
       for (int i = 0; i < B_CH; ++i) b_reg[i] = *reinterpret_cast<const u32x4 *>(b_base[i] + koff);
     }
@@ -420,23 +425,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
   const int co = n0 + oc_mine * 8;
   const bool has_res = p.flags & Y3_F_RESIDUAL;
   // residual prefetch (16 bytes per step) only for the single-pass bf16 layout it was written for
-  const bool res_fast = has_res && EP == 1 && sizeof(T) == 2 && (p.res_ld % 8) == 0 && co + 8 <= p.Cout;
-  u32x4 resv[WR];
+  const bool res_fast = has_res && sizeof(T) == 2 && (p.res_ld % 8) == 0 && co + 8 <= p.Cout;
+  u32x4 resv[EP * WR];
   f32x4 sc_lo, sc_hi, bi_lo, bi_hi;
 
   auto compute = [&](const char *sA, const char *sB) {
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < G; ++g) {
       u32x4 xf[MI], wf[NI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int row = wm * TM + mi * 16 + fr;
-        xf[mi] = *reinterpret_cast<const u32x4 *>(sA + row * 128 + (((g * 4 + fq) ^ (row & 7)) << 4));
+        const int ch = RB == 128 ? ((g * 4 + fq) ^ (row & 7)) : (fq ^ ((row >> 1) & 3));
+        xf[mi] = *reinterpret_cast<const u32x4 *>(sA + row * RB + (ch << 4));
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int row = wn * TN + ni * 16 + fr;
-        wf[ni] = *reinterpret_cast<const u32x4 *>(sB + row * 128 + (((g * 4 + fq) ^ (row & 7)) << 4));
+        const int ch = RB == 128 ? ((g * 4 + fq) ^ (row & 7)) : (fq ^ ((row >> 1) & 3));
+        wf[ni] = *reinterpret_cast<const u32x4 *>(sB + row * RB + (ch << 4));
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
       __syncthreads();                                   // ... everyone's; stage cur^1 is free again
       if (kt == 0) Y3_STAMP(1);
       if (kt + 1 < p.n_ktiles) issue(kt + 1, cur ^ 1);
-      compute(smem + cur * STAGE, smem + cur * STAGE + BM * 128);
+      compute(smem + cur * STAGE, smem + cur * STAGE + BM * RB);
     }
   } else {
     fetch(0);
@@ -464,11 +471,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4 *>(smem + tid * 16 + i * (NT * 16)) = a_reg[i];
 #pragma unroll
-      for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4 *>(smem + BM * 128 + tid * 16 + i * (NT * 16)) = b_reg[i];
+      for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4 *>(smem + BM * RB + tid * 16 + i * (NT * 16)) = b_reg[i];
       __syncthreads();
       if (kt == 0) Y3_STAMP(1);
       if (kt + 1 < p.n_ktiles) fetch(kt + 1);            // next tile's loads fly during the MFMAs
-      compute(smem, smem + BM * 128);
+      compute(smem, smem + BM * RB);
       __syncthreads();
     }
   }
@@ -480,11 +487,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
   bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
   if (res_fast) {
 #pragma unroll
-    for (int j = 0; j < WR; ++j) {
-      const int m = m0 + (tid / OCT_PER_ROW) + j * (NT / OCT_PER_ROW);
-      const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
-      resv[j] = (m < p.M && co < p.Cout) ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
-    }
+    for (int h = 0; h < EP; ++h)
+#pragma unroll
+      for (int j = 0; j < WR; ++j) {
+        const int m = m0 + h * RP + (tid / OCT_PER_ROW) + j * (NT / OCT_PER_ROW);
+        const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
+        resv[h * WR + j] = (m < p.M && co < p.Cout) ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
+      }
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);   // this wave's fragment reads are done ...
   __builtin_amdgcn_s_barrier();         // ... and everyone's: the stages can hold the output tile
@@ -536,7 +545,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
       if (has_res) {
         if (res_fast) {
           if constexpr (sizeof(T) == 2) {
-            const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[j]);
+            const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[h * WR + j]);
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
           }
@@ -574,26 +583,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
   Y3_STAMP_COUNT();
 }
 
+static int g_igemm_version = 2;   // 1 = register-staged single buffer, 2 = LDS-DMA double buffer
+static int g_igemm_bm = 0;        // 0 = heuristic, else 128 / 256 (256 = 8-wave tile, v2 bf16 only)
 static int g_igemm_staging = 0;    // 0 = LDS-DMA two stages, 1 = register-staged one stage
+static int g_igemm_rb = 128;       // bytes of K per tile row (128 or 64)
 
-template <typename T, int BM, int BN, int WM, int WN>
-int launch_cfg2(const IgemmArgs &a0, int kmode, hipStream_t s) {
-  IgemmArgs a = a0;
+template <typename T, int BM, int BN, int WM, int WN, int ST, int RB>
+int launch_cfg2x(IgemmArgs a, int kmode, hipStream_t s) {
   a.m_tiles = y3_ceil_div(a.M, BM);
   a.n_tiles = y3_ceil_div(a.Cout, BN);
   const dim3 grid(a.m_tiles * a.n_tiles), block(64 * WM * WN);
-  if (g_igemm_staging == 1 && BM == 128) {
-    if (kmode == 0) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 0, 1>), grid, block, 0, s, a);
-    else if (kmode == 2) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 2, 1>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 1, 1>), grid, block, 0, s, a);
-    Y3_HIP_CHECK(hipGetLastError());
-    return Y3_OK;
-  }
-  if (kmode == 0) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 0, 0>), grid, block, 0, s, a);
-  else if (kmode == 2) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 2, 0>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 1, 0>), grid, block, 0, s, a);
+  if (kmode == 0) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 0, ST, RB>), grid, block, 0, s, a);
+  else if (kmode == 2) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 2, ST, RB>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 1, ST, RB>), grid, block, 0, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_cfg2(const IgemmArgs &a, int kmode, hipStream_t s) {
+  if (g_igemm_staging == 1 && BM == 128) return launch_cfg2x<T, BM, BN, WM, WN, 1, 128>(a, kmode, s);
+  return launch_cfg2x<T, BM, BN, WM, WN, 0, 128>(a, kmode, s);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -635,14 +645,13 @@ static void igemm_fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
 }
 
 // process-wide tuning knobs (y3_set_tuning): kernel generation and tile override, for A/B runs
-static int g_igemm_version = 2;   // 1 = register-staged single buffer, 2 = LDS-DMA double buffer
-static int g_igemm_bm = 0;        // 0 = heuristic, else 128 / 256 (256 = 8-wave tile, v2 bf16 only)
 
 extern "C" int y3_set_tuning(const char *key, int value) {
   if (!key) return Y3_ERR_INVALID;
   if (!strcmp(key, "igemm_version")) { g_igemm_version = value; return Y3_OK; }
   if (!strcmp(key, "igemm_bm")) { g_igemm_bm = value; return Y3_OK; }
   if (!strcmp(key, "igemm_staging")) { g_igemm_staging = value; return Y3_OK; }
+  if (!strcmp(key, "igemm_rb")) { g_igemm_rb = value; return Y3_OK; }
   if (!strcmp(key, "conv_halo")) { g_y3_use_halo = value; return Y3_OK; }
   if (!strcmp(key, "halo_pp")) { g_y3_halo_pp = value; return Y3_OK; }
   if (!strcmp(key, "halo_bm")) { g_y3_halo_bm = value; return Y3_OK; }
@@ -655,7 +664,10 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
   Y3_REQUIRE(y3_conv_igemm_supported(op), "conv block %d: shape not supported by the igemm kernel",
              op.block_idx);
   const int es = y3_elem_size(op.dtype);
-  const int bke = 128 / es;
+  // K-tile row: 128 bytes, or 64 bytes (tuning knob "igemm_rb": 3 workgroups per CU) for the 128-wide tile
+  const bool rb64 = g_igemm_rb == 64 && g_igemm_version == 2 && op.out_c > 64 && !(op.flags & Y3_F_OUT_F32) &&
+                    g_igemm_bm != 256;
+  const int bke = (rb64 ? 64 : 128) / es;
   IgemmArgs a;
   a.in = static_cast<const char *>(d_in);
   a.wgt = static_cast<const char *>(op.d_weight);
@@ -711,6 +723,11 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
       *kernel_name = "conv_igemm2_bf16_256x128";
       if (dry_run) return Y3_OK;
       return launch_cfg2<bf16_t, 256, 128, 4, 2>(a, kmode, s);
+    }
+    if (rb64) {
+      *kernel_name = bf ? "conv_igemm2_bf16_128x128_k32" : "conv_igemm2_f32_128x128_k16";
+      if (dry_run) return Y3_OK;
+      return bf ? launch_cfg2x<bf16_t, 128, 128, 2, 2, 0, 64>(a, kmode, s) : launch_cfg2x<float, 128, 128, 2, 2, 0, 64>(a, kmode, s);
     }
     *kernel_name = bf ? "conv_igemm2_bf16_128x128" : "conv_igemm2_f32_128x128";
     if (dry_run) return Y3_OK;

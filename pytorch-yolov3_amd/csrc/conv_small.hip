@@ -102,6 +102,112 @@ __global__ __launch_bounds__(256) void conv_stem3x3_kernel(SmallArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA stem for the throughput path (uint8 BGR frames in, bf16 NHWC out, 3x3 stride 1 pad 1, Cout <= 32).
+// K = 27 fits one v_mfma_f32_16x16x32_bf16 step.  A workgroup owns an 8 x 32 pixel tile: the (8+2) x (32+2)
+// input halo is read once (byte loads), normalised (v / 255.0f, correctly rounded, then bf16) into LDS, and
+// every wave builds the im2col fragments of its two pixel rows straight from that image: for one filter row the
+// 9 values (kx, c) of a pixel are 9 consecutive bf16, so K is ordered k = ky*9 + kx*3 + c_mem and the host
+// permutes the weights to match (c_mem = 2 - c_rgb: the BGR->RGB flip costs nothing).
+struct StemMfmaArgs {
+  const uint8_t *in;       // (B, H, W, 3) uint8 BGR
+  const bf16_t *wgt;       // [32][32] bf16: row = output channel, k as above, zero padded
+  const float *scale;
+  const float *bias;
+  bf16_t *out;
+  int B, H, W, Cout, out_ld, tiles_x, tiles_y;
+  uint32_t flags;
+};
+
+constexpr int kStemTH = 8, kStemTW = 32;
+constexpr int kStemRow = (kStemTW + 2) * 3 + 2;   // bf16 elements per halo row (102 used, padded to 104)
+
+__global__ __launch_bounds__(256) void conv_stem_mfma_kernel(StemMfmaArgs p) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[(kStemTH + 2) * kStemRow];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int tx = bid % p.tiles_x;
+  bid /= p.tiles_x;
+  const int ty = bid % p.tiles_y;
+  const int b = bid / p.tiles_y;
+  const int y0 = ty * kStemTH, x0 = tx * kStemTW;
+
+  // ---- stage the normalised halo: (TH+2) rows x (TW+2)*3 bytes ------------------------------------
+  constexpr int ROWB = (kStemTW + 2) * 3;
+  for (int i = tid; i < (kStemTH + 2) * ROWB; i += 256) {
+    const int r = i / ROWB, cb = i - r * ROWB;
+    const int iy = y0 - 1 + r;
+    const int ixb = (x0 - 1) * 3 + cb;            // byte column inside the image row
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)p.H && ixb >= 0 && ixb < p.W * 3)
+      v = (float)p.in[((long long)b * p.H + iy) * p.W * 3 + ixb] / 255.0f;
+    tile[r * kStemRow + cb] = (bf16_t)v;
+  }
+
+  // ---- weights: two A fragments (channels 0-15, 16-31), lane (co = lane&15, q = lane>>4) holds k = 8q..8q+7
+  const int fr = lane & 15, fq = lane >> 4;
+  const bf16x8 w0 = *reinterpret_cast<const bf16x8 *>(p.wgt + (0 + fr) * 32 + fq * 8);
+  const bf16x8 w1 = *reinterpret_cast<const bf16x8 *>(p.wgt + (16 + fr) * 32 + fq * 8);
+  // per-lane LDS element offsets of k = 8q + j relative to the pixel's first byte in halo row `row`
+  int koff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = fq * 8 + j;
+    const int ky = k < 27 ? k / 9 : 0, jj = k < 27 ? k - ky * 9 : 0;   // padded k: any valid element (weight is 0)
+    koff[j] = ky * kStemRow + jj;
+  }
+  const int cq = fq * 4;   // this lane's 4 output channels inside a 16-channel fragment
+  f32x4 sc[2], bi[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    sc[ni] = *reinterpret_cast<const f32x4 *>(p.scale + ni * 16 + cq);
+    bi[ni] = *reinterpret_cast<const f32x4 *>(p.bias + ni * 16 + cq);
+  }
+  const bool leaky = p.flags & Y3_F_LEAKY;
+  __syncthreads();
+
+  // ---- each wave: 2 pixel rows x 2 groups of 16 pixels ------------------------------------------------
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int row = wave * 2 + rr;
+    const int oy = y0 + row;
+#pragma unroll
+    for (int gx = 0; gx < kStemTW / 16; ++gx) {
+      const int px = gx * 16 + fr;
+      const bf16_t *base = tile + row * kStemRow + px * 3;
+      bf16x8 xf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xf[j] = base[koff[j]];
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xf, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xf, acc1, 0, 0, 0);
+      const int ox = x0 + px;
+      if (oy < p.H && ox < p.W) {
+        bf16_t *op = p.out + (((long long)b * p.H + oy) * p.W + ox) * p.out_ld;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const f32x4 a = ni ? acc1 : acc0;
+          const int co = ni * 16 + cq;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t = a[r] * sc[ni][r] + bi[ni][r];
+            if (leaky) t = t > 0.f ? t : Y3_LEAKY_SLOPE * t;
+            v[r] = t;
+          }
+          if (co + 4 <= p.Cout) {
+            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4 *>(op + co) = o;
+          } else {
+            for (int r = 0; r < 4; ++r)
+              if (co + r < p.Cout) op[co + r] = (bf16_t)v[r];
+          }
+        }
+      }
+    }
+  }
+}
+
 struct DirectArgs {
   const void *in;
   const void *wgt;  // [cout_pad][k_ld] element type T
@@ -192,6 +298,31 @@ int y3_launch_conv_small(const y3_op &op, const void *d_in, hipStream_t s, const
     if (out_bf16) hipLaunchKernelGGL((conv_stem3x3_kernel<bf16_t, 0>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((conv_stem3x3_kernel<float, 0>), grid, block, lds, s, a);
   }
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+// MFMA stem: needs weights in its own layout (bf16 [32][32], see yolov3/darknet.py) -> separate conv path (3)
+bool y3_conv_stem_mfma_supported(const y3_op &op) {
+  return (op.flags & Y3_F_IN_NHWC_U8BGR) && !(op.flags & (Y3_F_OUT_F32 | Y3_F_RESIDUAL)) && op.dtype == Y3_BF16 &&
+         op.in_c == 3 && op.ksize == 3 && op.stride == 1 && op.pad == 1 && op.out_c <= 32 && op.out_ld % 4 == 0;
+}
+
+int y3_launch_conv_stem_mfma(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
+                             bool dry_run) {
+  Y3_REQUIRE(y3_conv_stem_mfma_supported(op), "conv block %d: not a shape for the MFMA stem", op.block_idx);
+  *kernel_name = "conv_stem_mfma_u8_bf16";
+  if (dry_run) return Y3_OK;
+  StemMfmaArgs a;
+  a.in = static_cast<const uint8_t *>(d_in);
+  a.wgt = static_cast<const bf16_t *>(op.d_weight);
+  a.scale = op.d_scale; a.bias = op.d_bias;
+  a.out = static_cast<bf16_t *>(op.d_out);
+  a.B = op.batch; a.H = op.in_h; a.W = op.in_w; a.Cout = op.out_c; a.out_ld = op.out_ld;
+  a.tiles_x = y3_ceil_div(op.in_w, kStemTW);
+  a.tiles_y = y3_ceil_div(op.in_h, kStemTH);
+  a.flags = op.flags;
+  hipLaunchKernelGGL(conv_stem_mfma_kernel, dim3(a.tiles_x * a.tiles_y * op.batch), dim3(256), 0, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }

@@ -180,7 +180,16 @@ class Darknet(object):
         cout, cin, k = c["cout"], c["cin"], c["k"]
         w = self._params[slot]["weight"].astype(np.float32)
         scale, bias = self._fold_bn(slot)
-        if path == _hip.PATH_STEM:
+        if path == _hip.PATH_STEM_MFMA:
+            # bf16 [32][32]: row = output channel, k = ky*9 + kx*3 + c_mem with c_mem the BYTE order of the
+            # uint8 BGR frame (c_mem = 2 - c_rgb), zero padded (csrc/conv_small.hip: conv_stem_mfma_kernel)
+            cout_pad = 32
+            k_ld = 32
+            host = np.zeros((32, 32), dtype=np.float32)
+            wk = w[:, ::-1, :, :].transpose(0, 2, 3, 1).reshape(cout, 27)      # (co, ky, kx, c_mem)
+            host[:cout, :27] = wk
+            dw = torch.from_numpy(f32_to_bf16_bits(host).view(np.int16)).to(dev)
+        elif path == _hip.PATH_STEM:
             cout_pad = _round_up(cout, 8)
             k_ld = cout_pad
             host = np.zeros((k * k * cin, cout_pad), dtype=np.float32)

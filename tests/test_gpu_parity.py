@@ -86,6 +86,45 @@ def test_mini_bf16_close_to_fp32():
     assert np.median(dp) < 5e-3 and dp.max() < 0.3
 
 
+def test_mini_bf16_uint8_stem_matches_bf16_float_stem():
+    """bf16 mode has two first-layer kernels: the MFMA stem (uint8 frames) and the VALU stem (float input).
+    Same network, same weights: their outputs may differ only by the bf16 rounding of the 27 inputs."""
+    g = np.load(os.path.join(GOLDEN, "mini_blocks.npz"))
+    net = _net("mini", dtype="bf16")
+    a = net.forward(torch.from_numpy(g["input"]))
+    b = net.forward_frames(g["frames"])
+    d = (a["class_prob"] - b["class_prob"]).abs().cpu().numpy()
+    assert np.median(d) < 2e-3 and d.max() < 0.1
+    assert (a["class_idx"] == b["class_idx"]).float().mean() > 0.97
+
+
+def test_tuning_knobs_do_not_change_results():
+    """Every kernel variant behind y3_set_tuning computes the same convolution (fp32: same values up to
+    summation order)."""
+    from yolov3 import _hip
+    lib = _hip.lib()
+    g = np.load(os.path.join(GOLDEN, "mini_blocks.npz"))
+    x = torch.from_numpy(g["input"])
+    ref = _net("mini").forward(x)
+    try:
+        for knobs in ({"igemm_version": 1}, {"igemm_staging": 1}, {"igemm_rb": 64}, {"conv_halo": 1, "halo_pp": 0},
+                      {"conv_halo": 1, "halo_pp": 1, "halo_bm": 256}):
+            for k, v in knobs.items():
+                _hip.check(lib.y3_set_tuning(k.encode(), v))
+            out = _net("mini").forward(x)
+            np.testing.assert_allclose(out["class_prob"].cpu().numpy(), ref["class_prob"].cpu().numpy(), atol=2e-5,
+                                       err_msg=str(knobs))
+            np.testing.assert_allclose(out["bbox_xywh"].cpu().numpy(), ref["bbox_xywh"].cpu().numpy(), rtol=1e-4,
+                                       atol=1e-5, err_msg=str(knobs))
+            for k in knobs:
+                _hip.check(lib.y3_set_tuning(k.encode(), {"igemm_version": 2, "igemm_rb": 128}.get(k, 0)))
+    finally:
+        for k, v in (("igemm_version", 2), ("igemm_staging", 0), ("igemm_rb", 128), ("conv_halo", 0), ("halo_pp", 1),
+                     ("halo_bm", 0), ("igemm_bm", 0)):
+            lib.y3_set_tuning(k.encode(), v)
+    assert lib.y3_set_tuning(b"no_such_knob", 1) != 0
+
+
 @pytest.mark.parametrize("model", ["yolov3-tiny", "yolov3", "yolov3-spp"])
 def test_forward_golden_fp32(model):
     g = np.load(os.path.join(GOLDEN, "forward_%s.npz" % model))
@@ -202,6 +241,24 @@ def test_shape_sweep_bf16(model, dim, batch):
     assert out["class_prob"].shape == (batch, 3 * cells) and out["class_idx"].shape == (batch, 3 * cells)
     assert torch.isfinite(out["bbox_xywh"]).all() and torch.isfinite(out["class_prob"]).all()
     assert int(out["class_idx"].min()) >= 0 and int(out["class_idx"].max()) < 80
+
+
+def test_halo_kernels_match_igemm_on_yolov3_fp32():
+    """The experimental halo-reuse 3x3 kernels (off by default) against the goldens, whole network."""
+    from yolov3 import _hip
+    lib = _hip.lib()
+    g = np.load(os.path.join(GOLDEN, "forward_yolov3.npz"))
+    frames = np.stack([resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), 608, 608), synth_frames(5, 1, 608, 608)[0]])
+    try:
+        for pp in (0, 1):
+            _hip.check(lib.y3_set_tuning(b"conv_halo", 1))
+            _hip.check(lib.y3_set_tuning(b"halo_pp", pp))
+            out = _net("yolov3").forward(torch.from_numpy(orc.frames_to_input(list(frames))))
+            np.testing.assert_allclose(out["bbox_xywh"].cpu().numpy(), g["bbox_xywh"], rtol=1e-4, atol=BOX_ATOL)
+            np.testing.assert_allclose(out["class_prob"].cpu().numpy(), g["class_prob"], atol=SCORE_ATOL)
+    finally:
+        lib.y3_set_tuning(b"conv_halo", 0)
+        lib.y3_set_tuning(b"halo_pp", 1)
 
 
 def test_bf16_agreement_report_yolov3():

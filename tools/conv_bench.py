@@ -39,9 +39,9 @@ LAYERS = [
 ]
 
 VARIANTS = [
-    ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0}),
-    ("v2_regstage1", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 1}),
-    ("halo_pp256", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 1, "halo_bm": 256, "igemm_staging": 0}),
+    ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128}),
+    ("v2_rb64", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 64}),
+    ("halo_pp256", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 1, "halo_bm": 256, "igemm_staging": 0, "igemm_rb": 128}),
 ]
 
 
