@@ -168,8 +168,17 @@ def main():
         dk = by_kernel[dominant]
         achieved = dk["flops"] / (dk["ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
+        # HBM-side traffic of the dominant kernel comes from a separate rocprofv3 PMC run (FETCH_SIZE / WRITE_SIZE
+        # cannot share a pass, and counters cannot be read from inside this process); the committed summary of
+        # that run is looked up here, null if it does not cover this kernel
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                traffic = json.load(fh).get(dominant, {}).get("traffic_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         report = dict(by_kernel=by_kernel, dominant=dominant, achieved=achieved, peak=peak,
-                      plan_ms=float(per_op.sum()))
+                      plan_ms=float(per_op.sum()), traffic=traffic)
 
     # ---- CPU baseline: the oracle (reference "-d cpu" op sequence) on a bounded sample ----------
     cpu = None
@@ -208,7 +217,11 @@ def main():
                        "collective": "all_gather(%d x %d x 8 int32 records)" % (b, args.kmax) if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": report["dominant"], "achieved": round(report["achieved"], 2),
                          "peak": report["peak"], "unit": "TFLOP/s", "frac": round(report["achieved"] / report["peak"], 4),
-                         "traffic": None,
+                         "traffic": report["traffic"],
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_traffic.json)",
+                         "algorithmic_bytes_per_launch": round(report["by_kernel"][report["dominant"]]["bytes"] /
+                                                               report["by_kernel"][report["dominant"]]["launches"]),
+                         "timing": "HIP events around every launch, serial passes on the launch stream",
                          "launches_per_step": report["by_kernel"][report["dominant"]]["launches"],
                          "kernel_ms_per_step": round(report["by_kernel"][report["dominant"]]["ms"], 4),
                          "all_kernels_ms_per_step": round(report["plan_ms"], 4)},
