@@ -108,6 +108,15 @@ __device__ __forceinline__ unsigned long long y3_now() {
 #define Y3_STAMP_COUNT() do {} while (0)
 #endif
 
+// Y3_STAMPS_FINE (diagnostic): the ping-pong kernel stamps the pieces of its K-step instead of its phases
+#if defined(Y3_STAMPS) && defined(Y3_STAMPS_FINE)
+#define Y3_FINE(slot) Y3_STAMP(slot)
+#define Y3_COARSE(slot) do { _st_prev = y3_now(); } while (0)
+#else
+#define Y3_FINE(slot) do {} while (0)
+#define Y3_COARSE(slot) Y3_STAMP(slot)
+#endif
+
 // launchers implemented in the .hip files; each fills *kernel_name with a static string
 int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
                          const char **kernel_name, bool dry_run);

@@ -188,12 +188,19 @@ __global__ __launch_bounds__(BM * 2) void conv_halo3x3_kernel(HaloArgs p) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
       if (!((tapmask[mi] >> tap) & 1u)) xf[mi] = u32x4{0u, 0u, 0u, 0u};
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) MmaH<T>::run(acc[mi][ni], wf[ni], xf[mi]);
-    __builtin_amdgcn_s_setprio(0);
+  };
+  // scheduling recipe for one half-step: the 8 fragment reads of the OTHER register set ride in the gaps of
+  // this set's 16 MFMAs (bf16: 2 MFMAs per read; fp32: 8), instead of being issued as one LDS burst up front
+  auto interleave = [&]() {
+#pragma unroll
+    for (int i = 0; i < MI + NI; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          // one DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 2 : 8, 0);     // its share of the MFMAs
+    }
   };
 
   // ---- first operands: halo(0), weights(0), weights(1) must have landed ----------------------------
@@ -233,9 +240,10 @@ __global__ __launch_bounds__(BM * 2) void conv_halo3x3_kernel(HaloArgs p) {
 
     const char *aBuf = sA + (chunk & 1) * p.a_bytes;
     const int ky = (tap * 11) >> 5, kx = tap - ky * 3;         // tap / 3, tap % 3 for tap in 0..8
-    read_frags(xf1, wf1, aBuf, sB + (it % NSB) * B_BYTES, ky * p.W + kx, 1);   // second half of this step ...
     __builtin_amdgcn_sched_barrier(0);
+    read_frags(xf1, wf1, aBuf, sB + (it % NSB) * B_BYTES, ky * p.W + kx, 1);   // second half of this step ...
     mma_all(xf0, wf0, tap);                                    // ... flies under the first half's MFMAs
+    interleave();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xC07F);   // second-half fragments (16 MFMAs old); keeps <= 8 LDS reads in flight
     const int tap_n = tap == 8 ? 0 : tap + 1;
@@ -244,8 +252,8 @@ __global__ __launch_bounds__(BM * 2) void conv_halo3x3_kernel(HaloArgs p) {
       const int ky_n = (tap_n * 11) >> 5, kx_n = tap_n - ky_n * 3;   // in-bounds read after the last one)
       read_frags(xf0, wf0, sA + (chunk_n & 1) * p.a_bytes, sB + ((it + 1) % NSB) * B_BYTES, ky_n * p.W + kx_n, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);
     mma_all(xf1, wf1, tap);
+    interleave();
     __builtin_amdgcn_sched_barrier(0);
     // the prefetched fragments have had 16 MFMAs of time; retiring them here (lgkmcnt(0) only, in a form
     // hipcc's wait-count pass understands) lets it issue the next step's first MFMAs without a wait
@@ -429,10 +437,10 @@ __global__ __launch_bounds__(512) void conv_halo3x3_pp_kernel(HaloArgs p) {
   const int b_off0 = b_lane_row * 128 + (((0 + fq) ^ (b_lane_row & 7)) << 4);
   const int b_off1 = b_lane_row * 128 + (((4 + fq) ^ (b_lane_row & 7)) << 4);
 
-  Y3_STAMP(0);
+  Y3_COARSE(0);
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
-  Y3_STAMP(1);
+  Y3_COARSE(1);
   if (grp) __builtin_amdgcn_s_barrier();              // group 1 runs one segment behind group 0
 
   // write-out role of this thread (epilogue): 8 channels [co, co+8) of pixels (tid>>4) + 32*j
@@ -479,20 +487,23 @@ __global__ __launch_bounds__(512) void conv_halo3x3_pp_kernel(HaloArgs p) {
         }
       }
     }
+    Y3_FINE(0);   // [barrier wait that started this load segment ... fragment reads issued]
     // the fragment reads' latency hides under the LDS-DMA issue below
     int issued = 0;
     if (chunk + 1 < p.nchunks && tap < p.na) { issue_halo_pass(chunk + 1, tap); issued += 1; }
     if (s + 2 < nit) { issue_weights(chunk2, tap2, (s + 2) % NSB); issued += NB; }
-    Y3_STAMP(4);   // load segment: reads + LDS-DMA issue
+    Y3_FINE(1);   // LDS-DMA issue
     if (grp == 1 && s != nit - 1) {                   // end of an odd half-step for group 1
       if (issued == NB + 1) wait_vmcnt<NB + 1>();
       else if (issued == NB) wait_vmcnt<NB>();
       else if (issued == 1) wait_vmcnt<1>();
       else wait_vmcnt<0>();
     }
+    Y3_FINE(2);   // vmcnt wait (group 1 only)
     __builtin_amdgcn_s_waitcnt(0xC07F);
+    Y3_FINE(3);   // fragment reads landed
     __builtin_amdgcn_s_barrier();
-    Y3_STAMP(5);   // waits + barrier that end the load segment
+    Y3_FINE(4);   // barrier (waiting for the partner group's compute segment)
     // ================= compute segment =================
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -510,7 +521,7 @@ __global__ __launch_bounds__(512) void conv_halo3x3_pp_kernel(HaloArgs p) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) MmaH<T>::run(acc[mi][ni], wf[g][ni], xf[g][mi]);
     __builtin_amdgcn_s_setprio(0);
-    Y3_STAMP(6);   // compute segment: masks + 32 MFMAs issued
+    Y3_FINE(5);   // masks + 32 MFMAs issued
     if (grp == 0 && s != nit - 1) {                   // end of an odd half-step for group 0
       if (issued == NB + 1) wait_vmcnt<NB + 1>();
       else if (issued == NB) wait_vmcnt<NB>();
@@ -518,6 +529,7 @@ __global__ __launch_bounds__(512) void conv_halo3x3_pp_kernel(HaloArgs p) {
       else wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
+    Y3_FINE(6);   // vmcnt wait (group 0) + barrier (waiting for the partner group's load segment)
     tap = tap == 8 ? 0 : tap + 1;
     chunk += tap == 0 ? 1 : 0;
     tap2 = tap2 == 8 ? 0 : tap2 + 1;
@@ -525,7 +537,7 @@ __global__ __launch_bounds__(512) void conv_halo3x3_pp_kernel(HaloArgs p) {
   }
   if (!grp) __builtin_amdgcn_s_barrier();             // balance group 1's extra barrier
   __syncthreads();
-  Y3_STAMP(2);
+  Y3_COARSE(2);
 
   // ---- epilogue (as above): raw fp32 tile -> LDS -> 8 channels of one pixel per thread-step ----------
   constexpr int SWZ = 15;
@@ -582,7 +594,7 @@ __global__ __launch_bounds__(512) void conv_halo3x3_pp_kernel(HaloArgs p) {
       *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
     }
   }
-  Y3_STAMP(3);
+  Y3_COARSE(3);
   Y3_STAMP_COUNT();
 }
 

@@ -40,7 +40,8 @@ LAYERS = [
 
 VARIANTS = [
     ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128}),
-    ("v2_rb64", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 64}),
+    ("halo_il256", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 0, "halo_bm": 256, "igemm_staging": 0, "igemm_rb": 128}),
+    ("halo_il192", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 0, "halo_bm": 192, "igemm_staging": 0, "igemm_rb": 128}),
     ("halo_pp256", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 1, "halo_bm": 256, "igemm_staging": 0, "igemm_rb": 128}),
 ]
 
@@ -132,7 +133,7 @@ def main():
                         if buf[7]:
                             n = float(buf[7])
                             print("    [%s %s] blocks/launch %.0f  cycles/block: setup %.0f  first-wait %.0f  mainloop %.0f  "
-                                  "epilogue %.0f | per-block sums: s4 %.0f s5 %.0f s6 %.0f" % (
+                                  "epilogue %.0f | slots 4-6: %.0f %.0f %.0f" % (
                                       vname, rd[16:], n / (args.iters + 2), buf[0] / n, buf[1] / n, buf[2] / n, buf[3] / n,
                                       buf[4] / n, buf[5] / n, buf[6] / n))
         ref = outs[0].float()
