@@ -164,6 +164,12 @@ int y3_nms(const int64_t *d_tlbr, const float *d_prob, const int64_t *d_cls, int
 /* cxywh_to_tlbr (inference.py:269-283) on int64 rows of `cols` >= 4 columns ---------------- */
 int y3_cxywh_to_tlbr(const int64_t *d_xywh, int64_t *d_tlbr, int n, int cols, void *stream);
 
+/* frame resize on device (replaces the host cv2.resize of inference.py:320-326): uint8
+ * (src_h,src_w,3) -> (dst_h,dst_w,3), fixed-point bilinear.  d_ytab (dst_h,4) / d_xtab (dst_w,4) int32 rows =
+ * {lo index, hi index, weight_lo, weight_hi} with weights summing to 2048 (yolov3/preprocess.py:axis_table). */
+int y3_resize_bilinear_u8(const uint8_t *d_src, int src_h, int src_w, uint8_t *d_dst, int dst_h, int dst_w,
+                          const int32_t *d_ytab, const int32_t *d_xtab, void *stream);
+
 /* padded fixed-size detection records for the multi-GPU all-gather (no reference counterpart:
  * the reference is single device).  Record = 8 x int32: x1,y1,x2,y2, score bits, class, row, valid.
  * d_records (batch, kmax, 8) int32, d_counts passthrough of min(count,kmax) in slot [b][0][7]... */

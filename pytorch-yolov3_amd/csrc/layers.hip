@@ -211,3 +211,39 @@ int y3_launch_copy(const y3_op &op, const void *d_in, hipStream_t s, const char 
   *kernel_name = op.dtype == Y3_BF16 ? "copy_bf16" : "copy_f32";
   return launch_layer(COPY, op, d_in, s, dry_run);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Frame resize on device: uint8 HxWx3 -> net_h x net_w x 3, fixed-point bilinear.
+// Replaces the host `cv2.resize(image, (net_h, net_w))` of /root/reference/yolov3/inference.py:320-326 for
+// frames that are not net-sized.  Integer arithmetic only, identical to yolov3/preprocess.py:
+// resize_bilinear_u8 (the tap tables -- lo index, hi index, 11-bit weights per output row / column -- are
+// computed once on the host and passed in, so host and device results are bit-identical).
+namespace {
+__global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t *src, int sh, int sw, uint8_t *dst, int dh,
+                                                        int dw, const int *ytab, const int *xtab) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= dh * dw) return;
+  const int y = idx / dw, x = idx - y * dw;
+  const int ylo = ytab[y * 4 + 0], yhi = ytab[y * 4 + 1], wy0 = ytab[y * 4 + 2], wy1 = ytab[y * 4 + 3];
+  const int xlo = xtab[x * 4 + 0], xhi = xtab[x * 4 + 1], wx0 = xtab[x * 4 + 2], wx1 = xtab[x * 4 + 3];
+  const uint8_t *r0 = src + (long long)ylo * sw * 3, *r1 = src + (long long)yhi * sw * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int top = r0[xlo * 3 + c] * wx0 + r0[xhi * 3 + c] * wx1;
+    const int bot = r1[xlo * 3 + c] * wx0 + r1[xhi * 3 + c] * wx1;
+    int v = (top * wy0 + bot * wy1 + (1 << 21)) >> 22;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    dst[(long long)idx * 3 + c] = (uint8_t)v;
+  }
+}
+}  // namespace
+
+extern "C" int y3_resize_bilinear_u8(const uint8_t *d_src, int src_h, int src_w, uint8_t *d_dst, int dst_h, int dst_w,
+                                     const int32_t *d_ytab, const int32_t *d_xtab, void *stream) {
+  Y3_REQUIRE(d_src && d_dst && d_ytab && d_xtab, "y3_resize_bilinear_u8: null pointer argument");
+  Y3_REQUIRE(src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0, "y3_resize_bilinear_u8: empty image");
+  hipLaunchKernelGGL(resize_u8_kernel, dim3((dst_h * dst_w + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     d_src, src_h, src_w, d_dst, dst_h, dst_w, d_ytab, d_xtab);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}

@@ -9,8 +9,8 @@
 * ``inference()`` runs threshold, scaling, integer truncation, corner conversion and
   per-class NMS in one device kernel per batch (libyolov3_hip ``y3_detect``) and copies
   only the surviving detections back to the host;
-* frames that are not net-sized are resized on the host by ``preprocess.resize_bilinear_u8``
-  (the reference uses ``cv2.resize``; see that module's docstring).
+* frames that are not net-sized are resized on the GPU (``y3_resize_bilinear_u8``, bit-identical to
+  ``preprocess.resize_bilinear_u8``; the reference uses ``cv2.resize``, see that module's docstring).
 
 There is no CPU fallback: without the HIP library / a GPU these functions raise.
 """
@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _hip
-from .preprocess import prepare_frames
+from .preprocess import prepare_frames_device
 
 
 def _device(device=None):
@@ -146,8 +146,8 @@ def inference(net, images, device="cuda", prob_thresh=0.05, nms_iou_thresh=0.3, 
         images = [images]
     if str(device).startswith("cuda") and not str(net.device).startswith("cuda"):
         net.cuda(device)
-    frames, shapes = prepare_frames(list(images), net.net_info["height"], net.net_info["width"], resize)
     dev = net._torch_device()
+    frames, shapes = prepare_frames_device(list(images), net.net_info["height"], net.net_info["width"], dev, resize)
     out = net.forward_frames(frames, fresh=False)
     batch, rows = out["class_prob"].shape
     det = get_detector(batch, rows, dev)

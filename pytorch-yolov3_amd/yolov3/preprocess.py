@@ -42,6 +42,57 @@ def resize_bilinear_u8(img, out_h, out_w):
     return np.clip(out, 0, 255).astype(np.uint8)
 
 
+def axis_table(src_len, dst_len):
+    """(dst_len, 4) int32 rows {lo, hi, weight_lo, weight_hi}: the tap table both the host resize above and
+    the device kernel ``y3_resize_bilinear_u8`` use (so they agree bit for bit)."""
+    lo, hi, w0, w1 = _axis_taps(src_len, dst_len)
+    return np.ascontiguousarray(np.stack([lo, hi, w0, w1], axis=1).astype(np.int32))
+
+
+_device_tables = {}
+
+
+def resize_on_device(frame, out_h, out_w, device, out=None):
+    """uint8 (H,W,3) numpy / torch frame -> uint8 (out_h,out_w,3) torch tensor on ``device`` (HIP kernel;
+    identical result to :func:`resize_bilinear_u8`).  ``out`` may be a preallocated slice of a batch tensor."""
+    import torch
+    from . import _hip
+    src = frame if isinstance(frame, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frame))
+    src = src.to(device).contiguous()
+    sh, sw = int(src.shape[0]), int(src.shape[1])
+    if out is None:
+        out = torch.empty((out_h, out_w, 3), dtype=torch.uint8, device=device)
+    if (sh, sw) == (out_h, out_w):
+        out.copy_(src)
+        return out
+    key = (sh, sw, out_h, out_w, str(device))
+    if key not in _device_tables:
+        _device_tables[key] = (torch.from_numpy(axis_table(sh, out_h)).to(device),
+                               torch.from_numpy(axis_table(sw, out_w)).to(device))
+    ytab, xtab = _device_tables[key]
+    with torch.cuda.device(device):
+        _hip.check(_hip.lib().y3_resize_bilinear_u8(src.data_ptr(), sh, sw, out.data_ptr(), out_h, out_w,
+                                                    ytab.data_ptr(), xtab.data_ptr(), _hip.stream_ptr()))
+    return out
+
+
+def prepare_frames_device(images, net_h, net_w, device, resize=True):
+    """Like :func:`prepare_frames` but uploads every original frame once and resizes on the GPU."""
+    import torch
+    if not isinstance(images, (list, tuple)):
+        images = [images]
+    shapes = [tuple(im.shape) for im in images]
+    if not resize:
+        # the reference then stacks the frames as they are (np.stack needs equal sizes) and runs the net at that size
+        net_h, net_w = shapes[0][0], shapes[0][1]
+        if any(s[:2] != (net_h, net_w) for s in shapes):
+            raise ValueError("resize=False needs frames of one size, got {}".format(sorted(set(s[:2] for s in shapes))))
+    batch = torch.empty((len(images), net_h, net_w, 3), dtype=torch.uint8, device=device)
+    for i, im in enumerate(images):
+        resize_on_device(im, net_h, net_w, device, out=batch[i])
+    return batch, shapes
+
+
 def prepare_frames(images, net_h, net_w, resize=True):
     """list of HxWx3 uint8 BGR -> (uint8 (B,net_h,net_w,3) BGR, list of original shapes)."""
     if not isinstance(images, (list, tuple)):

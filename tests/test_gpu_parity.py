@@ -166,6 +166,17 @@ def test_inference_golden_fp32(model):
             print(model, tag, f, "kept", len(res[f][1]), "keep-set diff", ndiff, "fragile box diffs", nbad)
 
 
+def test_device_resize_is_bit_identical_to_host_resize():
+    from yolov3.preprocess import resize_on_device
+    for name, (oh, ow) in (("000000229358.jpg", (608, 608)), ("000000393569.jpg", (416, 416)), ("000000035279.jpg", (320, 480))):
+        img = load_jpeg_bgr(name)
+        want = resize_bilinear_u8(img, oh, ow)
+        got = resize_on_device(img, oh, ow, torch.device("cuda")).cpu().numpy()
+        assert got.shape == want.shape and (got == want).all(), name
+    same = synth_frames(4, 1, 64, 48)[0]
+    assert (resize_on_device(same, 64, 48, torch.device("cuda")).cpu().numpy() == same).all()
+
+
 def test_inference_single_frame_and_empty_result():
     net = _net("yolov3-tiny")
     frame = synth_frames(3, 1, 416, 416)[0]
