@@ -112,10 +112,10 @@ __global__ __launch_bounds__(BM * 2) void conv_halo3x3_kernel(HaloArgs p) {
   const int kc = slot ^ (row0 & 7);                   // RPP % 8 == 0, so (row & 7) == (row0 & 7)
   const long long q0 = (long long)m0 - p.W - 1;       // flattened input pixel of halo row 0
 
-  auto issue_halo_pass = [&](int chunk, int pass) {
+  auto issue_halo_pass = [&](int chunk, int pass, bool live = true) {
     const int row = row0 + pass * RPP;
     const long long q = q0 + row;
-    const bool ok = q >= 0 && q < p.M;
+    const bool ok = live && q >= 0 && q < p.M;
     const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
     char *dst = sA + (chunk & 1) * p.a_bytes + pass * (NT * 16) + wave * 1024;
     __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
@@ -126,10 +126,10 @@ __global__ __launch_bounds__(BM * 2) void conv_halo3x3_kernel(HaloArgs p) {
     const int r = row0 + i * RPP;
     b_src[i] = r < BN ? p.wgt + ((long long)(n0 + r) * p.k_ld) * ES + kc * 16 : nullptr;
   }
-  auto issue_weights = [&](int it) {  // it = chunk*9 + tap; K offset = (tap*Cin + chunk*BKE) elements
+  auto issue_weights = [&](int it, int slot_it = -1) {  // it = chunk*9 + tap; K offset = (tap*Cin + chunk*BKE) elements
     const int chunk = it / 9, tap = it - chunk * 9;
     const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
-    char *dst = sB + (it % NSB) * B_BYTES + wave * 1024;
+    char *dst = sB + ((slot_it < 0 ? it : slot_it) % NSB) * B_BYTES + wave * 1024;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const char *src = b_src[i] ? b_src[i] + koff : p.zero;
@@ -204,10 +204,10 @@ __global__ __launch_bounds__(BM * 2) void conv_halo3x3_kernel(HaloArgs p) {
   };
 
   // ---- first operands: halo(0), weights(0), weights(1) must have landed ----------------------------
-  Y3_STAMP(0);
+  Y3_COARSE(0);
   if (D == 2 && nit > 2) wait_vmcnt<NB>(); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
-  Y3_STAMP(1);
+  Y3_COARSE(1);
   u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
   read_frags(xf0, wf0, sA, sB, 0, 0);
   __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -233,19 +233,52 @@ __global__ __launch_bounds__(BM * 2) void conv_halo3x3_kernel(HaloArgs p) {
       }
       __builtin_amdgcn_s_barrier();
     }
-    // halo slice first, weights second: only later steps' loads are younger than these weights
-    issued_prev = 0;
-    if (chunk + 1 < p.nchunks && tap < p.na) { issue_halo_pass(chunk + 1, tap); issued_prev += 1; }
-    if (it + 1 + D < nit) { issue_weights(it + 1 + D); issued_prev += NB; }
-
+    Y3_FINE(0);   // vmcnt wait + barrier
+    // This step's LDS-DMA (halo slice first, weights second: only later steps' loads are younger than these
+    // weights) is issued INSIDE half-step A's scheduling region, so the up-to-NB+1 DMA instructions -- ~150 cycles
+    // each when all eight waves issue at once -- ride in MFMA gaps instead of forming a DMA-only phase.
     const char *aBuf = sA + (chunk & 1) * p.a_bytes;
     const int ky = (tap * 11) >> 5, kx = tap - ky * 3;         // tap / 3, tap % 3 for tap in 0..8
     __builtin_amdgcn_sched_barrier(0);
-    read_frags(xf1, wf1, aBuf, sB + (it % NSB) * B_BYTES, ky * p.W + kx, 1);   // second half of this step ...
-    mma_all(xf0, wf0, tap);                                    // ... flies under the first half's MFMAs
-    interleave();
+    // Branch-free on purpose (one basic block = one scheduling region): when there is nothing left to fetch the
+    // same number of DMA instructions is still issued -- a repeated halo slice / the last weight tile again --
+    // into LDS that nobody reads any more (the next-chunk halo buffer, the ring slot that is free by invariant).
+    // The DMA calls sit BETWEEN the fragment reads in program order: LDS-DMA and ds_read both touch LDS, so the
+    // scheduler keeps their relative order, and this is what lets the group barriers below spread them.
+    {
+      const int r0 = a_lane_row + ky * p.W + kx;
+      const char *ap = aBuf + r0 * 128 + (((4 + fq) ^ (r0 & 7)) << 4);
+      const char *bp = sB + (it % NSB) * B_BYTES + b_off1;
+      const bool live = chunk + 1 < p.nchunks;
+      const int itw = it + 1 + D < nit ? it + 1 + D : nit - 1;
+      xf1[0] = *reinterpret_cast<const u32x4 *>(ap);
+      xf1[1] = *reinterpret_cast<const u32x4 *>(ap + 2048);
+      issue_halo_pass(chunk + 1, tap < p.na ? tap : p.na - 1, live);
+      xf1[2] = *reinterpret_cast<const u32x4 *>(ap + 4096);
+      xf1[3] = *reinterpret_cast<const u32x4 *>(ap + 6144);
+      wf1[0] = *reinterpret_cast<const u32x4 *>(bp);
+      wf1[1] = *reinterpret_cast<const u32x4 *>(bp + 2048);
+      issue_weights(itw, it + 1 + D);
+      wf1[2] = *reinterpret_cast<const u32x4 *>(bp + 4096);
+      wf1[3] = *reinterpret_cast<const u32x4 *>(bp + 6144);
+      issued_prev = NB + 1;
+    }
+    mma_all(xf0, wf0, tap);                                    // the first half's MFMAs cover all of the above
+    // 2 DS reads, 4 MFMAs, 1 DMA | 2 DS, 4 MFMA | 2 DS, 4 MFMA, NB DMA | 2 DS, 4 MFMA   (bf16 counts)
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
+    __builtin_amdgcn_sched_group_barrier(0x010, NB, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
     __builtin_amdgcn_sched_barrier(0);
+    Y3_FINE(2);   // half-step A issued (8 reads + masks + 16 MFMAs)
     __builtin_amdgcn_s_waitcnt(0xC07F);   // second-half fragments (16 MFMAs old); keeps <= 8 LDS reads in flight
+    Y3_FINE(3);   // lgkmcnt(0)
     const int tap_n = tap == 8 ? 0 : tap + 1;
     const int chunk_n = tap == 8 ? chunk + 1 : chunk;
     {                                                          // first half of the next step (harmless
@@ -255,14 +288,16 @@ __global__ __launch_bounds__(BM * 2) void conv_halo3x3_kernel(HaloArgs p) {
     mma_all(xf1, wf1, tap);
     interleave();
     __builtin_amdgcn_sched_barrier(0);
+    Y3_FINE(4);   // half-step B issued
     // the prefetched fragments have had 16 MFMAs of time; retiring them here (lgkmcnt(0) only, in a form
     // hipcc's wait-count pass understands) lets it issue the next step's first MFMAs without a wait
     __builtin_amdgcn_s_waitcnt(0xC07F);
+    Y3_FINE(5);   // lgkmcnt(0)
     tap = tap_n;
     chunk = chunk_n;
   }
   __syncthreads();  // all operand reads done: LDS can hold the output tile
-  Y3_STAMP(2);  // main loop
+  Y3_COARSE(2);  // main loop
 
   // ---- epilogue: raw fp32 accumulators -> LDS (pixel rows, XOR-swizzled 16-byte chunks) -> every thread
   // finishes 8 consecutive channels of one pixel: scale/bias/LeakyReLU, + residual, one 16-byte store
@@ -338,7 +373,7 @@ __global__ __launch_bounds__(BM * 2) void conv_halo3x3_kernel(HaloArgs p) {
       *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
     }
   }
-  Y3_STAMP(3);  // epilogue
+  Y3_COARSE(3);  // epilogue
   Y3_STAMP_COUNT();
 }
 
