@@ -633,6 +633,249 @@ __global__ __launch_bounds__(512) void conv_halo3x3_pp_kernel(HaloArgs p) {
   Y3_STAMP_COUNT();
 }
 
+// ------------------------------------------------------------------------------------------------
+// 32-channel-chunk variant ("halo32"): 64-byte LDS rows.  The halo of a chunk is then 4x smaller, which buys
+// what the 128-byte version cannot afford at W = 76: a 5-slot weight ring (loads issued 3 K-steps ahead, so
+// the counted vmcnt wait at the top of a step is normally free) next to the double-buffered halo, in 112 KiB.
+// One K-step = one filter tap x 32 channels = ONE MFMA k-step: 16 MFMAs per wave, whose gaps carry the 8
+// fragment reads of the NEXT step (double-buffered registers, loop unrolled by two) and the step's two LDS-DMA
+// instructions (branch-free issue; a dummy goes to a dump region when there is nothing to fetch).
+template <typename T>
+__global__ __launch_bounds__(512) void conv_halo32_kernel(HaloArgs p) {
+  constexpr int BM = 256, BN = 128, NT = 512, NSB = 5, D = NSB - 2;
+  constexpr int ES = sizeof(T);
+  constexpr int RB = 64;                              // bytes per LDS row
+  constexpr int BKE = RB / ES;                        // channels per chunk (32 bf16 / 16 fp32)
+  constexpr int RPP = NT / 4;                         // rows per loader pass (4 chunks of 16 B per row)
+  constexpr int B_BYTES = BN * RB;                    // 8 KiB per weight slot: exactly one DMA per thread
+  constexpr int MI = 4, NI = 4;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *sB = smem;                                    // [NSB][128][64]
+  char *sDump = smem + NSB * B_BYTES;                 // [8 waves][1 KiB] target of dummy DMAs
+  char *sA = sDump + 8 * 1024;                        // [2][hr_pad][64]
+
+  Y3_STAMP_DECL
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / p.n_tiles) * BM;
+  const int n0 = (tile % p.n_tiles) * BN;
+
+  const int slot = tid & 3;
+  const int row0 = tid >> 2;                          // 0..127
+  const int kc = slot ^ ((row0 >> 1) & 3);            // RPP % 8 == 0: later passes keep (row >> 1) & 3
+  const long long q0 = (long long)m0 - p.W - 1;
+
+  auto issue_halo_pass = [&](int chunk, int pass, bool live) {
+    const long long q = q0 + row0 + pass * RPP;
+    const bool ok = live && q >= 0 && q < p.M;
+    const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
+    char *dst = live ? sA + (chunk & 1) * p.a_bytes + pass * (NT * 16) + wave * 1024 : sDump + wave * 1024;
+    __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
+  };
+  const char *b_src = p.wgt + ((long long)(n0 + row0) * p.k_ld) * ES + kc * 16;
+  auto issue_weights = [&](int it, int slot_it) {     // it = chunk*9 + tap
+    const int chunk = it / 9, tap = it - chunk * 9;
+    const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
+    __builtin_amdgcn_global_load_lds((gbl_void *)(b_src + koff), (lds_void *)(sB + (slot_it % NSB) * B_BYTES + wave * 1024), 16, 0, 0);
+  };
+
+  const int nit = p.nchunks * 9;                      // even (the launcher requires an even chunk count)
+  for (int pass = 0; pass < p.na; ++pass) issue_halo_pass(0, pass, true);
+#pragma unroll
+  for (int j = 0; j <= D; ++j) issue_weights(j, j);
+
+  uint32_t tapmask[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const uint32_t m = (uint32_t)(m0 + wm * 64 + mi * 16 + fr);
+    uint32_t mask = 0u;
+    if (m < (uint32_t)p.M) {
+      const uint32_t img = (__umulhi(m, p.mul_hw) + m) >> p.sh_hw;
+      const uint32_t rem = m - img * (uint32_t)p.HW;
+      const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
+      const uint32_t ox = rem - oy * (uint32_t)p.W;
+      const uint32_t vx = (ox >= 1u ? 1u : 0u) | 2u | (ox + 1u < (uint32_t)p.W ? 4u : 0u);
+      mask = (oy >= 1u ? vx : 0u) | (vx << 3) | (oy + 1u < (uint32_t)p.H ? vx << 6 : 0u);
+    }
+    tapmask[mi] = mask;
+  }
+  bool need_mask[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) need_mask[mi] = __any(tapmask[mi] != 0x1FFu);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int a_lane_row = wm * 64 + fr;
+  const int b_lane_row = wn * 64 + fr;
+  const int b_off = b_lane_row * RB + ((fq ^ ((b_lane_row >> 1) & 3)) << 4);
+
+  // fragment pointers of step `it` (tap, chunk): A rows shift with the tap, B comes from the ring slot
+  auto a_ptr = [&](int chunk, int tap) -> const char * {
+    const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+    const int r0 = a_lane_row + ky * p.W + kx;
+    return sA + (chunk & 1) * p.a_bytes + r0 * RB + ((fq ^ ((r0 >> 1) & 3)) << 4);
+  };
+
+  Y3_COARSE(0);
+  // halo(0) and weights(0..D-1) landed; only weights(D) may still fly.  (Waiting for just weights(1) would
+  // break the steady-state count at step 1, whose weights(2) would then have D younger loads, not 2(D-1).)
+  wait_vmcnt<1>();
+  __builtin_amdgcn_s_barrier();
+  Y3_COARSE(1);
+
+  u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
+  {
+    const char *ap = a_ptr(0, 0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) xf0[mi] = *reinterpret_cast<const u32x4 *>(ap + mi * 16 * RB);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) wf0[ni] = *reinterpret_cast<const u32x4 *>(sB + b_off + ni * 16 * RB);
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+
+  // one K-step: MFMAs on (xc, wc) while (xn, wn_) receive the next step's fragments and the step's DMA goes out
+  auto step = [&](int it, int tap, int chunk, u32x4 (&xc)[MI], u32x4 (&wc)[NI], u32x4 (&xn)[MI], u32x4 (&wn_)[NI]) {
+    wait_vmcnt<2 * (D - 1)>();                        // weights(it+1) (+ a due halo) landed; D-1 steps' loads may fly
+    __builtin_amdgcn_s_barrier();
+    const int tap_n = tap == 8 ? 0 : tap + 1;
+    const int chunk_n = tap == 8 ? chunk + 1 : chunk;
+    const char *ap = a_ptr(chunk_n, tap_n);
+    const char *bp = sB + ((it + 1) % NSB) * B_BYTES + b_off;
+    const bool live = chunk + 1 < p.nchunks && tap < p.na;
+    const int itw = it + 1 + D < nit ? it + 1 + D : nit - 1;
+    __builtin_amdgcn_sched_barrier(0);
+    xn[0] = *reinterpret_cast<const u32x4 *>(ap);
+    xn[1] = *reinterpret_cast<const u32x4 *>(ap + 16 * RB);
+    issue_halo_pass(chunk + 1, tap < p.na ? tap : 0, live);
+    xn[2] = *reinterpret_cast<const u32x4 *>(ap + 32 * RB);
+    xn[3] = *reinterpret_cast<const u32x4 *>(ap + 48 * RB);
+    wn_[0] = *reinterpret_cast<const u32x4 *>(bp);
+    wn_[1] = *reinterpret_cast<const u32x4 *>(bp + 16 * RB);
+    issue_weights(itw, it + 1 + D);
+    wn_[2] = *reinterpret_cast<const u32x4 *>(bp + 32 * RB);
+    wn_[3] = *reinterpret_cast<const u32x4 *>(bp + 48 * RB);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+      if (need_mask[mi] && !((tapmask[mi] >> tap) & 1u)) xc[mi] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) MmaH<T>::run(acc[mi][ni], wc[ni], xc[mi]);
+    // 2 DS reads, 4 MFMAs, 1 DMA | 2 DS, 4 MFMA | 2 DS, 4 MFMA, 1 DMA | 2 DS, 4 MFMA   (bf16 counts)
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);               // next fragments landed (16 MFMAs of cover)
+  };
+
+  int tap = 0, chunk = 0;
+#pragma unroll 1
+  for (int it = 0; it < nit; it += 2) {
+    step(it, tap, chunk, xf0, wf0, xf1, wf1);
+    const int tap1 = tap == 8 ? 0 : tap + 1;
+    const int chunk1 = tap == 8 ? chunk + 1 : chunk;
+    step(it + 1, tap1, chunk1, xf1, wf1, xf0, wf0);
+    tap = tap1 == 8 ? 0 : tap1 + 1;
+    chunk = tap1 == 8 ? chunk1 + 1 : chunk1;
+  }
+  wait_vmcnt<0>();                                    // dummy DMAs of the last steps
+  __syncthreads();
+  Y3_COARSE(2);
+
+  // ---- epilogue (as in the ping-pong kernel) ---------------------------------------------------------------
+  constexpr int SWZ = 15;
+  constexpr int OCT_PER_ROW = BN / 8;
+  constexpr int WR = BM * OCT_PER_ROW / NT;
+  float *sC = reinterpret_cast<float *>(smem);
+  const bool leaky = p.flags & Y3_F_LEAKY;
+  const bool has_res = p.flags & Y3_F_RESIDUAL;
+  const int oc_mine = tid & 15;
+  const int co = n0 + oc_mine * 8;
+  const f32x4 sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
+  const f32x4 sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+  const f32x4 bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
+  const f32x4 bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+  u32x4 resv[WR];
+  if (has_res) {
+#pragma unroll
+    for (int j = 0; j < WR; ++j) {
+      const int m = m0 + (tid >> 4) + j * (NT / 16);
+      const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
+      resv[j] = m < p.M ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int cl = wn * 64 + ni * 16 + fq * 4;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int pl = wm * 64 + mi * 16 + fr;
+      *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < WR; ++j) {
+    const int pl = (tid >> 4) + j * (NT / 16);
+    const int m = m0 + pl;
+    if (m >= p.M) continue;
+    const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
+    const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = lo[r] * sc_lo[r] + bi_lo[r];
+      v[4 + r] = hi[r] * sc_hi[r] + bi_hi[r];
+    }
+    if (leaky) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : Y3_LEAKY_SLOPE * v[r];
+    }
+    if (has_res) {
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[j]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+      } else {
+        const float *rp = reinterpret_cast<const float *>(p.res) + (long long)m * p.res_ld + co;
+        const f32x4 r0v = __builtin_bit_cast(f32x4, resv[j]), r1v = *reinterpret_cast<const f32x4 *>(rp + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] += r0v[r]; v[4 + r] += r1v[r]; }
+      }
+    }
+    T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
+    if constexpr (sizeof(T) == 2) {
+      bf16x8 ov;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ov[r] = (bf16_t)v[r];
+      *reinterpret_cast<bf16x8 *>(op) = ov;
+    } else {
+      *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+  Y3_COARSE(3);
+  Y3_STAMP_COUNT();
+}
+
 // n / d == (umulhi(n, mul) + n) >> sh for 0 <= n < 2^31 (round-up method, d >= 1)
 void fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
   if (d <= 1) { mul = 0; sh = 0; return; }
@@ -699,6 +942,30 @@ int launch_halo_pp(const HaloArgs &a0, hipStream_t s) {
   return Y3_OK;
 }
 
+template <typename T>
+int launch_halo32(const HaloArgs &a0, hipStream_t s) {
+  HaloArgs a = a0;
+  constexpr int ES = sizeof(T);
+  const int hr = 256 + 2 * a.W + 2;
+  a.na = y3_ceil_div(hr, 128);
+  a.hr_pad = a.na * 128;
+  a.a_bytes = a.hr_pad * 64;
+  a.nchunks = a.Cin / (64 / ES);
+  size_t lds = (size_t)5 * 128 * 64 + 8 * 1024 + (size_t)2 * a.a_bytes;
+  if (lds < (size_t)256 * 128 * 4) lds = (size_t)256 * 128 * 4;
+  Y3_REQUIRE(a.na <= 4 && lds <= 160 * 1024 && a.nchunks % 2 == 0 && a.nchunks >= 2,
+             "halo32 kernel: shape does not fit (W %d, %d chunks)", a.W, a.nchunks);
+  static bool attr_set = false;
+  if (!attr_set) {
+    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo32_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_halo32_kernel<T>), dim3(y3_ceil_div(a.M, 256) * a.n_tiles), dim3(512), lds, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
 }  // namespace
 
 int g_y3_halo_pp = 1;
@@ -743,6 +1010,8 @@ int y3_launch_conv_halo(const y3_op &op, int bm, const void *d_in, const void *d
   Y3_REQUIRE(bm == 256 || bm == 192, "conv block %d: bad halo tile %d", op.block_idx, bm);
   if (bm == 256) *kernel_name = bf ? "conv_halo3x3_bf16_256x128" : "conv_halo3x3_f32_256x128";
   else *kernel_name = bf ? "conv_halo3x3_bf16_192x128" : "conv_halo3x3_f32_192x128";
+  const bool use32 = bm == 256 && g_y3_halo_pp == 2 && op.in_w <= 126 && (op.in_c / (64 / es)) % 2 == 0;
+  if (use32) *kernel_name = bf ? "conv_halo32_bf16_256x128" : "conv_halo32_f32_256x128";
   if (dry_run) return Y3_OK;
   HaloArgs a;
   a.in = static_cast<const char *>(d_in);
@@ -765,6 +1034,7 @@ int y3_launch_conv_halo(const y3_op &op, int bm, const void *d_in, const void *d
   Y3_REQUIRE((long long)op.batch * a.HW < (1ll << 31), "conv block %d: too many pixels for the 32-bit tile index", op.block_idx);
   const HaloGeom g = halo_geom(bm, op.in_w);
   Y3_REQUIRE(g.nsb != 0, "conv block %d: halo tile does not fit in LDS", op.block_idx);
+  if (use32) return bf ? launch_halo32<bf16_t>(a, s) : launch_halo32<float>(a, s);
   if (bm == 256 && g_y3_halo_pp) return bf ? launch_halo_pp<bf16_t>(a, s) : launch_halo_pp<float>(a, s);
   if (bf) {
     if (bm == 256) return g.nsb == 4 ? launch_halo<bf16_t, 256, 4>(a, g, s) : launch_halo<bf16_t, 256, 3>(a, g, s);

@@ -108,7 +108,7 @@ def test_tuning_knobs_do_not_change_results():
     ref = _net("mini").forward(x)
     try:
         for knobs in ({"igemm_version": 1}, {"igemm_staging": 1}, {"igemm_rb": 64}, {"conv_halo": 1, "halo_pp": 0},
-                      {"conv_halo": 1, "halo_pp": 1, "halo_bm": 256}):
+                      {"conv_halo": 1, "halo_pp": 1, "halo_bm": 256}, {"conv_halo": 1, "halo_pp": 2, "halo_bm": 256}):
             for k, v in knobs.items():
                 _hip.check(lib.y3_set_tuning(k.encode(), v))
             out = _net("mini").forward(x)
@@ -261,8 +261,9 @@ def test_halo_kernels_match_igemm_on_yolov3_fp32():
     g = np.load(os.path.join(GOLDEN, "forward_yolov3.npz"))
     frames = np.stack([resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), 608, 608), synth_frames(5, 1, 608, 608)[0]])
     try:
-        for pp in (0, 1):
+        for pp in (0, 1, 2):
             _hip.check(lib.y3_set_tuning(b"conv_halo", 1))
+            _hip.check(lib.y3_set_tuning(b"halo_bm", 256 if pp == 2 else 0))
             _hip.check(lib.y3_set_tuning(b"halo_pp", pp))
             out = _net("yolov3").forward(torch.from_numpy(orc.frames_to_input(list(frames))))
             np.testing.assert_allclose(out["bbox_xywh"].cpu().numpy(), g["bbox_xywh"], rtol=1e-4, atol=BOX_ATOL)
@@ -270,6 +271,7 @@ def test_halo_kernels_match_igemm_on_yolov3_fp32():
     finally:
         lib.y3_set_tuning(b"conv_halo", 0)
         lib.y3_set_tuning(b"halo_pp", 1)
+        lib.y3_set_tuning(b"halo_bm", 0)
 
 
 def test_bf16_agreement_report_yolov3():

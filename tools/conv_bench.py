@@ -41,7 +41,7 @@ LAYERS = [
 VARIANTS = [
     ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128}),
     ("halo_il256", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 0, "halo_bm": 256, "igemm_staging": 0, "igemm_rb": 128}),
-    ("halo_il192", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 0, "halo_bm": 192, "igemm_staging": 0, "igemm_rb": 128}),
+    ("halo32", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 2, "halo_bm": 256, "igemm_staging": 0, "igemm_rb": 128}),
     ("halo_pp256", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 1, "halo_bm": 256, "igemm_staging": 0, "igemm_rb": 128}),
 ]
 
