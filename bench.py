@@ -47,9 +47,10 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--profile-passes", type=int, default=3)
     ap.add_argument("--dump-ops", default=None, help="write the per-op timing table (text) to this file")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: step i runs on HIP stream i %% streams with its own arena, so "
                          "one batch's kernel tails overlap the next batch's ramp-up (1 = strictly serial steps)")
+    ap.add_argument("--tuning", default="", help="A/B runs: comma-separated y3_set_tuning knobs, e.g. auto_mask=15")
     return ap.parse_args()
 
 
@@ -88,6 +89,9 @@ def main():
     from yolov3.dist import DetectionGather
 
     dev = torch.device("cuda", local_rank)
+    for kv in filter(None, args.tuning.split(",")):
+        key, val = kv.split("=")
+        _hip.check(_hip.lib().y3_set_tuning(key.encode(), int(val)))
     cfg = os.path.join(ROOT, "pytorch-yolov3_amd", "models", args.model + ".cfg")
     net = yolov3.Darknet(cfg, device="cuda:%d" % local_rank, dtype=args.dtype).eval()
     params = W.synth_params(net.blocks, net.net_info, seed=0, obj_bias=args.obj_bias,

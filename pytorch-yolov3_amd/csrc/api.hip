@@ -14,6 +14,11 @@ namespace {
 thread_local char g_err[512] = "";
 }
 
+// per-layer kernel choice for the MFMA convs (tools/conv_bench.py tables in profiles/): bit 0: wave-specialised halo
+// kernel for 3x3 s1 layers with rows wider than 64; bit 1: wave-specialised igemm (3 stages) for 3x3 layers with rows of
+// 33..64; bit 2: halo kernel for rows <= 32; bit 3: wave-specialised igemm for 1x1 layers with Cin >= 1024;
+// bit 4: halo kernel for rows of 33..64 instead; bit 5: wave-specialised igemm for rows <= 32 instead
+int g_y3_auto_mask = 21;  // measured best end to end (profiles/r01_ab_kernel_selection.txt): halo kernel at every row width
 int g_y3_use_halo = 0;   // experimental halo-reuse 3x3 kernels (conv_halo.hip); off: the implicit GEMM measured as fast
 
 
@@ -62,6 +67,18 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
         case 0: {
           const int bm = g_y3_use_halo ? y3_conv_halo_bm(op) : 0;
           if (bm) return y3_launch_conv_halo(op, bm, in, d_zero, s, name, dry_run);
+          if (g_y3_auto_mask && !g_y3_use_halo) {
+            const int am = g_y3_auto_mask, w = op.in_w;
+            const bool k3 = op.ksize == 3 && op.stride == 1 && op.in_c >= 128 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32);
+            const bool halo_ok = k3 && y3_conv_halo_ws_fits(op);
+            bool want_halo = false, want_ws = false;
+            if (k3 && w > 64) want_halo = am & 1;
+            else if (k3 && w > 32) { want_halo = am & 16; want_ws = am & 2; }
+            else if (k3) { want_halo = am & 4; want_ws = am & 32; }
+            else if (op.ksize == 1 && op.in_c >= 1024 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32)) want_ws = am & 8;
+            if (want_halo && halo_ok) return y3_launch_conv_halo(op, 256, in, d_zero, s, name, dry_run, 3);
+            if (want_ws) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
+          }
           return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run);
         }
         case 1: return y3_launch_conv_small(op, in, s, name, dry_run);

@@ -118,8 +118,9 @@ __device__ __forceinline__ unsigned long long y3_now() {
 #endif
 
 // launchers implemented in the .hip files; each fills *kernel_name with a static string
+// force_version / force_ns: 0 = the "igemm_version" / "igemm_ns" knobs
 int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
-                         const char **kernel_name, bool dry_run);
+                         const char **kernel_name, bool dry_run, int force_version = 0, int force_ns = 0);
 int y3_launch_conv_small(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
                          bool dry_run);
 int y3_launch_conv_direct(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
@@ -139,11 +140,14 @@ int y3_launch_yolo(const y3_op &op, const void *d_in, hipStream_t s, const char 
                    bool dry_run);
 // halo-reuse 3x3 kernel: pixel-tile height it would use for this conv (256 / 192), 0 = not applicable
 int y3_conv_halo_bm(const y3_op &op);
+// variant: -1 = the "halo_pp" knob, else 0 lockstep / 1 ping-pong / 2 32-channel chunks / 3 wave-specialised
 int y3_launch_conv_halo(const y3_op &op, int bm, const void *d_in, const void *d_zero, hipStream_t s,
-                        const char **kernel_name, bool dry_run);
+                        const char **kernel_name, bool dry_run, int variant = -1);
+bool y3_conv_halo_ws_fits(const y3_op &op);
 // process-wide tuning knobs (y3_set_tuning)
 extern int g_y3_use_halo;
 extern int g_y3_halo_pp;
 extern int g_y3_halo_bm;   // 0 = heuristic, 256 / 192 = forced
+extern int g_y3_auto_mask; // per-layer kernel selection bits (api.hip)
 // true when the MFMA implicit-GEMM kernel can take this conv
 bool y3_conv_igemm_supported(const y3_op &op);

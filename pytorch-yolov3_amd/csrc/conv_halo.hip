@@ -76,6 +76,11 @@ __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_n() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <typename T, int BM, int NSB>
 __global__ __launch_bounds__(BM * 2) void conv_halo3x3_kernel(HaloArgs p) {
   constexpr int BN = 128;
@@ -884,6 +889,308 @@ void fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
   mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised variant (BM = 256, BN = 128): 8 consumer waves (wave tile 64 x 64, two per SIMD) that only
+// read fragments and issue MFMAs + 4 loader waves (one per SIMD) that only issue LDS-DMA.  Measured on the
+// kernels above and on conv_igemm3: a wave that issues a 1 KiB LDS-DMA piece is stuck for 60-185 cycles and
+// feeds no MFMA meanwhile, and the per-CU LDS-DMA path takes ~22 cycles per KiB however many waves issue.  The
+// halo image keeps the bytes per FLOP low (weights: 16 KiB per K-step, halo: ~52 KiB per nine K-steps, against
+// 1024 MFMA cycles per SIMD and K-step); the role split keeps the DMA issue out of the MFMA waves' streams.
+// One raw workgroup barrier per K-step:  loaders: wait(loads older than D-1 steps) ; barrier ; issue
+// weights(it+D+1) + two halo slices of the next chunk.   consumers: barrier ; MFMAs(it) with the fragments of the
+// second K-half and of step it+1's first K-half read in the MFMA gaps.  Ring: NSB = D + 2 weight slots.
+template <typename T, int NSB>
+__global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
+  constexpr int BM = 256, BN = 128;
+  constexpr int WAVES_N = 2;
+  constexpr int NC = 512, NL = 256;                   // consumer / loader threads
+  constexpr int ES = sizeof(T);
+  constexpr int BKE = 128 / ES;
+  constexpr int RPL = NL / 8;                         // rows filled per loader pass (32)
+  constexpr int NBL = BN / RPL;                       // weight-tile passes per loader thread (4)
+  constexpr int HPS = 2;                              // halo passes per K-step
+  constexpr int PER = NBL + HPS;                      // LDS-DMA instructions per loader thread and K-step
+  constexpr int B_BYTES = BN * 128;
+  constexpr int D = NSB - 2;
+  constexpr int MI = 4, NI = 4;
+  static_assert(NSB == 3 || NSB == 4, "weight ring has 3 or 4 slots");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *sB = smem;                                    // [NSB][BN][128]
+  char *sA = smem + NSB * B_BYTES;                    // [2][hr_pad][128]
+
+  Y3_STAMP_DECL
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= NC / 64;
+
+  const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / p.n_tiles) * BM;
+  const int n0 = (tile % p.n_tiles) * BN;
+  const int nit = p.nchunks * 9;
+
+  const int wm = (wave & 7) / WAVES_N, wn = (wave & 7) % WAVES_N;
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (loader) {
+    // ---------------- loader waves ----------------
+    // youngest waves of the workgroup: without a raised priority their few VALU / VMEM instructions lose every
+    // issue arbitration against the two MFMA waves of the SIMD (stamps: ~190 cycles per LDS-DMA instruction)
+    __builtin_amdgcn_s_setprio(3);
+    const int ltid = tid - NC;
+    const int lwave = wave - NC / 64;
+    const int slot = ltid & 7;
+    const int row0 = ltid >> 3;
+    const int kc = slot ^ (row0 & 7);
+    const long long q0 = (long long)m0 - p.W - 1;     // flattened input pixel of halo row 0
+    auto issue_halo_pass = [&](int chunk, int pass, bool live) {
+      const long long q = q0 + row0 + pass * RPL;
+      const bool ok = live && q >= 0 && q < p.M;
+      const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
+      char *dst = sA + (chunk & 1) * p.a_bytes + pass * (NL * 16) + lwave * 1024;
+      __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
+    };
+    const char *b_src[NBL];
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) b_src[i] = p.wgt + ((long long)(n0 + row0 + i * RPL) * p.k_ld) * ES + kc * 16;
+    auto issue_weights = [&](int it, int ring_slot) {  // it = chunk*9 + tap; K offset = tap*Cin + chunk*BKE elements
+      const int chunk = it / 9, tap = it - chunk * 9;
+      const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
+      char *dst = sB + ring_slot * B_BYTES + lwave * 1024;
+#pragma unroll
+      for (int i = 0; i < NBL; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_void *)(b_src[i] + koff), (lds_void *)(dst + i * (NL * 16)), 16, 0, 0);
+    };
+    for (int pass = 0; pass < p.na; ++pass) issue_halo_pass(0, pass, true);
+#pragma unroll
+    for (int j = 0; j <= D; ++j) issue_weights(j < nit ? j : nit - 1, j);
+    Y3_COARSE(6);
+    int tap = 0, chunk = 0, ring = (D + 1) % NSB;
+#pragma unroll 1
+    for (int it = 0; it < nit; ++it) {
+      // before barrier B(it): weights(it+1) (and everything older) landed; with the 4-slot ring the loads of the
+      // previous step (or, at it == 0, the prologue's last weight tile) may still fly
+      if (D == 2) { if (it == 0) wait_vmcnt<NBL>(); else wait_vmcnt_n<PER>(); }
+      else wait_vmcnt<0>();
+      Y3_COARSE(3);
+      __builtin_amdgcn_s_barrier();
+      Y3_COARSE(4);
+      const bool live = chunk + 1 < p.nchunks;
+      const int p0 = 2 * tap < p.na ? 2 * tap : p.na - 1;
+      const int p1 = 2 * tap + 1 < p.na ? 2 * tap + 1 : p.na - 1;
+      issue_halo_pass(chunk + 1, p0, live);
+      issue_halo_pass(chunk + 1, p1, live);
+      const int itw = it + 1 + D < nit ? it + 1 + D : nit - 1;
+      issue_weights(itw, ring);                       // ring == (it + 1 + D) % NSB: the slot of weights(it-1), free
+      ring = ring + 1 == NSB ? 0 : ring + 1;
+      if (++tap == 9) { tap = 0; ++chunk; }
+      Y3_COARSE(5);
+    }
+    wait_vmcnt<0>();                                  // the tail's dummy loads must not land on the output tile
+#if defined(Y3_STAMPS) && !defined(Y3_STAMPS_FINE)
+    if (tid == NC) for (int _i = 3; _i < 7; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]);
+#endif
+  } else {
+    // ---------------- consumer waves ----------------
+    uint32_t tapmask[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const uint32_t m = (uint32_t)(m0 + wm * 64 + mi * 16 + fr);
+      uint32_t mask = 0u;
+      if (m < (uint32_t)p.M) {
+        const uint32_t img = (__umulhi(m, p.mul_hw) + m) >> p.sh_hw;
+        const uint32_t rem = m - img * (uint32_t)p.HW;
+        const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
+        const uint32_t ox = rem - oy * (uint32_t)p.W;
+        const uint32_t vx = (ox >= 1u ? 1u : 0u) | 2u | (ox + 1u < (uint32_t)p.W ? 4u : 0u);
+        mask = (oy >= 1u ? vx : 0u) | (vx << 3) | (oy + 1u < (uint32_t)p.H ? vx << 6 : 0u);
+      }
+      tapmask[mi] = mask;
+    }
+    const int a_lane_row = wm * 64 + fr;
+    const int b_lane_row = wn * 64 + fr;
+    const int b_off0 = b_lane_row * 128 + (((0 + fq) ^ (b_lane_row & 7)) << 4);
+    const int b_off1 = b_lane_row * 128 + (((4 + fq) ^ (b_lane_row & 7)) << 4);
+    auto read_frags = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], const char *aBuf, const char *bBuf, int a_shift, int g) {
+      const int r0 = a_lane_row + a_shift;
+      const char *ap = aBuf + r0 * 128 + (((g * 4 + fq) ^ (r0 & 7)) << 4);
+      const char *bp = bBuf + (g ? b_off1 : b_off0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const u32x4 *>(ap + mi * 2048);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
+    };
+    auto mma_all = [&](u32x4 (&xf)[MI], const u32x4 (&wf)[NI], int tap) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        if (!((tapmask[mi] >> tap) & 1u)) xf[mi] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) MmaH<T>::run(acc[mi][ni], wf[ni], xf[mi]);
+    };
+    auto interleave = [&]() {
+#pragma unroll
+      for (int i = 0; i < MI + NI; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 2 : 8, 0);
+      }
+    };
+    Y3_STAMP(2);
+    __builtin_amdgcn_s_barrier();                     // B(0): halo(0), weights(0), weights(1) are in LDS
+    Y3_STAMP(0);
+    u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
+    read_frags(xf0, wf0, sA, sB, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    int tap = 0, chunk = 0, ring = 0;
+#pragma unroll 1
+    for (int it = 0; it < nit; ++it) {
+      if (it) {
+        __builtin_amdgcn_s_barrier();                 // B(it): weights(it+1) landed; slot of weights(it-1) released
+        Y3_STAMP(0);
+      }
+#if defined(Y3_STAMPS_FINE)
+      const bool w0 = wave == 0;
+#define Y3_W0(slot) do { if (w0) Y3_STAMP(slot); } while (0)
+#else
+#define Y3_W0(slot) do {} while (0)
+#endif
+      const char *aBuf = sA + (chunk & 1) * p.a_bytes;
+      const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(xf1, wf1, aBuf, sB + ring * B_BYTES, ky * p.W + kx, 1);
+      mma_all(xf0, wf0, tap);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      Y3_W0(2);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      Y3_W0(3);
+      const int tap_n = tap == 8 ? 0 : tap + 1;
+      const int chunk_n = tap == 8 ? chunk + 1 : chunk;
+      const int ring_n = ring + 1 == NSB ? 0 : ring + 1;
+      {
+        const int ky_n = (tap_n * 11) >> 5, kx_n = tap_n - ky_n * 3;
+        read_frags(xf0, wf0, sA + (chunk_n & 1) * p.a_bytes, sB + ring_n * B_BYTES, ky_n * p.W + kx_n, 0);
+      }
+      mma_all(xf1, wf1, tap);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      Y3_W0(4);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+#if defined(Y3_STAMPS_FINE)
+      if (w0) Y3_STAMP(5); else Y3_STAMP(1);
+#else
+      Y3_STAMP(1);
+#endif
+      tap = tap_n;
+      chunk = chunk_n;
+      ring = ring_n;
+    }
+#if defined(Y3_STAMPS_FINE)
+    if (tid == 0) {
+      for (int _i = 0; _i < 6; ++_i) if (_i != 1) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]);
+      atomicAdd(&g_y3_stamps[7], 1ull);
+    }
+    if (tid == 256) {   // wave 4: slot 1 = its compute time, slot 6 = its barrier wait
+      atomicAdd(&g_y3_stamps[1], _st_acc[1]);
+      atomicAdd(&g_y3_stamps[6], _st_acc[0]);
+    }
+#elif defined(Y3_STAMPS)
+    if (tid == 0) {
+      for (int _i = 0; _i < 3; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]);
+      atomicAdd(&g_y3_stamps[7], 1ull);
+    }
+#endif
+  }
+  __syncthreads();  // all operand reads and all LDS-DMA done: LDS can hold the output tile
+
+  // ---- epilogue (the 512 consumer threads write out; the loaders only keep the barrier count) ----
+  constexpr int SWZ = 15;
+  constexpr int OCT_PER_ROW = BN / 8;
+  constexpr int WR = BM * OCT_PER_ROW / NC;
+  float *sC = reinterpret_cast<float *>(smem);
+  const bool leaky = p.flags & Y3_F_LEAKY;
+  const bool has_res = p.flags & Y3_F_RESIDUAL;
+  const int oc_mine = tid & 15;
+  const int co = n0 + oc_mine * 8;
+  f32x4 sc_lo, sc_hi, bi_lo, bi_hi;
+  u32x4 resv[WR];
+  if (!loader) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int cl = wn * 64 + ni * 16 + fq * 4;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int pl = wm * 64 + mi * 16 + fr;
+        *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
+      }
+    }
+    sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
+    sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+    bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
+    bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+    if (has_res) {
+#pragma unroll
+      for (int j = 0; j < WR; ++j) {
+        const int m = m0 + (tid >> 4) + j * (NC / 16);
+        const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
+        if constexpr (sizeof(T) == 2) {
+          resv[j] = m < p.M ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (loader) return;
+#pragma unroll
+  for (int j = 0; j < WR; ++j) {
+    const int pl = (tid >> 4) + j * (NC / 16);
+    const int m = m0 + pl;
+    if (m >= p.M) continue;
+    const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
+    const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = lo[r] * sc_lo[r] + bi_lo[r];
+      v[4 + r] = hi[r] * sc_hi[r] + bi_hi[r];
+    }
+    if (leaky) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : Y3_LEAKY_SLOPE * v[r];
+    }
+    if (has_res) {
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[j]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+      } else {
+        const float *rp = reinterpret_cast<const float *>(p.res) + (long long)m * p.res_ld + co;
+        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(rp), r1 = *reinterpret_cast<const f32x4 *>(rp + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+      }
+    }
+    T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
+    if constexpr (sizeof(T) == 2) {
+      bf16x8 ov;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ov[r] = (bf16_t)v[r];
+      *reinterpret_cast<bf16x8 *>(op) = ov;
+    } else {
+      *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+}
+
 struct HaloGeom { int na, hr_pad, a_bytes, nsb; size_t lds; };
 
 // geometry / LDS budget of one tile configuration; nsb == 0: does not fit
@@ -966,21 +1273,66 @@ int launch_halo32(const HaloArgs &a0, hipStream_t s) {
   return Y3_OK;
 }
 
+
+template <typename T>
+int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
+  HaloArgs a = a0;
+  const int hr = 256 + 2 * a.W + 2;
+  a.na = y3_ceil_div(hr, 32);
+  a.hr_pad = a.na * 32;
+  a.a_bytes = a.hr_pad * 128;
+  // the next chunk's halo goes out two passes per K-step and must be older than the last loads allowed in flight
+  int nsb = 0;
+  size_t lds = 0;
+  for (int c = 4; c >= 3; --c) {
+    if (a.na > (c == 4 ? 14 : 16)) continue;
+    lds = (size_t)c * 128 * 128 + (size_t)2 * a.a_bytes;
+    if (lds < (size_t)256 * 128 * 4) lds = (size_t)256 * 128 * 4;
+    if (lds <= 160 * 1024) { nsb = c; break; }
+  }
+  Y3_REQUIRE(nsb != 0, "wave-specialised halo kernel: row width %d does not fit", a.W);
+  static bool attr_set = false;
+  if (!attr_set) {
+    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_ws_kernel<T, 3>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_ws_kernel<T, 4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const dim3 grid(y3_ceil_div(a.M, 256) * a.n_tiles);
+  if (nsb == 4) hipLaunchKernelGGL((conv_halo_ws_kernel<T, 4>), grid, dim3(768), lds, s, a);
+  else hipLaunchKernelGGL((conv_halo_ws_kernel<T, 3>), grid, dim3(768), lds, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
 }  // namespace
 
 int g_y3_halo_pp = 1;
 int g_y3_halo_bm = 0;   // tuning knob "halo_pp": use the ping-pong schedule for 256-pixel tiles
 
 // picks the pixel-tile height (256 or 192) that wastes the fewest CU rounds; 0 = not applicable
-int y3_conv_halo_bm(const y3_op &op) {
+bool y3_conv_halo_eligible(const y3_op &op) {
   const int es = y3_elem_size(op.dtype);
   const int bke = 128 / es;
-  if (op.ksize != 3 || op.stride != 1 || op.pad != 1) return 0;
-  if (op.flags & (Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR)) return 0;
-  if (op.in_c % bke != 0 || op.in_c / bke < 2) return 0;
-  if (op.out_c % 128 != 0 || op.out_ld % 8 != 0 || op.in_ld % (16 / es) != 0) return 0;
-  if ((op.flags & Y3_F_RESIDUAL) && op.res_ld % 8 != 0) return 0;
-  if (op.k_ld < 9 * op.in_c) return 0;
+  if (op.ksize != 3 || op.stride != 1 || op.pad != 1) return false;
+  if (op.flags & (Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR)) return false;
+  if (op.in_c % bke != 0 || op.in_c / bke < 2) return false;
+  if (op.out_c % 128 != 0 || op.out_ld % 8 != 0 || op.in_ld % (16 / es) != 0) return false;
+  if ((op.flags & Y3_F_RESIDUAL) && op.res_ld % 8 != 0) return false;
+  if (op.k_ld < 9 * op.in_c) return false;
+  return true;
+}
+
+// wave-specialised 256x128 halo kernel: additionally the halo image must fit (2 * (258 + 2W) rows + 3 weight slots)
+bool y3_conv_halo_ws_fits(const y3_op &op) {
+  if (!y3_conv_halo_eligible(op)) return false;
+  const int na = y3_ceil_div(256 + 2 * op.in_w + 2, 32);
+  return na <= 16 && (size_t)3 * 128 * 128 + (size_t)2 * na * 32 * 128 <= 160 * 1024;
+}
+
+int y3_conv_halo_bm(const y3_op &op) {
+  if (!y3_conv_halo_eligible(op)) return 0;
   const long long m = (long long)op.batch * op.out_h * op.out_w;
   const int n_tiles = op.out_c / 128;
   int best = 0;
@@ -1004,14 +1356,17 @@ int y3_conv_halo_bm(const y3_op &op) {
 }
 
 int y3_launch_conv_halo(const y3_op &op, int bm, const void *d_in, const void *d_zero, hipStream_t s,
-                        const char **kernel_name, bool dry_run) {
+                        const char **kernel_name, bool dry_run, int variant) {
+  const int pp = variant >= 0 ? variant : g_y3_halo_pp;
   const int es = y3_elem_size(op.dtype);
   const bool bf = op.dtype == Y3_BF16;
   Y3_REQUIRE(bm == 256 || bm == 192, "conv block %d: bad halo tile %d", op.block_idx, bm);
   if (bm == 256) *kernel_name = bf ? "conv_halo3x3_bf16_256x128" : "conv_halo3x3_f32_256x128";
   else *kernel_name = bf ? "conv_halo3x3_bf16_192x128" : "conv_halo3x3_f32_192x128";
-  const bool use32 = bm == 256 && g_y3_halo_pp == 2 && op.in_w <= 126 && (op.in_c / (64 / es)) % 2 == 0;
+  const bool use32 = bm == 256 && pp == 2 && op.in_w <= 126 && (op.in_c / (64 / es)) % 2 == 0;
   if (use32) *kernel_name = bf ? "conv_halo32_bf16_256x128" : "conv_halo32_f32_256x128";
+  const bool use_ws = bm == 256 && pp == 3;
+  if (use_ws) *kernel_name = bf ? "conv_halo_ws_bf16_256x128" : "conv_halo_ws_f32_256x128";
   if (dry_run) return Y3_OK;
   HaloArgs a;
   a.in = static_cast<const char *>(d_in);
@@ -1035,7 +1390,8 @@ int y3_launch_conv_halo(const y3_op &op, int bm, const void *d_in, const void *d
   const HaloGeom g = halo_geom(bm, op.in_w);
   Y3_REQUIRE(g.nsb != 0, "conv block %d: halo tile does not fit in LDS", op.block_idx);
   if (use32) return bf ? launch_halo32<bf16_t>(a, s) : launch_halo32<float>(a, s);
-  if (bm == 256 && g_y3_halo_pp) return bf ? launch_halo_pp<bf16_t>(a, s) : launch_halo_pp<float>(a, s);
+  if (use_ws) return bf ? launch_halo_ws<bf16_t>(a, s) : launch_halo_ws<float>(a, s);
+  if (bm == 256 && pp) return bf ? launch_halo_pp<bf16_t>(a, s) : launch_halo_pp<float>(a, s);
   if (bf) {
     if (bm == 256) return g.nsb == 4 ? launch_halo<bf16_t, 256, 4>(a, g, s) : launch_halo<bf16_t, 256, 3>(a, g, s);
     return g.nsb == 4 ? launch_halo<bf16_t, 192, 4>(a, g, s) : launch_halo<bf16_t, 192, 3>(a, g, s);

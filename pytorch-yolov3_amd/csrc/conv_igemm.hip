@@ -583,10 +583,332 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RB == 64 ? 3 : 1) void conv
   Y3_STAMP_COUNT();
 }
 
+// ------------------------------------------------------------------------------------------------
+// v3: wave-specialised pipeline.  Same tile geometry, LDS image and epilogue as v2, but the workgroup
+// carries twice the waves: waves [0, NC/64) only read fragments and issue MFMAs ("consumers"), waves
+// [NC/64, 2*NC/64) only compute source addresses and issue the LDS-DMA loads ("loaders").  Measured on
+// v2 (tools/conv_bench.py, stamps): one K-step of two co-resident 128x128 workgroups costs about the SUM
+// of its LDS-DMA issue time, its fragment reads and its MFMAs -- a wave that is stuck issuing a 1 KiB
+// LDS-DMA piece (60-185 cycles each, MI355X_MICROARCH.md constants table) issues no MFMA.  Splitting the
+// roles takes the DMA issue out of the MFMA waves' instruction stream; the SIMD's other wave keeps the
+// matrix pipe busy meanwhile.  NS LDS stages (2: 64 KiB, two workgroups per CU; 3: 96 KiB, one per CU, two
+// tiles in flight); one raw barrier per K-step pairs "tile kt has landed" with "stage kt-1 is free".
+template <int N>
+__device__ __forceinline__ void igemm_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, int NS>
+__global__ __launch_bounds__(128 * WAVES_M * WAVES_N, NS == 2 ? (WAVES_M * WAVES_N) : (WAVES_M * WAVES_N) / 2)
+void conv_igemm3_kernel(IgemmArgs p) {
+  constexpr int NC = 64 * WAVES_M * WAVES_N;         // consumer threads (== loader threads)
+  constexpr int NT = 2 * NC;
+  constexpr int RB = 128;
+  constexpr int ES = sizeof(T);
+  constexpr int CE = 16 / ES;
+  constexpr int BKE = RB / ES;
+  constexpr int CPRW = RB / 16;
+  constexpr int G = RB / 64;
+  constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
+  constexpr int MI = TM / 16, NI = TN / 16;
+  constexpr int ROWS_PER_PASS = NC / CPRW;
+  constexpr int A_CH = BM / ROWS_PER_PASS, B_CH = BN / ROWS_PER_PASS;
+  constexpr int PER = A_CH + B_CH;                   // LDS-DMA instructions per loader wave and K-tile
+  constexpr int STAGE = (BM + BN) * RB;
+  constexpr int LDS_BYTES = NS * STAGE;
+  static_assert(MI >= 1 && NI >= 1 && A_CH >= 1 && B_CH >= 1, "tile too small");
+  static_assert(BM * BN * 4 <= LDS_BYTES, "the fp32 output tile must fit in the operand stages");
+  static_assert((NS - 2) * PER <= 63, "vmcnt is 6 bits");
+
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar role branch
+  const bool loader = wave >= NC / 64;
+  Y3_STAMP_DECL
+
+  const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / p.n_tiles) * BM;
+  const int n0 = (tile % p.n_tiles) * BN;
+  const int n_kt = p.n_ktiles;
+
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void gbl_void;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wm = (wave % (NC / 64)) / WAVES_N, wn = (wave % (NC / 64)) % WAVES_N;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  if (loader) {
+    // ---------------- loader waves: addresses + LDS-DMA only ----------------
+    __builtin_amdgcn_s_setprio(3);   // youngest waves: keep their few instructions from starving behind the MFMA waves
+    const int ltid = tid - NC;
+    const int lwave = wave - NC / 64;
+    const int slot = ltid % CPRW;
+    const int row0 = ltid / CPRW;
+    const int kc = slot ^ (row0 & 7);
+    const char *a_base[A_CH];
+    uint32_t a_taps[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int m = m0 + row0 + ROWS_PER_PASS * i;
+      a_base[i] = p.zero;
+      a_taps[i] = 0u;
+      if (m < p.M) {
+        const uint32_t um = (uint32_t)m;
+        const uint32_t b = (__umulhi(um, p.mul_hw) + um) >> p.sh_hw;
+        const uint32_t rem = um - b * (uint32_t)p.HoWo;
+        const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
+        const uint32_t ox = rem - oy * (uint32_t)p.Wo;
+        const int iy0 = (int)oy * p.stride - p.pad;
+        const int ix0 = (int)ox * p.stride - p.pad;
+        const long long pix = ((long long)b * p.H + iy0) * p.W + ix0;
+        a_base[i] = p.in + pix * p.in_ld * ES + (KMODE == 0 ? kc * 16 : 0);
+        uint32_t vx = 0u, mask = 0u;
+        for (int kx = 0; kx < p.ks; ++kx) vx |= ((unsigned)(ix0 + kx) < (unsigned)p.W ? 1u : 0u) << kx;
+        for (int ky = 0; ky < p.ks; ++ky)
+          if ((unsigned)(iy0 + ky) < (unsigned)p.H) mask |= vx << (ky * p.ks);
+        a_taps[i] = mask;
+      }
+    }
+    const char *b_base[B_CH];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      b_base[i] = p.wgt + ((long long)(n0 + row0 + ROWS_PER_PASS * i) * p.k_ld) * ES + kc * 16;
+    int tl = 0, cc = 0, tpt = 1;
+    if constexpr (KMODE == 2) {
+      const int cpt = p.Cin / CE;
+      tpt = CPRW / cpt;
+      tl = kc / cpt;
+      cc = kc - tl * cpt;
+    }
+    auto issue = [&](int kt, int stage) {
+      long long tap_off;
+      int tap;
+      bool in_k = true;
+      if constexpr (KMODE == 0) {
+        tap = kt / p.ktiles_per_tap;
+        const int ci0 = (kt - tap * p.ktiles_per_tap) * BKE;
+        const int ky = tap / p.ks, kx = tap - ky * p.ks;
+        tap_off = ((long long)(ky * p.W + kx) * p.in_ld + ci0) * ES;
+      } else if constexpr (KMODE == 2) {
+        tap = kt * tpt + tl;
+        const int ky = tap / p.ks, kx = tap - ky * p.ks;
+        tap_off = ((long long)(ky * p.W + kx) * p.in_ld + cc * CE) * ES;
+        in_k = tap < p.ks * p.ks;
+      } else {
+        const int ke = kt * BKE + kc * CE;
+        tap = ke / p.Cin;
+        const int ci = ke - tap * p.Cin;
+        const int ky = tap / p.ks, kx = tap - ky * p.ks;
+        tap_off = ((long long)(ky * p.W + kx) * p.in_ld + ci) * ES;
+        in_k = ke < p.K;
+      }
+      char *sA = smem + stage * STAGE;
+      char *sB = sA + BM * RB;
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const bool ok = in_k && ((a_taps[i] >> tap) & 1u);
+        const char *src = ok ? a_base[i] + tap_off : p.zero;
+        __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(sA + lwave * 1024 + i * (NC * 16)), 16, 0, 0);
+      }
+      const long long koff = (long long)kt * RB;
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_void *)(b_base[i] + koff), (lds_void *)(sB + lwave * 1024 + i * (NC * 16)), 16, 0, 0);
+    };
+    int stage_next = 0;                               // stage that receives the next issued tile
+    for (int t = 0; t < NS - 1 && t < n_kt; ++t) {
+      issue(t, stage_next);
+      stage_next = stage_next + 1 == NS ? 0 : stage_next + 1;
+    }
+    Y3_STAMP(6);
+    for (int kt = 0; kt < n_kt; ++kt) {
+      // tiles issued so far: 0 .. min(kt + NS - 2, n_kt - 1); tile kt must have landed
+      if (NS > 2 && kt + NS - 2 < n_kt) igemm_wait_vmcnt<(NS - 2) * PER>();
+      else if (NS > 3 && kt + NS - 3 < n_kt) igemm_wait_vmcnt<(NS > 3 ? NS - 3 : 0) * PER>();
+      else igemm_wait_vmcnt<0>();
+      Y3_STAMP(3);
+      __builtin_amdgcn_s_barrier();                   // tile kt visible to the consumers; stage of tile kt-1 free
+      Y3_STAMP(4);
+      if (kt + NS - 1 < n_kt) {
+        issue(kt + NS - 1, stage_next);
+        stage_next = stage_next + 1 == NS ? 0 : stage_next + 1;
+      }
+      Y3_STAMP(5);
+    }
+#ifdef Y3_STAMPS
+    if (tid == NC) for (int _i = 3; _i < 7; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]);
+#endif
+  } else {
+    // ---------------- consumer waves: fragment reads + MFMAs only ----------------
+    int stage = 0;
+    Y3_STAMP(2);
+    for (int kt = 0; kt < n_kt; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      Y3_STAMP(0);
+      const char *sA = smem + stage * STAGE;
+      const char *sB = sA + BM * RB;
+      stage = stage + 1 == NS ? 0 : stage + 1;
+      u32x4 xf[G][MI], wf[G][NI];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int row = wn * TN + ni * 16 + fr;
+          wf[g][ni] = *reinterpret_cast<const u32x4 *>(sB + row * RB + ((((g * 4 + fq) ^ (row & 7))) << 4));
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int row = wm * TM + mi * 16 + fr;
+          xf[g][mi] = *reinterpret_cast<const u32x4 *>(sA + row * RB + ((((g * 4 + fq) ^ (row & 7))) << 4));
+        }
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], wf[g][ni], xf[g][mi]);
+      __builtin_amdgcn_s_setprio(0);
+      Y3_STAMP(1);
+    }
+#ifdef Y3_STAMPS
+    if (tid == 0) {
+      for (int _i = 0; _i < 3; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]);
+      atomicAdd(&g_y3_stamps[7], 1ull);
+    }
+#endif
+  }
+
+  // ---------------- epilogue: all 2*NC threads write out ----------------
+  constexpr int OCT_PER_ROW = BN / 8;
+  constexpr int WR = BM * OCT_PER_ROW / NT;
+  static_assert(WR * NT == BM * OCT_PER_ROW && NT % OCT_PER_ROW == 0, "write-out must tile evenly");
+  const int oc_mine = tid % OCT_PER_ROW;
+  const int co = n0 + oc_mine * 8;
+  const bool has_res = p.flags & Y3_F_RESIDUAL;
+  const bool res_fast = has_res && sizeof(T) == 2 && (p.res_ld % 8) == 0 && co + 8 <= p.Cout;
+  u32x4 resv[WR];
+  const f32x4 sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
+  const f32x4 sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+  const f32x4 bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
+  const f32x4 bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+  if (res_fast) {
+#pragma unroll
+    for (int j = 0; j < WR; ++j) {
+      const int m = m0 + (tid / OCT_PER_ROW) + j * (NT / OCT_PER_ROW);
+      const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
+      resv[j] = (m < p.M && co < p.Cout) ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();         // every consumer is done reading the last stage
+
+  constexpr int CPR = BN / 4;
+  constexpr int SWZ = (CPR < 16 ? CPR : 16) - 1;
+  float *sC = reinterpret_cast<float *>(smem);
+  const bool leaky = p.flags & Y3_F_LEAKY;
+  const bool out_f32 = (p.flags & Y3_F_OUT_F32) || sizeof(T) == 4;
+  const int nvalid = p.Cout - co < 8 ? p.Cout - co : 8;
+  if (!loader) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int cl = wn * TN + ni * 16 + fq * 4;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int pl = wm * TM + mi * 16 + fr;
+        *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
+      }
+    }
+  }
+  __syncthreads();
+  if (nvalid <= 0) return;
+#pragma unroll
+  for (int j = 0; j < WR; ++j) {
+    const int pl = (tid / OCT_PER_ROW) + j * (NT / OCT_PER_ROW);
+    const int m = m0 + pl;
+    if (m >= p.M) continue;
+    const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
+    const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = lo[r] * sc_lo[r] + bi_lo[r];
+      v[4 + r] = hi[r] * sc_hi[r] + bi_hi[r];
+    }
+    if (leaky) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : Y3_LEAKY_SLOPE * v[r];
+    }
+    if (has_res) {
+      if (res_fast) {
+        if constexpr (sizeof(T) == 2) {
+          const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[j]);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+        }
+      } else {
+        const T *rp = reinterpret_cast<const T *>(p.res) + (long long)m * p.res_ld + co;
+        for (int r = 0; r < nvalid; ++r) v[r] += y3_to_float<T>(rp[r]);
+      }
+    }
+    if (out_f32) {
+      float *op = reinterpret_cast<float *>(p.out) + (long long)m * p.out_ld + co;
+      if (nvalid == 8) {
+        *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
+        for (int r = 0; r < nvalid; ++r) op[r] = v[r];
+      }
+    } else {
+      T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
+      bool done = false;
+      if constexpr (sizeof(T) == 2) {
+        if (nvalid == 8 && (p.out_ld % 8) == 0) {
+          bf16x8 ov;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) ov[r] = (bf16_t)v[r];
+          *reinterpret_cast<bf16x8 *>(op) = ov;
+          done = true;
+        }
+      }
+      if (!done)
+        for (int r = 0; r < nvalid; ++r) op[r] = y3_from_float<T>(v[r]);
+    }
+  }
+}
+
 static int g_igemm_version = 2;   // 1 = register-staged single buffer, 2 = LDS-DMA double buffer
 static int g_igemm_bm = 0;        // 0 = heuristic, else 128 / 256 (256 = 8-wave tile, v2 bf16 only)
 static int g_igemm_staging = 0;    // 0 = LDS-DMA two stages, 1 = register-staged one stage
 static int g_igemm_rb = 128;       // bytes of K per tile row (128 or 64)
+static int g_igemm_ns = 2;         // v3: LDS stages (2 or 3)
+
+template <typename T, int BM, int BN, int WM, int WN, int NS>
+int launch_cfg3x(IgemmArgs a, int kmode, hipStream_t s) {
+  a.m_tiles = y3_ceil_div(a.M, BM);
+  a.n_tiles = y3_ceil_div(a.Cout, BN);
+  const dim3 grid(a.m_tiles * a.n_tiles), block(128 * WM * WN);
+  if (kmode == 0) hipLaunchKernelGGL((conv_igemm3_kernel<T, BM, BN, WM, WN, 0, NS>), grid, block, 0, s, a);
+  else if (kmode == 2) hipLaunchKernelGGL((conv_igemm3_kernel<T, BM, BN, WM, WN, 2, NS>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((conv_igemm3_kernel<T, BM, BN, WM, WN, 1, NS>), grid, block, 0, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_cfg3(const IgemmArgs &a, int kmode, int ns, hipStream_t s) {
+  if (ns == 4) return launch_cfg3x<T, BM, BN, WM, WN, 4>(a, kmode, s);
+  if (ns == 3) return launch_cfg3x<T, BM, BN, WM, WN, 3>(a, kmode, s);
+  return launch_cfg3x<T, BM, BN, WM, WN, 2>(a, kmode, s);
+}
 
 template <typename T, int BM, int BN, int WM, int WN, int ST, int RB>
 int launch_cfg2x(IgemmArgs a, int kmode, hipStream_t s) {
@@ -652,6 +974,8 @@ extern "C" int y3_set_tuning(const char *key, int value) {
   if (!strcmp(key, "igemm_bm")) { g_igemm_bm = value; return Y3_OK; }
   if (!strcmp(key, "igemm_staging")) { g_igemm_staging = value; return Y3_OK; }
   if (!strcmp(key, "igemm_rb")) { g_igemm_rb = value; return Y3_OK; }
+  if (!strcmp(key, "igemm_ns")) { g_igemm_ns = value; return Y3_OK; }
+  if (!strcmp(key, "auto_mask")) { g_y3_auto_mask = value; return Y3_OK; }
   if (!strcmp(key, "conv_halo")) { g_y3_use_halo = value; return Y3_OK; }
   if (!strcmp(key, "halo_pp")) { g_y3_halo_pp = value; return Y3_OK; }
   if (!strcmp(key, "halo_bm")) { g_y3_halo_bm = value; return Y3_OK; }
@@ -660,12 +984,14 @@ extern "C" int y3_set_tuning(const char *key, int value) {
 }
 
 int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
-                         const char **kernel_name, bool dry_run) {
+                         const char **kernel_name, bool dry_run, int force_version, int force_ns) {
+  const int version = force_version ? force_version : g_igemm_version;
+  const int ns = force_ns ? force_ns : g_igemm_ns;
   Y3_REQUIRE(y3_conv_igemm_supported(op), "conv block %d: shape not supported by the igemm kernel",
              op.block_idx);
   const int es = y3_elem_size(op.dtype);
   // K-tile row: 128 bytes, or 64 bytes (tuning knob "igemm_rb": 3 workgroups per CU) for the 128-wide tile
-  const bool rb64 = g_igemm_rb == 64 && g_igemm_version == 2 && op.out_c > 64 && !(op.flags & Y3_F_OUT_F32) &&
+  const bool rb64 = g_igemm_rb == 64 && version == 2 && op.out_c > 64 && !(op.flags & Y3_F_OUT_F32) &&
                     g_igemm_bm != 256;
   const int bke = (rb64 ? 64 : 128) / es;
   IgemmArgs a;
@@ -702,7 +1028,7 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
   // channel-tile width follows Cout so narrow layers do not multiply zero padding
   const int bn = op.out_c > 64 ? 128 : (op.out_c > 32 ? 64 : 32);
   // float32-output (detection head) convs: the direct epilogue of v1 measured faster
-  if (g_igemm_version == 1 || (g_igemm_version == 2 && bf && (op.flags & Y3_F_OUT_F32))) {
+  if (version == 1 || (version == 2 && bf && (op.flags & Y3_F_OUT_F32))) {
     const bool generic = kmode != 0;
     if (generic) a.n_ktiles = y3_ceil_div(a.K, bke);
     if (bn == 128) {
@@ -717,6 +1043,11 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
     *kernel_name = bf ? "conv_igemm_bf16_128x32" : "conv_igemm_f32_128x32";
     if (dry_run) return Y3_OK;
     return bf ? launch_cfg<bf16_t, 128, 32, 4, 1>(a, generic, s) : launch_cfg<float, 128, 32, 4, 1>(a, generic, s);
+  }
+  if (version == 3 && bn == 128 && !(op.flags & Y3_F_OUT_F32)) {
+    *kernel_name = bf ? "conv_igemm3_bf16_128x128" : "conv_igemm3_f32_128x128";
+    if (dry_run) return Y3_OK;
+    return bf ? launch_cfg3<bf16_t, 128, 128, 2, 2>(a, kmode, ns, s) : launch_cfg3<float, 128, 128, 2, 2>(a, kmode, ns, s);
   }
   if (bn == 128) {
     if (bf && g_igemm_bm == 256) {

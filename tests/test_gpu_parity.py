@@ -107,8 +107,9 @@ def test_tuning_knobs_do_not_change_results():
     x = torch.from_numpy(g["input"])
     ref = _net("mini").forward(x)
     try:
-        for knobs in ({"igemm_version": 1}, {"igemm_staging": 1}, {"igemm_rb": 64}, {"conv_halo": 1, "halo_pp": 0},
-                      {"conv_halo": 1, "halo_pp": 1, "halo_bm": 256}, {"conv_halo": 1, "halo_pp": 2, "halo_bm": 256}):
+        for knobs in ({"auto_mask": 0}, {"auto_mask": 63}, {"igemm_version": 1}, {"igemm_version": 3}, {"igemm_staging": 1}, {"igemm_rb": 64}, {"conv_halo": 1, "halo_pp": 0},
+                      {"conv_halo": 1, "halo_pp": 1, "halo_bm": 256}, {"conv_halo": 1, "halo_pp": 2, "halo_bm": 256},
+                      {"conv_halo": 1, "halo_pp": 3, "halo_bm": 256}):
             for k, v in knobs.items():
                 _hip.check(lib.y3_set_tuning(k.encode(), v))
             out = _net("mini").forward(x)
@@ -117,10 +118,10 @@ def test_tuning_knobs_do_not_change_results():
             np.testing.assert_allclose(out["bbox_xywh"].cpu().numpy(), ref["bbox_xywh"].cpu().numpy(), rtol=1e-4,
                                        atol=1e-5, err_msg=str(knobs))
             for k in knobs:
-                _hip.check(lib.y3_set_tuning(k.encode(), {"igemm_version": 2, "igemm_rb": 128}.get(k, 0)))
+                _hip.check(lib.y3_set_tuning(k.encode(), {"igemm_version": 2, "igemm_rb": 128, "auto_mask": 21}.get(k, 0)))
     finally:
         for k, v in (("igemm_version", 2), ("igemm_staging", 0), ("igemm_rb", 128), ("conv_halo", 0), ("halo_pp", 1),
-                     ("halo_bm", 0), ("igemm_bm", 0)):
+                     ("halo_bm", 0), ("igemm_bm", 0), ("auto_mask", 21)):
             lib.y3_set_tuning(k.encode(), v)
     assert lib.y3_set_tuning(b"no_such_knob", 1) != 0
 
@@ -261,9 +262,9 @@ def test_halo_kernels_match_igemm_on_yolov3_fp32():
     g = np.load(os.path.join(GOLDEN, "forward_yolov3.npz"))
     frames = np.stack([resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), 608, 608), synth_frames(5, 1, 608, 608)[0]])
     try:
-        for pp in (0, 1, 2):
+        for pp in (0, 1, 2, 3):
             _hip.check(lib.y3_set_tuning(b"conv_halo", 1))
-            _hip.check(lib.y3_set_tuning(b"halo_bm", 256 if pp == 2 else 0))
+            _hip.check(lib.y3_set_tuning(b"halo_bm", 256 if pp >= 2 else 0))
             _hip.check(lib.y3_set_tuning(b"halo_pp", pp))
             out = _net("yolov3").forward(torch.from_numpy(orc.frames_to_input(list(frames))))
             np.testing.assert_allclose(out["bbox_xywh"].cpu().numpy(), g["bbox_xywh"], rtol=1e-4, atol=BOX_ATOL)
@@ -272,6 +273,35 @@ def test_halo_kernels_match_igemm_on_yolov3_fp32():
         lib.y3_set_tuning(b"conv_halo", 0)
         lib.y3_set_tuning(b"halo_pp", 1)
         lib.y3_set_tuning(b"halo_bm", 0)
+
+
+def test_wave_specialised_igemm_is_bit_identical():
+    """igemm v3 (loader / consumer waves) runs the same MFMA sequence per accumulator as v2: whole-network
+    outputs must be bit-identical, fp32 against the goldens too, for 2 and 3 LDS stages."""
+    from yolov3 import _hip
+    lib = _hip.lib()
+    g = np.load(os.path.join(GOLDEN, "forward_yolov3.npz"))
+    frames = np.stack([resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), 608, 608), synth_frames(5, 1, 608, 608)[0]])
+    x = torch.from_numpy(orc.frames_to_input(list(frames)))
+    _hip.check(lib.y3_set_tuning(b"auto_mask", 0))      # every MFMA conv through the implicit GEMM
+    try:
+        ref32 = _net("yolov3").forward(x)
+        ref16 = _net("yolov3", dtype="bf16").forward_frames(frames)
+        ref16 = {k: v.clone() for k, v in ref16.items()}
+        for ns in (2, 3, 4):
+            _hip.check(lib.y3_set_tuning(b"igemm_version", 3))
+            _hip.check(lib.y3_set_tuning(b"igemm_ns", ns))
+            out = _net("yolov3").forward(x)
+            np.testing.assert_allclose(out["bbox_xywh"].cpu().numpy(), g["bbox_xywh"], rtol=1e-4, atol=BOX_ATOL)
+            for k in ("bbox_xywh", "class_prob", "class_idx"):
+                assert torch.equal(out[k], ref32[k]), (ns, k)
+            out16 = _net("yolov3", dtype="bf16").forward_frames(frames)
+            for k in ("bbox_xywh", "class_prob", "class_idx"):
+                assert torch.equal(out16[k], ref16[k]), (ns, k, "bf16")
+    finally:
+        lib.y3_set_tuning(b"igemm_version", 2)
+        lib.y3_set_tuning(b"igemm_ns", 2)
+        lib.y3_set_tuning(b"auto_mask", 21)
 
 
 def test_bf16_agreement_report_yolov3():

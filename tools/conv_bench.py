@@ -35,14 +35,16 @@ LAYERS = [
     ("s38_512-256_k1", 38, 512, 256, 1, 1, False, False),
     ("s19_1024-512_k1", 19, 1024, 512, 1, 1, False, False),
     ("s152_128-64_k1", 152, 128, 64, 1, 1, False, False),
+    ("s38_768-256_k1", 38, 768, 256, 1, 1, False, False),
+    ("s76_384-128_k1", 76, 384, 128, 1, 1, False, False),
     ("s76_256-255_k1_head", 76, 256, 255, 1, 1, False, True),
 ]
 
 VARIANTS = [
-    ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128}),
-    ("halo_il256", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 0, "halo_bm": 256, "igemm_staging": 0, "igemm_rb": 128}),
-    ("halo32", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 2, "halo_bm": 256, "igemm_staging": 0, "igemm_rb": 128}),
-    ("halo_pp256", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 1, "halo_bm": 256, "igemm_staging": 0, "igemm_rb": 128}),
+    ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128, "igemm_ns": 2}),
+    ("v3_ws_ns3", {"igemm_version": 3, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128, "igemm_ns": 3}),
+    ("v3_ws_ns4", {"igemm_version": 3, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128, "igemm_ns": 4}),
+    ("halo_ws", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 3, "halo_bm": 256, "igemm_staging": 0, "igemm_rb": 128, "igemm_ns": 2}),
 ]
 
 
@@ -132,10 +134,8 @@ def main():
                         getattr(lib, rd)(buf)
                         if buf[7]:
                             n = float(buf[7])
-                            print("    [%s %s] blocks/launch %.0f  cycles/block: setup %.0f  first-wait %.0f  mainloop %.0f  "
-                                  "epilogue %.0f | slots 4-6: %.0f %.0f %.0f" % (
-                                      vname, rd[16:], n / (args.iters + 2), buf[0] / n, buf[1] / n, buf[2] / n, buf[3] / n,
-                                      buf[4] / n, buf[5] / n, buf[6] / n))
+                            print("    [%s %s] blocks/launch %.0f  cycles/block slots 0-6: %s" % (
+                                vname, rd[16:], n / (args.iters + 2), " ".join("%.0f" % (buf[i] / n) for i in range(7))))
         ref = outs[0].float()
         row = dict(layer=name, gflop=flops / 1e9)
         line = "%-22s %7.1f GF |" % (name, flops / 1e9)
