@@ -25,6 +25,7 @@ namespace {
 
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
+constexpr int kIt = 8;          // 1024-row chunks handled per compaction pass (kIt * kWaves == 128)
 constexpr int kLdsSort = 4096;  // elements sorted in LDS; larger frames sort in global memory
 
 struct DetectArgs {
@@ -79,6 +80,42 @@ __device__ __forceinline__ long long shfl_ll(long long v, int src) {
   return ((long long)hi << 32) | (unsigned int)lo;
 }
 
+// value of lane k (wave-uniform k) as a scalar: v_readlane_b32, no LDS traffic
+__device__ __forceinline__ long long readlane_ll(long long v, int k) {
+  const int lo = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFFll), k);
+  const int hi = __builtin_amdgcn_readlane((int)(v >> 32), k);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// Fast form of the suppression test for boxes whose coordinates all lie within +-16000 (widths <= 32001, areas
+// <= 1.03e9, unions < 2^31: exact in 32-bit integers).  fl(inter / uni) > thr (float64 true division,
+// inference.py:211-215) is decided without dividing: d = inter - thr * uni (one fma rounding) has the exact sign of
+// inter / uni - thr, and the rounded quotient can disagree with that sign only inside (thr, thr + ulp(thr) / 2];
+// pairs that close (d <= uni * |thr| * 2.3e-16), or with a non-positive union (degenerate boxes: the reference's
+// inf / nan / negative quotient decides), take the division.  thr_m = |thr| * 2.3e-16.
+__device__ __forceinline__ bool iou_exceeds_i32(int ax1, int ay1, int ax2, int ay2, int aarea, int x1, int y1, int x2,
+                                                int y2, int area, double thr, double thr_m) {
+  int iw = (ax2 < x2 ? ax2 : x2) - (ax1 > x1 ? ax1 : x1) + 1;
+  int ih = (ay2 < y2 ? ay2 : y2) - (ay1 > y1 ? ay1 : y1) + 1;
+  iw = iw > 0 ? iw : 0;
+  ih = ih > 0 ? ih : 0;
+  const int inter = iw * ih;
+  const int uni = aarea + area - inter;
+  const double a = (double)inter, u = (double)uni;
+  const double d = fma(-thr, u, a);
+  bool hit = d > u * thr_m;
+  const bool unsure = !(uni > 0) || (d > 0.0 && !hit);
+  if (__ballot(unsure) != 0ull) {
+    if (unsure) hit = a / u > thr;
+  }
+  return hit;
+}
+
+__device__ __forceinline__ bool box_fits_i32(long long x1, long long y1, long long x2, long long y2) {
+  const long long lim = 16000;
+  return x1 > -lim && x1 < lim && y1 > -lim && y1 < lim && x2 > -lim && x2 < lim && y2 > -lim && y2 < lim;
+}
+
 // block-wide ordered compaction step: returns this thread's output slot (valid when flag) and
 // adds the step's total to `running`.  Must be called by all threads.
 __device__ __forceinline__ int ordered_slot(bool flag, int &running, int *wave_tot) {
@@ -105,6 +142,7 @@ __global__ __launch_bounds__(kThreads) void detect_kernel(DetectArgs p) {
   __shared__ unsigned long long skey[kLdsSort];
   __shared__ unsigned int spos[kLdsSort];
   __shared__ int wave_tot[kWaves];
+  __shared__ int chunk_tot[kIt * kWaves];
   __shared__ int nseg_sh;
 
   const int b = blockIdx.x;
@@ -126,27 +164,57 @@ __global__ __launch_bounds__(kThreads) void detect_kernel(DetectArgs p) {
     int *w_cls = p.c_cls + (long long)b * R;
     int *w_row = p.c_row + (long long)b * R;
     const float oh = (float)p.orig_hw[b * 2 + 0], ow = (float)p.orig_hw[b * 2 + 1];
-    for (int base = 0; base < p.rows; base += kThreads) {
-      const int r = base + tid;
-      float pr = 0.f;
-      bool flag = false;
-      if (r < p.rows) {
-        pr = p.prob[(long long)b * R + r];
-        flag = pr >= p.prob_thresh;  // float32 compare (inference.py:342)
+    // kIt row-chunks per pass: the kIt score loads of a thread fly together (one memory latency per pass instead
+    // of one per chunk), and the ordered slots of all kIt x 16 wave-chunks come from ONE workgroup barrier plus a
+    // wave-level scan of the 128 ballot counts (every wave scans them redundantly: no second barrier to publish).
+    for (int base = 0; base < p.rows; base += kIt * kThreads) {
+      float pr[kIt];
+#pragma unroll
+      for (int it = 0; it < kIt; ++it) {
+        const int r = base + it * kThreads + tid;
+        pr[it] = r < p.rows ? p.prob[(long long)b * R + r] : 0.f;
       }
-      const int slot = ordered_slot(flag, n, wave_tot);
-      if (flag) {
-        const f32x4 bb = *reinterpret_cast<const f32x4 *>(p.bbox + ((long long)b * R + r) * 4);
-        // float32 products, then truncation toward zero (inference.py:351-353)
-        const long long cx = (long long)(bb[0] * ow), cy = (long long)(bb[1] * oh);
-        const long long bw = (long long)(bb[2] * ow), bh = (long long)(bb[3] * oh);
-        const long long hw = bw >> 1, hh = bh >> 1;  // floor division by 2 (inference.py:281-282)
-        long long *o = w_box + (long long)slot * 4;
-        o[0] = cx - hw; o[1] = cy - hh; o[2] = cx + hw; o[3] = cy + hh;
-        w_prob[slot] = pr;
-        w_cls[slot] = (int)p.cls[(long long)b * R + r];
-        w_row[slot] = r;
+      int pre[kIt];
+      bool fl[kIt];
+#pragma unroll
+      for (int it = 0; it < kIt; ++it) {
+        const int r = base + it * kThreads + tid;
+        fl[it] = r < p.rows && pr[it] >= p.prob_thresh;  // float32 compare (inference.py:342)
+        const unsigned long long ballot = __ballot(fl[it]);
+        pre[it] = __popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) chunk_tot[it * kWaves + wave] = __popcll(ballot);
       }
+      __syncthreads();
+      const int t0 = chunk_tot[2 * lane], t1 = chunk_tot[2 * lane + 1];   // kIt * kWaves == 128 == 2 per lane
+      int incl = t0 + t1;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+      }
+      const int excl = incl - (t0 + t1);
+      const int total = __shfl(incl, 63, 64);
+#pragma unroll
+      for (int it = 0; it < kIt; ++it) {
+        const int e = it * kWaves + wave;                       // this thread's chunk in (pass, wave) order
+        const int off = __shfl(excl, e >> 1, 64) + ((e & 1) ? __shfl(t0, e >> 1, 64) : 0);
+        if (fl[it]) {
+          const int r = base + it * kThreads + tid;
+          const int slot = n + off + pre[it];
+          const f32x4 bb = *reinterpret_cast<const f32x4 *>(p.bbox + ((long long)b * R + r) * 4);
+          // float32 products, then truncation toward zero (inference.py:351-353)
+          const long long cx = (long long)(bb[0] * ow), cy = (long long)(bb[1] * oh);
+          const long long bw = (long long)(bb[2] * ow), bh = (long long)(bb[3] * oh);
+          const long long hw = bw >> 1, hh = bh >> 1;  // floor division by 2 (inference.py:281-282)
+          long long *o = w_box + (long long)slot * 4;
+          o[0] = cx - hw; o[1] = cy - hh; o[2] = cx + hw; o[3] = cy + hh;
+          w_prob[slot] = pr[it];
+          w_cls[slot] = (int)p.cls[(long long)b * R + r];
+          w_row[slot] = r;
+        }
+      }
+      n += total;
+      __syncthreads();   // chunk_tot is rewritten by the next pass
     }
     __syncthreads();
   } else {
@@ -231,6 +299,7 @@ __global__ __launch_bounds__(kThreads) void detect_kernel(DetectArgs p) {
   const int nseg = nseg_sh;
 
   // ---- phase 4: greedy NMS, one wavefront per class segment ----------------------------------
+  const double thr_m = fabs(p.iou_thresh) * 2.3e-16;
   for (int s = wave; s < nseg; s += kWaves) {
     const int start = seg[s];
     const unsigned int c = (unsigned int)(s_key[start] >> 32);
@@ -249,6 +318,10 @@ __global__ __launch_bounds__(kThreads) void detect_kernel(DetectArgs p) {
         x1 = bp[0]; y1 = bp[1]; x2 = bp[2]; y2 = bp[3];
       }
       const long long area = (x2 - x1 + 1) * (y2 - y1 + 1);
+      // 32-bit fast path when every box of this chunk (and of the earlier chunk it is compared with) is small
+      const bool fits_all = __ballot(box_fits_i32(x1, y1, x2, y2)) == ~0ull;
+      const int ix1 = (int)x1, iy1 = (int)y1, ix2 = (int)x2, iy2 = (int)y2;
+      const int iarea = (ix2 - ix1 + 1) * (iy2 - iy1 + 1);
       bool dead = !valid;
       // survivors of earlier chunks of this class
       for (int p0 = start; p0 < c0; p0 += 64) {
@@ -256,6 +329,19 @@ __global__ __launch_bounds__(kThreads) void detect_kernel(DetectArgs p) {
         if (kept == 0ull) continue;
         const long long *qp = c_box + (long long)s_pos[p0 + lane] * 4;
         const long long qx1 = qp[0], qy1 = qp[1], qx2 = qp[2], qy2 = qp[3];
+        if (fits_all && __ballot(box_fits_i32(qx1, qy1, qx2, qy2)) == ~0ull) {
+          const int pqx1 = (int)qx1, pqy1 = (int)qy1, pqx2 = (int)qx2, pqy2 = (int)qy2;
+          const int pqarea = (pqx2 - pqx1 + 1) * (pqy2 - pqy1 + 1);
+          while (kept) {
+            const int k = __ffsll((long long)kept) - 1;
+            kept &= kept - 1ull;
+            dead = dead || iou_exceeds_i32(__builtin_amdgcn_readlane(pqx1, k), __builtin_amdgcn_readlane(pqy1, k),
+                                           __builtin_amdgcn_readlane(pqx2, k), __builtin_amdgcn_readlane(pqy2, k),
+                                           __builtin_amdgcn_readlane(pqarea, k), ix1, iy1, ix2, iy2, iarea,
+                                           p.iou_thresh, thr_m);
+          }
+          continue;
+        }
         while (kept) {
           const int k = __ffsll((long long)kept) - 1;
           kept &= kept - 1ull;
@@ -273,6 +359,16 @@ __global__ __launch_bounds__(kThreads) void detect_kernel(DetectArgs p) {
       }
       // greedy inside the chunk, in score order (lane order)
       unsigned long long alive = __ballot(!dead);
+      if (fits_all) {
+        for (int k = 0; k < 64; ++k) {
+          if (!((alive >> k) & 1ull)) continue;  // wave-uniform
+          const bool hit = iou_exceeds_i32(__builtin_amdgcn_readlane(ix1, k), __builtin_amdgcn_readlane(iy1, k),
+                                           __builtin_amdgcn_readlane(ix2, k), __builtin_amdgcn_readlane(iy2, k),
+                                           __builtin_amdgcn_readlane(iarea, k), ix1, iy1, ix2, iy2, iarea,
+                                           p.iou_thresh, thr_m);
+          alive &= ~__ballot(lane > k && hit);
+        }
+      } else {
       for (int k = 0; k < 64; ++k) {
         if (!((alive >> k) & 1ull)) continue;  // wave-uniform
         const long long ax1 = shfl_ll(x1, k), ay1 = shfl_ll(y1, k);
@@ -286,6 +382,7 @@ __global__ __launch_bounds__(kThreads) void detect_kernel(DetectArgs p) {
         const double iou = (double)inter / (double)(aarea + area - inter);
         const bool hit = lane > k && (iou > p.iou_thresh);
         alive &= ~__ballot(hit);
+      }
       }
       if (valid) keep[idx] = (alive >> lane) & 1ull ? 1 : 0;
       __threadfence_block();  // later chunks of this wavefront read these flags

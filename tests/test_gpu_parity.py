@@ -227,6 +227,26 @@ def test_nms_cases_match_reference():
     assert yolov3.non_max_suppression(np.zeros((0, 4), dtype=np.int64), np.zeros(0, dtype=np.float32)) == []
 
 
+@pytest.mark.parametrize("thr", [0.3, 0.5, 0.25, 1.0 / 3.0, 0.2, 0.0, 1.0])
+def test_nms_borderline_ratios_match_oracle(thr):
+    """Small integer boxes make inter / union land exactly on (or one rounding away from) the threshold all the
+    time (3/10 vs 0.3, 1/2 vs 0.5, 1/3 ...): the kernel's division-free compare must decide exactly like the
+    reference's float64 quotient, including degenerate (x2 < x1) boxes whose union is <= 0."""
+    rs = np.random.RandomState(int(thr * 1000) + 7)
+    n = 1500
+    tl = rs.randint(0, 12, size=(n, 2))
+    wh = rs.randint(-1, 7, size=(n, 2))          # -1 -> degenerate boxes
+    boxes = np.concatenate([tl, tl + wh], axis=1).astype(np.int64)
+    boxes[0] = [0, 0, 9, 0]
+    boxes[1] = [7, 0, 9, 0]                        # inter 3, union 10 with box 0
+    prob = (rs.permutation(n).astype(np.float32) + 1) / (n + 1)
+    prob[0], prob[1] = 2.0, 1.5
+    for cls in (None, rs.randint(0, 4, size=n).astype(np.int64)):
+        want = orc.non_max_suppression(boxes, prob, class_idx=cls, iou_thresh=thr)
+        got = yolov3.non_max_suppression(boxes, prob, class_idx=cls, iou_thresh=thr)
+        assert sorted(got) == sorted(int(i) for i in want)
+
+
 @pytest.mark.parametrize("n,ncls", [(5000, 1), (9000, 3), (20000, 80)])
 def test_nms_large_matches_oracle(n, ncls):
     """Sizes past the in-LDS sort limit (4096) and a single crowded class."""
