@@ -1,0 +1,142 @@
+"""Callers of the hot path: COCO export, id matching, box drawing, file
+listing, command line.  CPU tests pin the host logic against vectors produced by the reference
+(tests/golden/coco_export.json, tools/make_goldens.py g9); the GPU tests check that the batched
+loops return exactly what per-frame ``inference()`` returns."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+
+import yolov3
+from yolov3 import stream
+from yolov3.__main__ import build_parser, main as cli_main
+from yolov3.devtools import coco_util
+
+from golden_util import GOLDEN, MODELS, golden_weights_path, load_jpeg_bgr
+
+
+def _coco_case():
+    with open(os.path.join(GOLDEN, "coco_export.json")) as fh:
+        g = json.load(fh)
+    output = [[np.array(b, dtype=np.int64).reshape(-1, 4), np.array(p, dtype=np.uint32).view(np.float32),
+               np.array(c, dtype=np.int64)] for b, p, c in g["inference_output"]]
+    return g, output
+
+
+def test_to_coco_matches_reference():
+    g, output = _coco_case()
+    got = yolov3.to_coco(g["image_filenames"], output, g["class_names"])
+    assert got == g["to_coco"]
+    json.dumps(got)   # plain Python numbers only
+
+
+def test_match_ids_matches_reference():
+    g, output = _coco_case()
+    dataset = yolov3.to_coco(g["image_filenames"], output, g["class_names"])
+    coco_util.match_ids(dataset, copy.deepcopy(g["reference_dataset"]))
+    assert dataset == g["match_ids"]
+    with pytest.raises(KeyError):
+        bad = copy.deepcopy(g["reference_dataset"])
+        bad["images"].append({"file_name": "missing.jpg", "id": 1, "height": 1, "width": 1})
+        coco_util.match_ids(yolov3.to_coco(g["image_filenames"], output, g["class_names"]), bad)
+
+
+def test_draw_boxes_outlines_and_clipping():
+    img = np.zeros((40, 60, 3), dtype=np.uint8)
+    boxes = np.array([[10, 8, 30, 20], [-5, -5, 70, 50]], dtype=np.int64)      # second one leaves the image
+    out = yolov3.draw_boxes(img, boxes)
+    assert out is img
+    assert (img[8, 10:31] == (0, 255, 0)).all() and (img[20, 10:31] == (0, 255, 0)).all()
+    assert (img[8:21, 10] == (0, 255, 0)).all() and (img[8:21, 30] == (0, 255, 0)).all()
+    assert (img[14, 20] == 0).all()                                            # interior untouched
+    # per-class colours + labels: no exception, label patch drawn inside the image
+    img2 = np.zeros((64, 64, 3), dtype=np.uint8)
+    yolov3.draw_boxes(img2, boxes[:1], class_prob=np.array([0.5]), class_idx=np.array([1]), class_names=["a", "b"])
+    assert img2.any()
+    assert len(set(stream.unique_colors(5))) == 5
+
+
+def test_list_image_files_sorted_and_filtered(tmp_path):
+    for name in ("b.jpg", "a.png", "notes.txt", "c.JPG"):
+        (tmp_path / name).write_bytes(b"x")
+    directory, names = stream.list_image_files(tmp_path)
+    assert directory == str(tmp_path) and names == ["a.png", "b.jpg", "c.JPG"]
+    directory, names = stream.list_image_files(tmp_path / "b.jpg")
+    assert directory == str(tmp_path) and names == ["b.jpg"]
+
+
+def test_cli_flags_mirror_the_reference():
+    p = build_parser()
+    a = p.parse_args(["-V", "v.mp4", "-c", "m.cfg", "-w", "m.weights", "-i", "0.4", "-p", "0.2", "-n", "names.txt",
+                      "-o", "out", "--show-fps", "-v"])
+    assert a.iou_thresh == 0.4 and a.prob_thresh == 0.2 and a.device == "cuda" and a.show_fps and a.verbose
+    assert p.parse_args(["-C", "-c", "m.cfg", "-w", "w"]).cam == 0           # bare -C: device 0
+    with pytest.raises(SystemExit):
+        p.parse_args(["-c", "m.cfg", "-w", "w"])                              # an input source is required
+    with pytest.raises(SystemExit):
+        p.parse_args(["-I", "a", "-V", "b", "-c", "m.cfg", "-w", "w"])        # ... and exactly one
+    with pytest.raises(SystemExit):
+        cli_main(["-I", "a", "-c", "m.cfg", "-w", "w", "-d", "cpu"])          # no CPU path: refused loudly
+
+
+def test_video_and_camera_need_opencv_and_say_so(tmp_path):
+    if stream._cv2() is not None:
+        pytest.skip("OpenCV present")
+    with pytest.raises(RuntimeError, match="OpenCV"):
+        list(stream._video_frames(str(tmp_path / "clip.mp4")))
+    with pytest.raises(RuntimeError, match="OpenCV"):
+        stream.detect_in_cam(None)
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+IMAGES = ["000000000785.jpg", "000000017627.jpg", "000000024919.jpg", "000000035279.jpg", "000000037777.jpg"]
+
+
+def _net(dtype="float32"):
+    net = yolov3.Darknet(MODELS["yolov3-tiny"], device="cuda", dtype=dtype)
+    net.load_weights(golden_weights_path("yolov3-tiny"))
+    return net.eval()
+
+
+def _same(a, b):
+    return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
+def test_batched_frame_loop_equals_per_frame_inference():
+    names = sorted(n for n in os.listdir(os.path.join(GOLDEN, "images")) if n.endswith(".jpg"))
+    frames = [load_jpeg_bgr(n) for n in names]          # different sizes: resized on the GPU per frame
+    net = _net()
+    want = [yolov3.inference(net, f, prob_thresh=0.2, nms_iou_thresh=0.3)[0] for f in frames]
+    for batch_size, in_flight in ((4, 2), (2, 3), (16, 1), (1, 2)):
+        got = list(yolov3.detect_in_frames(net, iter(frames), batch_size=batch_size, prob_thresh=0.2,
+                                           nms_iou_thresh=0.3, in_flight=in_flight))
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert _same(g, w), (batch_size, in_flight)
+    assert list(yolov3.detect_in_frames(net, [], batch_size=4)) == []
+
+
+@pytest.mark.gpu
+def test_video_loop_over_a_frame_directory_and_cli(tmp_path):
+    img_dir = os.path.join(GOLDEN, "images")
+    net = _net()
+    collected = []
+    results = yolov3.detect_in_video(net, img_dir, prob_thresh=0.2, frames=collected, batch_size=4)
+    names_sorted = stream.list_image_files(img_dir)[1]
+    assert len(results) == len(names_sorted) == len(collected)
+    first = yolov3.inference(net, load_jpeg_bgr(names_sorted[0]), prob_thresh=0.2)[0]
+    assert _same(results[0], first)
+    assert collected[0].shape == load_jpeg_bgr(names_sorted[0]).shape
+
+    out_json, out_dir = tmp_path / "det.json", tmp_path / "frames"
+    rc = cli_main(["-I", img_dir, "-c", MODELS["yolov3-tiny"], "-w", golden_weights_path("yolov3-tiny"), "-p", "0.2",
+                   "--dtype", "float32", "-b", "4", "--json", str(out_json), "-o", str(out_dir)])
+    assert rc == 0
+    with open(out_json) as fh:
+        ds = json.load(fh)
+    assert [im["file_name"] for im in ds["images"]] == names_sorted
+    assert len(ds["annotations"]) == sum(len(r[1]) for r in results)
+    assert len(os.listdir(out_dir)) == len(names_sorted)

@@ -22,6 +22,7 @@ Golden sets:
   G5 forward_<model>.npz      full Darknet.forward outputs
   G6 nms_cases.json           non_max_suppression cases (per-class, agnostic, edge cases)
   G7 inference_<model>.npz    inference() end-to-end lists + fragility audit
+  G9 coco_export.json         to_coco() and devtools.coco_util.match_ids() on a small detection set
 """
 import hashlib
 import importlib.util
@@ -319,8 +320,39 @@ def g6_nms():
     print("G6 ok", [(c["name"], len(c["per_class"] or []), len(c["agnostic"])) for c in cases])
 
 
+# ---------------------------------------------------------------- G9
+def g9_coco_export():
+    """Reference to_coco (inference.py:371-432) and match_ids (devtools/coco_util.py:110-150)."""
+    import copy
+    rs = np.random.RandomState(9)
+    names = ["person", "bicycle", "car", "dog"]
+    files = ["b.jpg", "a.jpg", "c.jpg"]
+    output = []
+    for k in (3, 0, 2):
+        tl = rs.randint(-5, 300, size=(k, 2))
+        wh = rs.randint(0, 90, size=(k, 2))
+        output.append([np.concatenate([tl, tl + wh], axis=1).astype(np.int64),
+                       rs.rand(k).astype(np.float32), rs.randint(0, 4, size=k).astype(np.int64)])
+    dataset = ref.to_coco(files, copy.deepcopy(output), names)
+    reference_dataset = {
+        "categories": [{"id": 18, "name": "dog"}, {"id": 1, "name": "person"}, {"id": 3, "name": "car"},
+                       {"id": 2, "name": "bicycle"}],
+        "images": [{"file_name": "a.jpg", "id": 900, "height": 480, "width": 640},
+                   {"file_name": "b.jpg", "id": 17, "height": 427, "width": 640},
+                   {"file_name": "c.jpg", "id": 23, "height": 333, "width": 500}],
+    }
+    matched = copy.deepcopy(dataset)
+    ref.devtools.coco_util.match_ids(matched, reference_dataset)
+    with open(os.path.join(GOLD, "coco_export.json"), "w") as fh:
+        json.dump(jsonable({
+            "class_names": names, "image_filenames": files,
+            "inference_output": [[o[0].tolist(), [int(v) for v in o[1].view(np.uint32)], o[2].tolist()] for o in output],
+            "to_coco": dataset, "reference_dataset": reference_dataset, "match_ids": matched}), fh, indent=1)
+    print("G9 ok", len(dataset["annotations"]), "annotations")
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"g2", "g3", "g4", "g5", "g6", "g7"}
+    which = set(sys.argv[1:]) or {"g2", "g3", "g4", "g5", "g6", "g7", "g9"}
     torch.manual_seed(0)
     if "g2" in which:
         g2_parse_config()
@@ -330,6 +362,8 @@ if __name__ == "__main__":
         g4_yolo_layer()
     if "g6" in which:
         g6_nms()
+    if "g9" in which:
+        g9_coco_export()
     if "g5" in which or "g7" in which:
         for model in MODELS:
             net = make_net(model)
