@@ -148,6 +148,7 @@ bool y3_conv_halo_ws_fits(const y3_op &op);
 extern int g_y3_use_halo;
 extern int g_y3_halo_pp;
 extern int g_y3_halo_bm;   // 0 = heuristic, 256 / 192 = forced
+extern int g_y3_halo_ws_variant;
 extern int g_y3_auto_mask; // per-layer kernel selection bits (api.hip)
 // true when the MFMA implicit-GEMM kernel can take this conv
 bool y3_conv_igemm_supported(const y3_op &op);

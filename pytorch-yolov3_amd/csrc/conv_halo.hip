@@ -977,18 +977,22 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     for (int it = 0; it < nit; ++it) {
       // before barrier B(it): weights(it+1) (and everything older) landed; with the 4-slot ring the loads of the
       // previous step (or, at it == 0, the prologue's last weight tile) may still fly
-      if (D == 2) { if (it == 0) wait_vmcnt<NBL>(); else wait_vmcnt_n<PER>(); }
-      else wait_vmcnt<0>();
+      // Per step the weight tile goes out FIRST and the two halo slices after it, so the counted wait can leave the
+      // youngest halo slices in flight (they are not needed before the next chunk, and a slice issued at step s is
+      // covered by the wait of step s+1): only the weights' landing sits on the barrier's critical path.
+      // (guaranteed landed at B(it): the weights issued D steps ago; halo slices issued D + 1 or more steps ago)
+      if (D == 2) { if (it == 0) wait_vmcnt<NBL>(); else if (it == 1) wait_vmcnt_n<PER>(); else wait_vmcnt_n<PER + HPS>(); }
+      else { if (it == 0) wait_vmcnt<0>(); else wait_vmcnt_n<HPS>(); }
       Y3_COARSE(3);
       __builtin_amdgcn_s_barrier();
       Y3_COARSE(4);
       const bool live = chunk + 1 < p.nchunks;
       const int p0 = 2 * tap < p.na ? 2 * tap : p.na - 1;
       const int p1 = 2 * tap + 1 < p.na ? 2 * tap + 1 : p.na - 1;
-      issue_halo_pass(chunk + 1, p0, live);
-      issue_halo_pass(chunk + 1, p1, live);
       const int itw = it + 1 + D < nit ? it + 1 + D : nit - 1;
       issue_weights(itw, ring);                       // ring == (it + 1 + D) % NSB: the slot of weights(it-1), free
+      issue_halo_pass(chunk + 1, p0, live);
+      issue_halo_pass(chunk + 1, p1, live);
       ring = ring + 1 == NSB ? 0 : ring + 1;
       if (++tap == 9) { tap = 0; ++chunk; }
       Y3_COARSE(5);
@@ -1191,6 +1195,281 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent form of the wave-specialised kernel: one workgroup per CU walks a list of tiles
+// (tile j of workgroup b = xcd_remap(b) + j * gridDim), and the operand streams never stop at a tile boundary:
+// the halo image of the next tile's first chunk is simply "the next chunk" of the double-buffered halo, the weight
+// ring runs D + 1 K-steps ahead straight into the next tile, so a tile's first MFMA does not wait for an 84 KiB
+// prologue (stamps on the one-tile kernel: ~5 k of ~41 k cycles per workgroup) nor for a workgroup dispatch.
+// The epilogue no longer parks the whole 256 x 128 fp32 tile over the operand buffers (they now hold the next tile's
+// prefetch): after one extra barrier per tile ("everyone is done reading the last chunk's halo") each consumer wave
+// parks 16 pixels x 64 channels at a time in a private 4 KiB slice of that -- now idle -- halo buffer and writes
+// them out as 16-byte NHWC chunks; no further workgroup barrier, and the loaders keep streaming meanwhile.
+template <typename T, int NSB>
+__global__ __launch_bounds__(768, 3) void conv_halo_wsp_kernel(HaloArgs p, int n_tiles_total) {
+  constexpr int BM = 256, BN = 128;
+  constexpr int WAVES_N = 2;
+  constexpr int NC = 512, NL = 256;
+  constexpr int ES = sizeof(T);
+  constexpr int BKE = 128 / ES;
+  constexpr int RPL = NL / 8;
+  constexpr int NBL = BN / RPL;
+  constexpr int HPS = 2;
+  constexpr int PER = NBL + HPS;
+  constexpr int B_BYTES = BN * 128;
+  constexpr int D = NSB - 2;
+  constexpr int MI = 4, NI = 4;
+  static_assert(NSB == 3 || NSB == 4, "weight ring has 3 or 4 slots");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *sB = smem;                                    // [NSB][BN][128]
+  char *sA = smem + NSB * B_BYTES;                    // [2][hr_pad][128]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= NC / 64;
+  const int nit = p.nchunks * 9;
+  const int grid = gridDim.x;
+  const int tile0 = y3_xcd_remap(blockIdx.x, grid);   // tiles of this workgroup: tile0, tile0 + grid, ...
+
+  if (loader) {
+    __builtin_amdgcn_s_setprio(3);
+    const int ltid = tid - NC;
+    const int lwave = wave - NC / 64;
+    const int slot = ltid & 7;
+    const int row0 = ltid >> 3;
+    const int kc = slot ^ (row0 & 7);
+    // halo slice `pass` of chunk `chunk` of the tile whose first halo pixel is q0, into halo buffer `buf`
+    auto issue_halo_pass = [&](long long q0, int chunk, int pass, int buf, bool live) {
+      const long long q = q0 + row0 + pass * RPL;
+      const bool ok = live && q >= 0 && q < p.M;
+      const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
+      char *dst = sA + buf * p.a_bytes + pass * (NL * 16) + lwave * 1024;
+      __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
+    };
+    auto issue_weights = [&](int n0, int it, int ring_slot) {
+      const int chunk = it / 9, tap = it - chunk * 9;
+      const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
+      const char *src0 = p.wgt + ((long long)(n0 + row0) * p.k_ld) * ES + kc * 16 + koff;
+      char *dst = sB + ring_slot * B_BYTES + lwave * 1024;
+#pragma unroll
+      for (int i = 0; i < NBL; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_void *)(src0 + (long long)i * RPL * p.k_ld * ES),
+                                         (lds_void *)(dst + i * (NL * 16)), 16, 0, 0);
+    };
+    auto tile_m0 = [&](int tile) { return (tile / p.n_tiles) * BM; };
+    auto tile_n0 = [&](int tile) { return (tile % p.n_tiles) * BN; };
+    // prologue of the first tile only
+    {
+      const long long q0 = (long long)tile_m0(tile0) - p.W - 1;
+      for (int pass = 0; pass < p.na; ++pass) issue_halo_pass(q0, 0, pass, 0, true);
+#pragma unroll
+      for (int j = 0; j <= D; ++j) issue_weights(tile_n0(tile0), j, j);
+    }
+    int ring = (D + 1) % NSB;                          // slot that receives the next weight tile
+    int gchunk = 0;                                    // chunks consumed so far (halo buffer = gchunk & 1)
+    int gstep = 0;                                     // K-steps issued so far, all tiles
+    for (int tile = tile0; tile < n_tiles_total; tile += grid) {
+      const int next_tile = tile + grid;
+      const bool has_next = next_tile < n_tiles_total;
+      const long long q0 = (long long)tile_m0(tile) - p.W - 1;
+      const long long q0n = (long long)tile_m0(has_next ? next_tile : tile) - p.W - 1;
+      const int n0 = tile_n0(tile), n0n = tile_n0(has_next ? next_tile : tile);
+      int tap = 0, chunk = 0;
+#pragma unroll 1
+      for (int it = 0; it < nit; ++it) {
+        // weights first, halo slices after: the counted wait leaves the youngest halo slices in flight (see above)
+        if (D == 2) { if (gstep == 0) wait_vmcnt<NBL>(); else if (gstep == 1) wait_vmcnt_n<PER>(); else wait_vmcnt_n<PER + HPS>(); }
+        else { if (gstep == 0) wait_vmcnt<0>(); else wait_vmcnt_n<HPS>(); }
+        ++gstep;
+        __builtin_amdgcn_s_barrier();
+        // weight tile D + 1 steps ahead: this tile's, the next tile's, or (nothing left) the last one again
+        const int itw = it + 1 + D;
+        if (itw < nit) issue_weights(n0, itw, ring);
+        else if (has_next) issue_weights(n0n, itw - nit, ring);
+        else issue_weights(n0, nit - 1, ring);
+        // two slices of the next chunk's halo: this tile's chunk + 1, or chunk 0 of the next tile
+        const bool in_tile = chunk + 1 < p.nchunks;
+        const bool live = in_tile || has_next;
+        const int p0 = 2 * tap < p.na ? 2 * tap : p.na - 1;
+        const int p1 = 2 * tap + 1 < p.na ? 2 * tap + 1 : p.na - 1;
+        const int nbuf = (gchunk + 1) & 1;
+        issue_halo_pass(in_tile ? q0 : q0n, in_tile ? chunk + 1 : 0, p0, nbuf, live);
+        issue_halo_pass(in_tile ? q0 : q0n, in_tile ? chunk + 1 : 0, p1, nbuf, live);
+        ring = ring + 1 == NSB ? 0 : ring + 1;
+        if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
+      }
+      __builtin_amdgcn_s_barrier();                    // E: consumers are done with the last chunk's halo buffer
+    }
+    wait_vmcnt<0>();
+    return;
+  }
+
+  // ---------------- consumer waves ----------------
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int a_lane_row = wm * 64 + fr;
+  const int b_lane_row = wn * 64 + fr;
+  const int b_off0 = b_lane_row * 128 + (((0 + fq) ^ (b_lane_row & 7)) << 4);
+  const int b_off1 = b_lane_row * 128 + (((4 + fq) ^ (b_lane_row & 7)) << 4);
+  const bool leaky = p.flags & Y3_F_LEAKY;
+  const bool has_res = p.flags & Y3_F_RESIDUAL;
+  int ring = 0, gchunk = 0;
+  for (int tile = tile0; tile < n_tiles_total; tile += grid) {
+    const int m0 = (tile / p.n_tiles) * BM;
+    const int n0 = (tile % p.n_tiles) * BN;
+    uint32_t tapmask[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const uint32_t m = (uint32_t)(m0 + wm * 64 + mi * 16 + fr);
+      uint32_t mask = 0u;
+      if (m < (uint32_t)p.M) {
+        const uint32_t img = (__umulhi(m, p.mul_hw) + m) >> p.sh_hw;
+        const uint32_t rem = m - img * (uint32_t)p.HW;
+        const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
+        const uint32_t ox = rem - oy * (uint32_t)p.W;
+        const uint32_t vx = (ox >= 1u ? 1u : 0u) | 2u | (ox + 1u < (uint32_t)p.W ? 4u : 0u);
+        mask = (oy >= 1u ? vx : 0u) | (vx << 3) | (oy + 1u < (uint32_t)p.H ? vx << 6 : 0u);
+      }
+      tapmask[mi] = mask;
+    }
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto read_frags = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], const char *aBuf, const char *bBuf, int a_shift, int g) {
+      const int r0 = a_lane_row + a_shift;
+      const char *ap = aBuf + r0 * 128 + (((g * 4 + fq) ^ (r0 & 7)) << 4);
+      const char *bp = bBuf + (g ? b_off1 : b_off0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const u32x4 *>(ap + mi * 2048);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
+    };
+    auto mma_all = [&](u32x4 (&xf)[MI], const u32x4 (&wf)[NI], int tap) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        if (!((tapmask[mi] >> tap) & 1u)) xf[mi] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) MmaH<T>::run(acc[mi][ni], wf[ni], xf[mi]);
+    };
+    auto interleave = [&]() {
+#pragma unroll
+      for (int i = 0; i < MI + NI; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 2 : 8, 0);
+      }
+    };
+    __builtin_amdgcn_s_barrier();                      // B(0) of this tile
+    u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
+    read_frags(xf0, wf0, sA + (gchunk & 1) * p.a_bytes, sB + ring * B_BYTES, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    int tap = 0;
+#pragma unroll 1
+    for (int it = 0; it < nit; ++it) {
+      if (it) __builtin_amdgcn_s_barrier();
+      const char *aBuf = sA + (gchunk & 1) * p.a_bytes;
+      const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(xf1, wf1, aBuf, sB + ring * B_BYTES, ky * p.W + kx, 1);
+      mma_all(xf0, wf0, tap);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      const int tap_n = tap == 8 ? 0 : tap + 1;
+      const int gchunk_n = tap == 8 ? gchunk + 1 : gchunk;
+      const int ring_n = ring + 1 == NSB ? 0 : ring + 1;
+      {
+        const int ky_n = (tap_n * 11) >> 5, kx_n = tap_n - ky_n * 3;
+        read_frags(xf0, wf0, sA + (gchunk_n & 1) * p.a_bytes, sB + ring_n * B_BYTES, ky_n * p.W + kx_n, 0);
+      }
+      mma_all(xf1, wf1, tap);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      tap = tap_n;
+      gchunk = gchunk_n;
+      ring = ring_n;
+    }
+    __builtin_amdgcn_s_barrier();                      // E: every consumer is done reading the last chunk's halo
+    // ---- epilogue, per wave: 16 pixels x 64 channels at a time through a private 4 KiB slice of that buffer ----
+    float *sC = reinterpret_cast<float *>(sA + ((gchunk + 1) & 1) * p.a_bytes) + wave * 1024;
+    const int oc = lane & 7;                           // 8-channel group of this lane's write-out items
+    const int co = n0 + wn * 64 + oc * 8;
+    const f32x4 sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
+    const f32x4 sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+    const f32x4 bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
+    const f32x4 bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      // residual first: its latency hides behind the LDS round trip
+      u32x4 resv[2];
+      f32x4 resf[2][2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int m = m0 + wm * 64 + mi * 16 + (lane >> 3) + r * 8;
+        if (has_res && m < p.M) {
+          if constexpr (sizeof(T) == 2) {
+            resv[r] = *reinterpret_cast<const u32x4 *>(p.res + ((long long)m * p.res_ld + co) * ES);
+          } else {
+            const float *rp = reinterpret_cast<const float *>(p.res) + (long long)m * p.res_ld + co;
+            resf[r][0] = *reinterpret_cast<const f32x4 *>(rp);
+            resf[r][1] = *reinterpret_cast<const f32x4 *>(rp + 4);
+          }
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)                  // pixel fr, channels ni*16 + fq*4 .. +3; 16-B chunks XOR-swizzled
+        *reinterpret_cast<f32x4 *>(sC + fr * 64 + (((ni * 4 + fq) ^ fr) << 2)) = acc[mi][ni];
+      __builtin_amdgcn_s_waitcnt(0xC07F);              // (same wave reads below: LDS ops of a wave complete in order)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int pl = (lane >> 3) + r * 8;            // pixel inside the 16-row group
+        const int m = m0 + wm * 64 + mi * 16 + pl;
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * 64 + (((2 * oc) ^ pl) << 2));
+        const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * 64 + (((2 * oc + 1) ^ pl) << 2));
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] = lo[q] * sc_lo[q] + bi_lo[q];
+          v[4 + q] = hi[q] * sc_hi[q] + bi_hi[q];
+        }
+        if (leaky) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = v[q] > 0.f ? v[q] : Y3_LEAKY_SLOPE * v[q];
+        }
+        if (m < p.M) {
+          if (has_res) {
+            if constexpr (sizeof(T) == 2) {
+              const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[r]);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] += (float)rv[q];
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { v[q] += resf[r][0][q]; v[4 + q] += resf[r][1][q]; }
+            }
+          }
+          T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
+          if constexpr (sizeof(T) == 2) {
+            bf16x8 ov;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ov[q] = (bf16_t)v[q];
+            *reinterpret_cast<bf16x8 *>(op) = ov;
+          } else {
+            *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);              // reads done before the next group overwrites the slice
+    }
+  }
+}
+
 struct HaloGeom { int na, hr_pad, a_bytes, nsb; size_t lds; };
 
 // geometry / LDS budget of one tile configuration; nsb == 0: does not fit
@@ -1285,7 +1564,7 @@ int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
   int nsb = 0;
   size_t lds = 0;
   for (int c = 4; c >= 3; --c) {
-    if (a.na > (c == 4 ? 14 : 16)) continue;
+    if (a.na > (c == 4 ? 12 : 14)) continue;   // all real halo slices out by tap 5 (4 slots) / 6 (3 slots)
     lds = (size_t)c * 128 * 128 + (size_t)2 * a.a_bytes;
     if (lds < (size_t)256 * 128 * 4) lds = (size_t)256 * 128 * 4;
     if (lds <= 160 * 1024) { nsb = c; break; }
@@ -1302,6 +1581,41 @@ int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
   const dim3 grid(y3_ceil_div(a.M, 256) * a.n_tiles);
   if (nsb == 4) hipLaunchKernelGGL((conv_halo_ws_kernel<T, 4>), grid, dim3(768), lds, s, a);
   else hipLaunchKernelGGL((conv_halo_ws_kernel<T, 3>), grid, dim3(768), lds, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+template <typename T>
+int launch_halo_wsp(const HaloArgs &a0, hipStream_t s) {
+  HaloArgs a = a0;
+  const int hr = 256 + 2 * a.W + 2;
+  a.na = y3_ceil_div(hr, 32);
+  a.hr_pad = a.na * 32;
+  a.a_bytes = a.hr_pad * 128;
+  int nsb = 0;
+  size_t lds = 0;
+  for (int c = 4; c >= 3; --c) {
+    if (a.na > (c == 4 ? 12 : 14)) continue;   // all real halo slices out by tap 5 (4 slots) / 6 (3 slots)
+    lds = (size_t)c * 128 * 128 + (size_t)2 * a.a_bytes;
+    if (lds <= 160 * 1024) { nsb = c; break; }
+  }
+  Y3_REQUIRE(nsb != 0 && a.a_bytes >= 32 * 1024, "persistent halo kernel: row width %d does not fit", a.W);
+  static bool attr_set = false;
+  static int n_cu = 0;
+  if (!attr_set) {
+    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_wsp_kernel<T, 3>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_wsp_kernel<T, 4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int dev = 0;
+    Y3_HIP_CHECK(hipGetDevice(&dev));
+    Y3_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    attr_set = true;
+  }
+  const int tiles = y3_ceil_div(a.M, 256) * a.n_tiles;
+  const int grid = tiles < n_cu ? tiles : n_cu;
+  if (nsb == 4) hipLaunchKernelGGL((conv_halo_wsp_kernel<T, 4>), dim3(grid), dim3(768), lds, s, a, tiles);
+  else hipLaunchKernelGGL((conv_halo_wsp_kernel<T, 3>), dim3(grid), dim3(768), lds, s, a, tiles);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -1328,7 +1642,7 @@ bool y3_conv_halo_eligible(const y3_op &op) {
 bool y3_conv_halo_ws_fits(const y3_op &op) {
   if (!y3_conv_halo_eligible(op)) return false;
   const int na = y3_ceil_div(256 + 2 * op.in_w + 2, 32);
-  return na <= 16 && (size_t)3 * 128 * 128 + (size_t)2 * na * 32 * 128 <= 160 * 1024;
+  return na <= 14 && (size_t)3 * 128 * 128 + (size_t)2 * na * 32 * 128 <= 160 * 1024;
 }
 
 int y3_conv_halo_bm(const y3_op &op) {
@@ -1367,6 +1681,8 @@ int y3_launch_conv_halo(const y3_op &op, int bm, const void *d_in, const void *d
   if (use32) *kernel_name = bf ? "conv_halo32_bf16_256x128" : "conv_halo32_f32_256x128";
   const bool use_ws = bm == 256 && pp == 3;
   if (use_ws) *kernel_name = bf ? "conv_halo_ws_bf16_256x128" : "conv_halo_ws_f32_256x128";
+  const bool use_wsp = bm == 256 && pp == 4;
+  if (use_wsp) *kernel_name = bf ? "conv_halo_wsp_bf16_256x128" : "conv_halo_wsp_f32_256x128";
   if (dry_run) return Y3_OK;
   HaloArgs a;
   a.in = static_cast<const char *>(d_in);
@@ -1391,6 +1707,7 @@ int y3_launch_conv_halo(const y3_op &op, int bm, const void *d_in, const void *d
   Y3_REQUIRE(g.nsb != 0, "conv block %d: halo tile does not fit in LDS", op.block_idx);
   if (use32) return bf ? launch_halo32<bf16_t>(a, s) : launch_halo32<float>(a, s);
   if (use_ws) return bf ? launch_halo_ws<bf16_t>(a, s) : launch_halo_ws<float>(a, s);
+  if (use_wsp) return bf ? launch_halo_wsp<bf16_t>(a, s) : launch_halo_wsp<float>(a, s);
   if (bm == 256 && pp) return bf ? launch_halo_pp<bf16_t>(a, s) : launch_halo_pp<float>(a, s);
   if (bf) {
     if (bm == 256) return g.nsb == 4 ? launch_halo<bf16_t, 256, 4>(a, g, s) : launch_halo<bf16_t, 256, 3>(a, g, s);

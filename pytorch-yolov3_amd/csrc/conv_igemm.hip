@@ -976,6 +976,7 @@ extern "C" int y3_set_tuning(const char *key, int value) {
   if (!strcmp(key, "igemm_rb")) { g_igemm_rb = value; return Y3_OK; }
   if (!strcmp(key, "igemm_ns")) { g_igemm_ns = value; return Y3_OK; }
   if (!strcmp(key, "auto_mask")) { g_y3_auto_mask = value; return Y3_OK; }
+  if (!strcmp(key, "halo_ws_variant")) { g_y3_halo_ws_variant = value; return Y3_OK; }
   if (!strcmp(key, "conv_halo")) { g_y3_use_halo = value; return Y3_OK; }
   if (!strcmp(key, "halo_pp")) { g_y3_halo_pp = value; return Y3_OK; }
   if (!strcmp(key, "halo_bm")) { g_y3_halo_bm = value; return Y3_OK; }

@@ -109,7 +109,8 @@ def test_tuning_knobs_do_not_change_results():
     try:
         for knobs in ({"auto_mask": 0}, {"auto_mask": 63}, {"igemm_version": 1}, {"igemm_version": 3}, {"igemm_staging": 1}, {"igemm_rb": 64}, {"conv_halo": 1, "halo_pp": 0},
                       {"conv_halo": 1, "halo_pp": 1, "halo_bm": 256}, {"conv_halo": 1, "halo_pp": 2, "halo_bm": 256},
-                      {"conv_halo": 1, "halo_pp": 3, "halo_bm": 256}):
+                      {"conv_halo": 1, "halo_pp": 3, "halo_bm": 256}, {"conv_halo": 1, "halo_pp": 4, "halo_bm": 256},
+                      {"halo_ws_variant": 4}):
             for k, v in knobs.items():
                 _hip.check(lib.y3_set_tuning(k.encode(), v))
             out = _net("mini").forward(x)
@@ -118,10 +119,10 @@ def test_tuning_knobs_do_not_change_results():
             np.testing.assert_allclose(out["bbox_xywh"].cpu().numpy(), ref["bbox_xywh"].cpu().numpy(), rtol=1e-4,
                                        atol=1e-5, err_msg=str(knobs))
             for k in knobs:
-                _hip.check(lib.y3_set_tuning(k.encode(), {"igemm_version": 2, "igemm_rb": 128, "auto_mask": 21}.get(k, 0)))
+                _hip.check(lib.y3_set_tuning(k.encode(), {"igemm_version": 2, "igemm_rb": 128, "auto_mask": 21, "halo_ws_variant": 3}.get(k, 0)))
     finally:
         for k, v in (("igemm_version", 2), ("igemm_staging", 0), ("igemm_rb", 128), ("conv_halo", 0), ("halo_pp", 1),
-                     ("halo_bm", 0), ("igemm_bm", 0), ("auto_mask", 21)):
+                     ("halo_bm", 0), ("igemm_bm", 0), ("auto_mask", 21), ("halo_ws_variant", 3)):
             lib.y3_set_tuning(k.encode(), v)
     assert lib.y3_set_tuning(b"no_such_knob", 1) != 0
 
@@ -282,7 +283,7 @@ def test_halo_kernels_match_igemm_on_yolov3_fp32():
     g = np.load(os.path.join(GOLDEN, "forward_yolov3.npz"))
     frames = np.stack([resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), 608, 608), synth_frames(5, 1, 608, 608)[0]])
     try:
-        for pp in (0, 1, 2, 3):
+        for pp in (0, 1, 2, 3, 4):
             _hip.check(lib.y3_set_tuning(b"conv_halo", 1))
             _hip.check(lib.y3_set_tuning(b"halo_bm", 256 if pp >= 2 else 0))
             _hip.check(lib.y3_set_tuning(b"halo_pp", pp))
