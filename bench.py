@@ -34,8 +34,8 @@ MODEL_FLOPS_PER_FRAME = {("yolov3", 608): 140.692e9, ("yolov3-tiny", 416): 5.565
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="yolov3")
     ap.add_argument("--dim", type=int, default=608)
     ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
@@ -240,6 +240,7 @@ def main():
                            for k, v in report["by_kernel"].items()}
         print(json.dumps(line), flush=True)
     if distributed:
+        dist.barrier()          # ranks > 0 wait for rank 0's profiling passes before the group goes away
         dist.destroy_process_group()
 
 

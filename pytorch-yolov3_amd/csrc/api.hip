@@ -17,7 +17,8 @@ thread_local char g_err[512] = "";
 // per-layer kernel choice for the MFMA convs (tools/conv_bench.py tables in profiles/): bit 0: wave-specialised halo
 // kernel for 3x3 s1 layers with rows wider than 64; bit 1: wave-specialised igemm (3 stages) for 3x3 layers with rows of
 // 33..64; bit 2: halo kernel for rows <= 32; bit 3: wave-specialised igemm for 1x1 layers with Cin >= 1024;
-// bit 4: halo kernel for rows of 33..64 instead; bit 5: wave-specialised igemm for rows <= 32 instead
+// bit 4: halo kernel for rows of 33..64 instead; bit 5: wave-specialised igemm for rows <= 32 instead;
+// bit 6: wave-specialised igemm with 64-pixel tiles (3 stages, two workgroups per CU) for bf16 1x1 layers with Cin >= 256
 int g_y3_auto_mask = 21;  // measured best end to end (profiles/r01_ab_kernel_selection.txt): halo kernel at every row width
 int g_y3_halo_ws_variant = 3;   // 3 = one tile per workgroup, 4 = persistent tile loop (conv_halo.hip)
 int g_y3_use_halo = 0;   // experimental halo-reuse 3x3 kernels (conv_halo.hip); off: the implicit GEMM measured as fast
@@ -77,6 +78,9 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
             else if (k3 && w > 32) { want_halo = am & 16; want_ws = am & 2; }
             else if (k3) { want_halo = am & 4; want_ws = am & 32; }
             else if (op.ksize == 1 && op.in_c >= 1024 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32)) want_ws = am & 8;
+            if ((am & 64) && op.ksize == 1 && op.in_c >= 256 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32) &&
+                op.dtype == Y3_BF16)
+              return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3, 64);
             if (want_halo && halo_ok) return y3_launch_conv_halo(op, 256, in, d_zero, s, name, dry_run, g_y3_halo_ws_variant);
             if (want_ws) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
           }

@@ -118,9 +118,10 @@ __device__ __forceinline__ unsigned long long y3_now() {
 #endif
 
 // launchers implemented in the .hip files; each fills *kernel_name with a static string
-// force_version / force_ns: 0 = the "igemm_version" / "igemm_ns" knobs
+// force_version / force_ns / force_bm: 0 = the "igemm_version" / "igemm_ns" / "igemm_bm" knobs
 int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
-                         const char **kernel_name, bool dry_run, int force_version = 0, int force_ns = 0);
+                         const char **kernel_name, bool dry_run, int force_version = 0, int force_ns = 0,
+                         int force_bm = 0);
 int y3_launch_conv_small(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
                          bool dry_run);
 int y3_launch_conv_direct(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,

@@ -599,7 +599,8 @@ __device__ __forceinline__ void igemm_wait_vmcnt() {
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, int NS>
-__global__ __launch_bounds__(128 * WAVES_M * WAVES_N, NS == 2 ? (WAVES_M * WAVES_N) : (WAVES_M * WAVES_N) / 2)
+__global__ __launch_bounds__(128 * WAVES_M * WAVES_N,
+                             NS * (BM + BN) * 128 <= 80 * 1024 ? (WAVES_M * WAVES_N) : (WAVES_M * WAVES_N) / 2)
 void conv_igemm3_kernel(IgemmArgs p) {
   constexpr int NC = 64 * WAVES_M * WAVES_N;         // consumer threads (== loader threads)
   constexpr int NT = 2 * NC;
@@ -985,15 +986,16 @@ extern "C" int y3_set_tuning(const char *key, int value) {
 }
 
 int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
-                         const char **kernel_name, bool dry_run, int force_version, int force_ns) {
+                         const char **kernel_name, bool dry_run, int force_version, int force_ns, int force_bm) {
   const int version = force_version ? force_version : g_igemm_version;
   const int ns = force_ns ? force_ns : g_igemm_ns;
+  const int bm_knob = force_bm ? force_bm : g_igemm_bm;
   Y3_REQUIRE(y3_conv_igemm_supported(op), "conv block %d: shape not supported by the igemm kernel",
              op.block_idx);
   const int es = y3_elem_size(op.dtype);
   // K-tile row: 128 bytes, or 64 bytes (tuning knob "igemm_rb": 3 workgroups per CU) for the 128-wide tile
   const bool rb64 = g_igemm_rb == 64 && version == 2 && op.out_c > 64 && !(op.flags & Y3_F_OUT_F32) &&
-                    g_igemm_bm != 256;
+                    bm_knob != 256;
   const int bke = (rb64 ? 64 : 128) / es;
   IgemmArgs a;
   a.in = static_cast<const char *>(d_in);
@@ -1045,13 +1047,18 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
     if (dry_run) return Y3_OK;
     return bf ? launch_cfg<bf16_t, 128, 32, 4, 1>(a, generic, s) : launch_cfg<float, 128, 32, 4, 1>(a, generic, s);
   }
+  if (version == 3 && bn == 128 && bm_knob == 64 && bf && !(op.flags & Y3_F_OUT_F32)) {
+    *kernel_name = "conv_igemm3_bf16_64x128";          // 64-pixel tiles: twice the workgroups, two per CU at 3 stages
+    if (dry_run) return Y3_OK;
+    return launch_cfg3<bf16_t, 64, 128, 1, 4>(a, kmode, ns, s);
+  }
   if (version == 3 && bn == 128 && !(op.flags & Y3_F_OUT_F32)) {
     *kernel_name = bf ? "conv_igemm3_bf16_128x128" : "conv_igemm3_f32_128x128";
     if (dry_run) return Y3_OK;
     return bf ? launch_cfg3<bf16_t, 128, 128, 2, 2>(a, kmode, ns, s) : launch_cfg3<float, 128, 128, 2, 2>(a, kmode, ns, s);
   }
   if (bn == 128) {
-    if (bf && g_igemm_bm == 256) {
+    if (bf && bm_knob == 256) {
       *kernel_name = "conv_igemm2_bf16_256x128";
       if (dry_run) return Y3_OK;
       return launch_cfg2<bf16_t, 256, 128, 4, 2>(a, kmode, s);

@@ -42,8 +42,9 @@ LAYERS = [
 
 VARIANTS = [
     ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128, "igemm_ns": 2, "auto_mask": 0}),
-    ("halo_ws", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 3, "halo_bm": 256, "igemm_staging": 0, "igemm_rb": 128, "igemm_ns": 2, "auto_mask": 0}),
-    ("halo_wsp", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 1, "halo_pp": 4, "halo_bm": 256, "igemm_staging": 0, "igemm_rb": 128, "igemm_ns": 2, "auto_mask": 0}),
+    ("v3_64_ns3", {"igemm_version": 3, "igemm_bm": 64, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128, "igemm_ns": 3, "auto_mask": 0}),
+    ("v3_64_ns2", {"igemm_version": 3, "igemm_bm": 64, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128, "igemm_ns": 2, "auto_mask": 0}),
+    ("v3_64_ns4", {"igemm_version": 3, "igemm_bm": 64, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128, "igemm_ns": 4, "auto_mask": 0}),
 ]
 
 
