@@ -126,10 +126,14 @@ double y3_plan_op_bytes(const y3_plan *plan, int op_index);
  * out accordingly.                                                                              */
 int y3_conv_path(const y3_op *op);
 
-/* process-wide tuning knob for A/B measurements: "igemm_version" (1 register-staged, 2 LDS-DMA
- * double-buffered [default]), "igemm_bm" (0 heuristic, 256 = 8-wave 256x128 tile), "conv_halo" (1 [default] =
- * halo-reuse kernel for 3x3 stride-1 convs, 0 = implicit GEMM everywhere).  Results do not
- * depend on the knobs beyond floating-point summation order.                                   */
+/* process-wide tuning knobs for A/B measurements (tools/conv_bench.py, bench.py --tuning):
+ *   "auto_mask"       per-layer kernel choice bits, default 21: halo-reuse kernel for every 3x3 stride-1 conv it
+ *                     fits (bit 0: rows > 64 px, bit 4: 33..64, bit 2: <= 32); 0 = implicit GEMM everywhere;
+ *                     bits 1 / 5 / 3 / 6 route layers to the wave-specialised implicit GEMM instead (api.hip)
+ *   "halo_persistent" 0 [default] one tile per workgroup, 1 persistent tile loop
+ *   "igemm_version"   1 register-staged, 2 LDS-DMA double-buffered [default], 3 wave-specialised
+ *   "igemm_ns"        LDS stages of version 3 (2..4);  "igemm_bm" 64 = 64-pixel tiles for version 3 (bf16)
+ * Results do not depend on the knobs beyond floating-point summation order.                          */
 int y3_set_tuning(const char *key, int value);
 
 /* single op (unit tests): same dispatch as inside a plan */

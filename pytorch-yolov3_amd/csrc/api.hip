@@ -20,8 +20,7 @@ thread_local char g_err[512] = "";
 // bit 4: halo kernel for rows of 33..64 instead; bit 5: wave-specialised igemm for rows <= 32 instead;
 // bit 6: wave-specialised igemm with 64-pixel tiles (3 stages, two workgroups per CU) for bf16 1x1 layers with Cin >= 256
 int g_y3_auto_mask = 21;  // measured best end to end (profiles/r01_ab_kernel_selection.txt): halo kernel at every row width
-int g_y3_halo_ws_variant = 3;   // 3 = one tile per workgroup, 4 = persistent tile loop (conv_halo.hip)
-int g_y3_use_halo = 0;   // experimental halo-reuse 3x3 kernels (conv_halo.hip); off: the implicit GEMM measured as fast
+int g_y3_halo_persistent = 0;   // halo kernel: 0 = one tile per workgroup, 1 = persistent tile loop (conv_halo.hip)   // experimental halo-reuse 3x3 kernels (conv_halo.hip); off: the implicit GEMM measured as fast
 
 
 void y3_set_error(const char *fmt, ...) {
@@ -67,9 +66,7 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
         Y3_REQUIRE(op.d_weight && op.d_scale && op.d_bias, "conv block %d: missing parameters", op.block_idx);
       switch (conv_path(op)) {
         case 0: {
-          const int bm = g_y3_use_halo ? y3_conv_halo_bm(op) : 0;
-          if (bm) return y3_launch_conv_halo(op, bm, in, d_zero, s, name, dry_run);
-          if (g_y3_auto_mask && !g_y3_use_halo) {
+          if (g_y3_auto_mask) {
             const int am = g_y3_auto_mask, w = op.in_w;
             const bool k3 = op.ksize == 3 && op.stride == 1 && op.in_c >= 128 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32);
             const bool halo_ok = k3 && y3_conv_halo_ws_fits(op);
@@ -81,7 +78,7 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
             if ((am & 64) && op.ksize == 1 && op.in_c >= 256 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32) &&
                 op.dtype == Y3_BF16)
               return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3, 64);
-            if (want_halo && halo_ok) return y3_launch_conv_halo(op, 256, in, d_zero, s, name, dry_run, g_y3_halo_ws_variant);
+            if (want_halo && halo_ok) return y3_launch_conv_halo(op, in, d_zero, s, name, dry_run, g_y3_halo_persistent != 0);
             if (want_ws) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
           }
           return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run);

@@ -139,17 +139,12 @@ int y3_launch_copy(const y3_op &op, const void *d_in, hipStream_t s, const char 
                    bool dry_run);
 int y3_launch_yolo(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
                    bool dry_run);
-// halo-reuse 3x3 kernel: pixel-tile height it would use for this conv (256 / 192), 0 = not applicable
-int y3_conv_halo_bm(const y3_op &op);
-// variant: -1 = the "halo_pp" knob, else 0 lockstep / 1 ping-pong / 2 32-channel chunks / 3 wave-specialised
-int y3_launch_conv_halo(const y3_op &op, int bm, const void *d_in, const void *d_zero, hipStream_t s,
-                        const char **kernel_name, bool dry_run, int variant = -1);
+// halo-reuse 3x3 kernel (conv_halo.hip): whether it can take this conv, and its launcher
 bool y3_conv_halo_ws_fits(const y3_op &op);
+int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
+                        const char **kernel_name, bool dry_run, bool persistent);
 // process-wide tuning knobs (y3_set_tuning)
-extern int g_y3_use_halo;
-extern int g_y3_halo_pp;
-extern int g_y3_halo_bm;   // 0 = heuristic, 256 / 192 = forced
-extern int g_y3_halo_ws_variant;
+extern int g_y3_halo_persistent;
 extern int g_y3_auto_mask; // per-layer kernel selection bits (api.hip)
 // true when the MFMA implicit-GEMM kernel can take this conv
 bool y3_conv_igemm_supported(const y3_op &op);

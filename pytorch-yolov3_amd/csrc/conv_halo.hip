@@ -2,24 +2,26 @@
 //
 // Same contract as conv_igemm.hip (conv -> scale/bias -> LeakyReLU -> +residual; replaces
 // /root/reference/yolov3/darknet.py:244-257 and the shortcut at :376-379), specialised for the
-// layers that carry ~75 % of Darknet-53's FLOPs: 3x3, stride 1, pad 1, Cin a multiple of the
-// K-tile (64 bf16 / 32 fp32 channels = 128 bytes).
+// layers that carry 61 % of Darknet-53's FLOPs: 3x3, stride 1, pad 1, Cin >= 2 K-tiles
+// (K-tile = 64 bf16 / 32 fp32 channels = 128 bytes), Cout a multiple of 128.
 //
 // Why: the generic implicit GEMM re-reads every input pixel once per filter tap (9x) and every
-// weight tile once per 128-pixel tile; measured, its K loop is bound by global->LDS latency and
-// traffic (~10 TB/s of LDS-DMA at 25-30 % MFMA busy), not by the matrix cores.  Here a workgroup
-// owns BM consecutive output pixels in raster order (b, y, x flattened) and stages, per 128-byte
-// channel chunk, the BM + 2W + 2 input pixels that ALL nine taps of those outputs touch -- once.
-// Tap (ky,kx) of output pixel p is halo row  p + ky*W + kx, so the nine K-steps of a chunk read the
-// same LDS image at nine row offsets.  Row-wrap / image-border taps (the zero padding) are cleared
-// in registers with a per-pixel 9-bit mask after the fragment read.  Only the weight tile (BN x 128
-// B) changes per K-step; it streams through a 3-slot LDS ring two steps ahead.  Bytes moved per FLOP
-// drop ~3x versus the 128x128 implicit GEMM.
+// weight tile once per 128-pixel tile; measured, its K loop is bound by the LDS-DMA ingest path
+// (1 KiB per ~16-22 cycles per CU whatever the number of issuing waves: a 128x128x64 tile needs as
+// many cycles of it as of MFMA).  Here a workgroup owns 256 consecutive output pixels in raster
+// order (b, y, x flattened) x 128 output channels and stages, per 128-byte channel chunk, the
+// 256 + 2W + 2 input pixels that ALL nine taps of those outputs touch -- once.  Tap (ky,kx) of
+// output pixel p is halo row  p + ky*W + kx, so the nine K-steps of a chunk read the same LDS
+// image at nine row offsets.  Row-wrap / image-border taps (the zero padding) are cleared in
+// registers with a per-pixel 9-bit mask after the fragment read.  Only the weight tile (128 rows x
+// 128 B) changes per K-step; it streams through a 3- or 4-slot LDS ring.  Bytes through the LDS-DMA
+// path per FLOP drop ~3x versus the 128x128 implicit GEMM.
 //
-// Pipeline (all LDS-DMA, global_load_lds_dwordx4, counted vmcnt, one barrier per K-step):
-//   step it = chunk*9 + tap:  wait(all but the loads issued in step it-1) ; barrier ;
-//                             issue weights(it+2) [+ one slice of the next chunk's halo] ; MFMAs(it)
-// Workgroup: (BM/64) x 2 waves, wave tile 64 x 64 (4x4 MFMA 16x16 accumulators), BN = 128.
+// Two kernels: conv_halo_ws_kernel (one tile per workgroup; default) and conv_halo_wsp_kernel
+// (persistent tile loop; faster alone, slower with several batches in flight).  Earlier schedules
+// -- every wave loading and computing in lock step, ping-pong wave groups, 32-channel chunks with a
+// deeper ring -- measured 5-25 % slower (profiles/r01_convbench_v2_vs_halo.txt,
+// profiles/r01_convbench_variants.txt) and were removed.
 #include "common.h"
 
 namespace {
@@ -80,815 +82,6 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt_n() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-
-template <typename T, int BM, int NSB>
-__global__ __launch_bounds__(BM * 2) void conv_halo3x3_kernel(HaloArgs p) {
-  constexpr int BN = 128;
-  constexpr int WAVES_M = BM / 64, WAVES_N = 2;
-  constexpr int NT = 64 * WAVES_M * WAVES_N;
-  constexpr int ES = sizeof(T);
-  constexpr int BKE = 128 / ES;
-  constexpr int RPP = NT / 8;                         // rows filled per loader pass
-  constexpr int NB = (BN + RPP - 1) / RPP;            // weight-tile passes (glds per thread per K-step)
-  constexpr int B_ROWS = NB * RPP;
-  constexpr int B_BYTES = B_ROWS * 128;
-  constexpr int D = NSB - 2;                          // K-steps of load latency the ring tolerates
-  constexpr int MI = 4, NI = 4;
-  static_assert(NSB == 3 || NSB == 4, "weight ring has 3 or 4 slots");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *sB = smem;                                    // [NSB][B_ROWS][128]
-  char *sA = smem + NSB * B_BYTES;                    // [2][hr_pad][128]
-
-  Y3_STAMP_DECL
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int fr = lane & 15, fq = lane >> 4;
-
-  const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / p.n_tiles) * BM;
-  const int n0 = (tile % p.n_tiles) * BN;
-
-  // ---- loader geometry -----------------------------------------------------------------------
-  const int slot = tid & 7;
-  const int row0 = tid >> 3;
-  const int kc = slot ^ (row0 & 7);                   // RPP % 8 == 0, so (row & 7) == (row0 & 7)
-  const long long q0 = (long long)m0 - p.W - 1;       // flattened input pixel of halo row 0
-
-  auto issue_halo_pass = [&](int chunk, int pass, bool live = true) {
-    const int row = row0 + pass * RPP;
-    const long long q = q0 + row;
-    const bool ok = live && q >= 0 && q < p.M;
-    const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
-    char *dst = sA + (chunk & 1) * p.a_bytes + pass * (NT * 16) + wave * 1024;
-    __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
-  };
-  const char *b_src[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int r = row0 + i * RPP;
-    b_src[i] = r < BN ? p.wgt + ((long long)(n0 + r) * p.k_ld) * ES + kc * 16 : nullptr;
-  }
-  auto issue_weights = [&](int it, int slot_it = -1) {  // it = chunk*9 + tap; K offset = (tap*Cin + chunk*BKE) elements
-    const int chunk = it / 9, tap = it - chunk * 9;
-    const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
-    char *dst = sB + ((slot_it < 0 ? it : slot_it) % NSB) * B_BYTES + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const char *src = b_src[i] ? b_src[i] + koff : p.zero;
-      __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(dst + i * (NT * 16)), 16, 0, 0);
-    }
-  };
-
-  // ---- prologue: get the first operands moving before anything else ------------------------------
-  const int nit = p.nchunks * 9;
-  for (int pass = 0; pass < p.na; ++pass) issue_halo_pass(0, pass);
-#pragma unroll
-  for (int j = 0; j <= D; ++j)
-    if (j < nit) issue_weights(j);
-
-  // per-lane tap validity of the 4 pixels this lane feeds to the MFMAs (closed form, no loops)
-  uint32_t tapmask[MI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const uint32_t m = (uint32_t)(m0 + wm * 64 + mi * 16 + fr);
-    uint32_t mask = 0u;
-    if (m < (uint32_t)p.M) {
-      const uint32_t img = (__umulhi(m, p.mul_hw) + m) >> p.sh_hw;
-      const uint32_t rem = m - img * (uint32_t)p.HW;
-      const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
-      const uint32_t ox = rem - oy * (uint32_t)p.W;
-      const uint32_t vx = (ox >= 1u ? 1u : 0u) | 2u | (ox + 1u < (uint32_t)p.W ? 4u : 0u);
-      mask = (oy >= 1u ? vx : 0u) | (vx << 3) | (oy + 1u < (uint32_t)p.H ? vx << 6 : 0u);
-    }
-    tapmask[mi] = mask;
-  }
-  const int oc_mine = tid & 15;  // this thread's 8-channel group in the write-out phase
-
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment addressing: lane (fr, fq) reads 16-byte chunk (g*4 + fq) of row (base + fr [+ shift]);
-  // mi / ni steps are +16 rows = +2048 bytes and do not change (row & 7), so they are immediates
-  const int a_lane_row = wm * 64 + fr;
-  const int b_lane_row = wn * 64 + fr;
-  const int b_off0 = b_lane_row * 128 + (((0 + fq) ^ (b_lane_row & 7)) << 4);
-  const int b_off1 = b_lane_row * 128 + (((4 + fq) ^ (b_lane_row & 7)) << 4);
-
-  auto read_frags = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], const char *aBuf, const char *bBuf, int a_shift, int g) {
-    const int r0 = a_lane_row + a_shift;
-    const char *ap = aBuf + r0 * 128 + (((g * 4 + fq) ^ (r0 & 7)) << 4);
-    const char *bp = bBuf + (g ? b_off1 : b_off0);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const u32x4 *>(ap + mi * 2048);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
-  };
-  auto mma_all = [&](u32x4 (&xf)[MI], const u32x4 (&wf)[NI], int tap) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-      if (!((tapmask[mi] >> tap) & 1u)) xf[mi] = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) MmaH<T>::run(acc[mi][ni], wf[ni], xf[mi]);
-  };
-  // scheduling recipe for one half-step: the 8 fragment reads of the OTHER register set ride in the gaps of
-  // this set's 16 MFMAs (bf16: 2 MFMAs per read; fp32: 8), instead of being issued as one LDS burst up front
-  auto interleave = [&]() {
-#pragma unroll
-    for (int i = 0; i < MI + NI; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          // one DS read
-      __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 2 : 8, 0);     // its share of the MFMAs
-    }
-  };
-
-  // ---- first operands: halo(0), weights(0), weights(1) must have landed ----------------------------
-  Y3_COARSE(0);
-  if (D == 2 && nit > 2) wait_vmcnt<NB>(); else wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  Y3_COARSE(1);
-  u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
-  read_frags(xf0, wf0, sA, sB, 0, 0);
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-
-  // LDS-DMA instructions this thread issued in the previous step (step "-1" = the prologue, whose
-  // only possibly unfinished loads are weights(2) of the 4-slot ring)
-  int issued_prev = (D == 2 && nit > 2) ? NB : 0;
-  int tap = 0, chunk = 0;
-#pragma unroll 1
-  for (int it = 0; it < nit; ++it) {
-    {
-      // weights(it+1) -- and the next chunk's halo when the next step starts it -- must have landed
-      // before this barrier; with the 4-slot ring only the loads of step it-1 may still be in flight.
-      // (Step 0 repeats the prologue's barrier on purpose: every trip then enters with the same
-      // "fragment set 0 complete" state and hipcc emits counted LDS waits inside the loop.)
-      if (D == 2) {
-        if (issued_prev == NB + 1) wait_vmcnt<NB + 1>();
-        else if (issued_prev == NB) wait_vmcnt<NB>();
-        else if (issued_prev == 1) wait_vmcnt<1>();
-        else wait_vmcnt<0>();
-      } else {
-        wait_vmcnt<0>();
-      }
-      __builtin_amdgcn_s_barrier();
-    }
-    Y3_FINE(0);   // vmcnt wait + barrier
-    // This step's LDS-DMA (halo slice first, weights second: only later steps' loads are younger than these
-    // weights) is issued INSIDE half-step A's scheduling region, so the up-to-NB+1 DMA instructions -- ~150 cycles
-    // each when all eight waves issue at once -- ride in MFMA gaps instead of forming a DMA-only phase.
-    const char *aBuf = sA + (chunk & 1) * p.a_bytes;
-    const int ky = (tap * 11) >> 5, kx = tap - ky * 3;         // tap / 3, tap % 3 for tap in 0..8
-    __builtin_amdgcn_sched_barrier(0);
-    // Branch-free on purpose (one basic block = one scheduling region): when there is nothing left to fetch the
-    // same number of DMA instructions is still issued -- a repeated halo slice / the last weight tile again --
-    // into LDS that nobody reads any more (the next-chunk halo buffer, the ring slot that is free by invariant).
-    // The DMA calls sit BETWEEN the fragment reads in program order: LDS-DMA and ds_read both touch LDS, so the
-    // scheduler keeps their relative order, and this is what lets the group barriers below spread them.
-    {
-      const int r0 = a_lane_row + ky * p.W + kx;
-      const char *ap = aBuf + r0 * 128 + (((4 + fq) ^ (r0 & 7)) << 4);
-      const char *bp = sB + (it % NSB) * B_BYTES + b_off1;
-      const bool live = chunk + 1 < p.nchunks;
-      const int itw = it + 1 + D < nit ? it + 1 + D : nit - 1;
-      xf1[0] = *reinterpret_cast<const u32x4 *>(ap);
-      xf1[1] = *reinterpret_cast<const u32x4 *>(ap + 2048);
-      issue_halo_pass(chunk + 1, tap < p.na ? tap : p.na - 1, live);
-      xf1[2] = *reinterpret_cast<const u32x4 *>(ap + 4096);
-      xf1[3] = *reinterpret_cast<const u32x4 *>(ap + 6144);
-      wf1[0] = *reinterpret_cast<const u32x4 *>(bp);
-      wf1[1] = *reinterpret_cast<const u32x4 *>(bp + 2048);
-      issue_weights(itw, it + 1 + D);
-      wf1[2] = *reinterpret_cast<const u32x4 *>(bp + 4096);
-      wf1[3] = *reinterpret_cast<const u32x4 *>(bp + 6144);
-      issued_prev = NB + 1;
-    }
-    mma_all(xf0, wf0, tap);                                    // the first half's MFMAs cover all of the above
-    // 2 DS reads, 4 MFMAs, 1 DMA | 2 DS, 4 MFMA | 2 DS, 4 MFMA, NB DMA | 2 DS, 4 MFMA   (bf16 counts)
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
-    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
-    __builtin_amdgcn_sched_group_barrier(0x010, NB, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    Y3_FINE(2);   // half-step A issued (8 reads + masks + 16 MFMAs)
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // second-half fragments (16 MFMAs old); keeps <= 8 LDS reads in flight
-    Y3_FINE(3);   // lgkmcnt(0)
-    const int tap_n = tap == 8 ? 0 : tap + 1;
-    const int chunk_n = tap == 8 ? chunk + 1 : chunk;
-    {                                                          // first half of the next step (harmless
-      const int ky_n = (tap_n * 11) >> 5, kx_n = tap_n - ky_n * 3;   // in-bounds read after the last one)
-      read_frags(xf0, wf0, sA + (chunk_n & 1) * p.a_bytes, sB + ((it + 1) % NSB) * B_BYTES, ky_n * p.W + kx_n, 0);
-    }
-    mma_all(xf1, wf1, tap);
-    interleave();
-    __builtin_amdgcn_sched_barrier(0);
-    Y3_FINE(4);   // half-step B issued
-    // the prefetched fragments have had 16 MFMAs of time; retiring them here (lgkmcnt(0) only, in a form
-    // hipcc's wait-count pass understands) lets it issue the next step's first MFMAs without a wait
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    Y3_FINE(5);   // lgkmcnt(0)
-    tap = tap_n;
-    chunk = chunk_n;
-  }
-  __syncthreads();  // all operand reads done: LDS can hold the output tile
-  Y3_COARSE(2);  // main loop
-
-  // ---- epilogue: raw fp32 accumulators -> LDS (pixel rows, XOR-swizzled 16-byte chunks) -> every thread
-  // finishes 8 consecutive channels of one pixel: scale/bias/LeakyReLU, + residual, one 16-byte store
-  constexpr int SWZ = 15;
-  constexpr int OCT_PER_ROW = BN / 8;
-  constexpr int WR = BM * OCT_PER_ROW / NT;   // write-out steps per thread (8)
-  float *sC = reinterpret_cast<float *>(smem);
-  const bool leaky = p.flags & Y3_F_LEAKY;
-  const bool has_res = p.flags & Y3_F_RESIDUAL;
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int cl = wn * 64 + ni * 16 + fq * 4;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int pl = wm * 64 + mi * 16 + fr;
-      *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
-    }
-  }
-  const int co = n0 + oc_mine * 8;
-  const f32x4 sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
-  const f32x4 sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
-  const f32x4 bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
-  const f32x4 bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
-  u32x4 resv[WR];
-  if (has_res) {
-#pragma unroll
-    for (int j = 0; j < WR; ++j) {
-      const int m = m0 + (tid >> 4) + j * (NT / 16);
-      const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
-      if constexpr (sizeof(T) == 2) {
-        resv[j] = m < p.M ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
-      }
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < WR; ++j) {
-    const int pl = (tid >> 4) + j * (NT / 16);
-    const int m = m0 + pl;
-    if (m >= p.M) continue;
-    const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
-    const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
-    float v[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[r] = lo[r] * sc_lo[r] + bi_lo[r];
-      v[4 + r] = hi[r] * sc_hi[r] + bi_hi[r];
-    }
-    if (leaky) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : Y3_LEAKY_SLOPE * v[r];
-    }
-    if (has_res) {
-      if constexpr (sizeof(T) == 2) {
-        const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[j]);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
-      } else {
-        const float *rp = reinterpret_cast<const float *>(p.res) + (long long)m * p.res_ld + co;
-        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(rp), r1 = *reinterpret_cast<const f32x4 *>(rp + 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
-      }
-    }
-    T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
-    if constexpr (sizeof(T) == 2) {
-      bf16x8 ov;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) ov[r] = (bf16_t)v[r];
-      *reinterpret_cast<bf16x8 *>(op) = ov;
-    } else {
-      *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-    }
-  }
-  Y3_COARSE(3);  // epilogue
-  Y3_STAMP_COUNT();
-}
-
-// ------------------------------------------------------------------------------------------------
-// Ping-pong variant (BM = 256, 8 waves = 2 per SIMD).  Measured on the kernel above: the two waves of
-// a SIMD run in lockstep -- both issue LDS-DMA / LDS reads, then both want the matrix pipe -- so a
-// K-step costs ~2100 cycles for 1024 cycles of MFMA.  Here every wave alternates a LOAD segment
-// (its share of the LDS-DMA for step s+2, then the 16 fragment reads of step s into registers)
-// with a COMPUTE segment (32 MFMAs of step s, operands already in registers); waves 4-7 run one
-// segment behind waves 0-3 (they share SIMDs pairwise), and one workgroup barrier per segment keeps
-// the alternation, so on every SIMD one wave feeds the matrix pipe while its partner loads.
-// Ring: 3 weight slots; weights(s+2) are issued in load segment s; every wave drains its older loads
-// at the end of each odd half-step (group 0: after compute(s), group 1: after load(s)).
-template <typename T>
-__global__ __launch_bounds__(512) void conv_halo3x3_pp_kernel(HaloArgs p) {
-  constexpr int BM = 256, BN = 128, NT = 512, NSB = 3;
-  constexpr int ES = sizeof(T);
-  constexpr int BKE = 128 / ES;
-  constexpr int RPP = NT / 8;
-  constexpr int NB = BN / RPP;                        // 2 LDS-DMA instructions per thread per weight tile
-  constexpr int B_BYTES = BN * 128;
-  constexpr int MI = 4, NI = 4;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *sB = smem;                                    // [NSB][128][128]
-  char *sA = smem + NSB * B_BYTES;                    // [2][hr_pad][128]
-
-  Y3_STAMP_DECL
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  // waves w and w+4 share a SIMD; readfirstlane makes the group id provably wave-uniform, so the
-  // group-dependent barriers below are real scalar branches (never executed under an empty EXEC mask)
-  const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 15, fq = lane >> 4;
-
-  const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / p.n_tiles) * BM;
-  const int n0 = (tile % p.n_tiles) * BN;
-
-  const int slot = tid & 7;
-  const int row0 = tid >> 3;
-  const int kc = slot ^ (row0 & 7);
-  const long long q0 = (long long)m0 - p.W - 1;
-
-  auto issue_halo_pass = [&](int chunk, int pass) {
-    const long long q = q0 + row0 + pass * RPP;
-    const bool ok = q >= 0 && q < p.M;
-    const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
-    char *dst = sA + (chunk & 1) * p.a_bytes + pass * (NT * 16) + wave * 1024;
-    __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
-  };
-  const char *b_src0 = p.wgt + ((long long)(n0 + row0) * p.k_ld) * ES + kc * 16;
-  const char *b_src1 = b_src0 + (long long)RPP * p.k_ld * ES;
-  auto issue_weights = [&](int chunk, int tap, int slot_idx) {
-    const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
-    char *dst = sB + slot_idx * B_BYTES + wave * 1024;
-    __builtin_amdgcn_global_load_lds((gbl_void *)(b_src0 + koff), (lds_void *)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_void *)(b_src1 + koff), (lds_void *)(dst + NT * 16), 16, 0, 0);
-  };
-
-  const int nit = p.nchunks * 9;
-  for (int pass = 0; pass < p.na; ++pass) issue_halo_pass(0, pass);
-  issue_weights(0, 0, 0);
-  issue_weights(0, 1, 1);   // nit >= 18: the launcher requires at least two channel chunks
-
-  uint32_t tapmask[MI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const uint32_t m = (uint32_t)(m0 + wm * 64 + mi * 16 + fr);
-    uint32_t mask = 0u;
-    if (m < (uint32_t)p.M) {
-      const uint32_t img = (__umulhi(m, p.mul_hw) + m) >> p.sh_hw;
-      const uint32_t rem = m - img * (uint32_t)p.HW;
-      const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
-      const uint32_t ox = rem - oy * (uint32_t)p.W;
-      const uint32_t vx = (ox >= 1u ? 1u : 0u) | 2u | (ox + 1u < (uint32_t)p.W ? 4u : 0u);
-      mask = (oy >= 1u ? vx : 0u) | (vx << 3) | (oy + 1u < (uint32_t)p.H ? vx << 6 : 0u);
-    }
-    tapmask[mi] = mask;
-  }
-  // wave-uniform: does any of the 64 lanes need masking for this 16-pixel group at all?
-  bool need_mask[MI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) need_mask[mi] = __any(tapmask[mi] != 0x1FFu);
-
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int a_lane_row = wm * 64 + fr;
-  const int b_lane_row = wn * 64 + fr;
-  const int b_off0 = b_lane_row * 128 + (((0 + fq) ^ (b_lane_row & 7)) << 4);
-  const int b_off1 = b_lane_row * 128 + (((4 + fq) ^ (b_lane_row & 7)) << 4);
-
-  Y3_COARSE(0);
-  wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  Y3_COARSE(1);
-  if (grp) __builtin_amdgcn_s_barrier();              // group 1 runs one segment behind group 0
-
-  // write-out role of this thread (epilogue): 8 channels [co, co+8) of pixels (tid>>4) + 32*j
-  constexpr int WR = BM * (BN / 8) / NT;
-  const int oc_mine = tid & 15;
-  const int co = n0 + oc_mine * 8;
-  const bool has_res = p.flags & Y3_F_RESIDUAL;
-  u32x4 resv[WR];
-  f32x4 sc_lo, sc_hi, bi_lo, bi_hi;
-
-  u32x4 xf[2][MI], wf[2][NI];
-  int tap = 0, chunk = 0;        // step s
-  int tap2 = 2, chunk2 = 0;      // step s + 2 (whose weights are issued in load segment s)
-#pragma unroll 1
-  for (int s = 0; s < nit; ++s) {
-    // ================= load segment =================
-    const char *aBuf = sA + (chunk & 1) * p.a_bytes;
-    const char *bBuf = sB + (s % NSB) * B_BYTES;
-    const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
-    const int r0 = a_lane_row + ky * p.W + kx;
-    const char *ap0 = aBuf + r0 * 128 + (((0 + fq) ^ (r0 & 7)) << 4);
-    const char *ap1 = aBuf + r0 * 128 + (((4 + fq) ^ (r0 & 7)) << 4);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) xf[0][mi] = *reinterpret_cast<const u32x4 *>(ap0 + mi * 2048);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) wf[0][ni] = *reinterpret_cast<const u32x4 *>(bBuf + b_off0 + ni * 2048);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) xf[1][mi] = *reinterpret_cast<const u32x4 *>(ap1 + mi * 2048);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) wf[1][ni] = *reinterpret_cast<const u32x4 *>(bBuf + b_off1 + ni * 2048);
-    if (s == nit - 1) {
-      // last step: no LDS-DMA left to issue; start the epilogue's global reads now so that their latency
-      // hides under this step's MFMAs (every counted vmcnt wait below is skipped for this step)
-      sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
-      sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
-      bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
-      bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
-      if (has_res) {
-#pragma unroll
-        for (int j = 0; j < WR; ++j) {
-          const int m = m0 + (tid >> 4) + j * (NT / 16);
-          const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
-          resv[j] = m < p.M ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
-        }
-      }
-    }
-    Y3_FINE(0);   // [barrier wait that started this load segment ... fragment reads issued]
-    // the fragment reads' latency hides under the LDS-DMA issue below
-    int issued = 0;
-    if (chunk + 1 < p.nchunks && tap < p.na) { issue_halo_pass(chunk + 1, tap); issued += 1; }
-    if (s + 2 < nit) { issue_weights(chunk2, tap2, (s + 2) % NSB); issued += NB; }
-    Y3_FINE(1);   // LDS-DMA issue
-    if (grp == 1 && s != nit - 1) {                   // end of an odd half-step for group 1
-      if (issued == NB + 1) wait_vmcnt<NB + 1>();
-      else if (issued == NB) wait_vmcnt<NB>();
-      else if (issued == 1) wait_vmcnt<1>();
-      else wait_vmcnt<0>();
-    }
-    Y3_FINE(2);   // vmcnt wait (group 1 only)
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    Y3_FINE(3);   // fragment reads landed
-    __builtin_amdgcn_s_barrier();
-    Y3_FINE(4);   // barrier (waiting for the partner group's compute segment)
-    // ================= compute segment =================
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-      if (need_mask[mi]) {   // scalar branch: interior pixel groups skip the 8 v_cndmask
-        const bool dead = !((tapmask[mi] >> tap) & 1u);
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-          if (dead) xf[g][mi] = u32x4{0u, 0u, 0u, 0u};
-      }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) MmaH<T>::run(acc[mi][ni], wf[g][ni], xf[g][mi]);
-    __builtin_amdgcn_s_setprio(0);
-    Y3_FINE(5);   // masks + 32 MFMAs issued
-    if (grp == 0 && s != nit - 1) {                   // end of an odd half-step for group 0
-      if (issued == NB + 1) wait_vmcnt<NB + 1>();
-      else if (issued == NB) wait_vmcnt<NB>();
-      else if (issued == 1) wait_vmcnt<1>();
-      else wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    Y3_FINE(6);   // vmcnt wait (group 0) + barrier (waiting for the partner group's load segment)
-    tap = tap == 8 ? 0 : tap + 1;
-    chunk += tap == 0 ? 1 : 0;
-    tap2 = tap2 == 8 ? 0 : tap2 + 1;
-    chunk2 += tap2 == 0 ? 1 : 0;
-  }
-  if (!grp) __builtin_amdgcn_s_barrier();             // balance group 1's extra barrier
-  __syncthreads();
-  Y3_COARSE(2);
-
-  // ---- epilogue (as above): raw fp32 tile -> LDS -> 8 channels of one pixel per thread-step ----------
-  constexpr int SWZ = 15;
-  constexpr int OCT_PER_ROW = BN / 8;
-  float *sC = reinterpret_cast<float *>(smem);
-  const bool leaky = p.flags & Y3_F_LEAKY;
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int cl = wn * 64 + ni * 16 + fq * 4;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int pl = wm * 64 + mi * 16 + fr;
-      *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < WR; ++j) {
-    const int pl = (tid >> 4) + j * (NT / 16);
-    const int m = m0 + pl;
-    if (m >= p.M) continue;
-    const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
-    const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
-    float v[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[r] = lo[r] * sc_lo[r] + bi_lo[r];
-      v[4 + r] = hi[r] * sc_hi[r] + bi_hi[r];
-    }
-    if (leaky) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : Y3_LEAKY_SLOPE * v[r];
-    }
-    if (has_res) {
-      if constexpr (sizeof(T) == 2) {
-        const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[j]);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
-      } else {
-        const float *rp = reinterpret_cast<const float *>(p.res) + (long long)m * p.res_ld + co;
-        const f32x4 r0v = __builtin_bit_cast(f32x4, resv[j]), r1v = *reinterpret_cast<const f32x4 *>(rp + 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { v[r] += r0v[r]; v[4 + r] += r1v[r]; }
-      }
-    }
-    T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
-    if constexpr (sizeof(T) == 2) {
-      bf16x8 ov;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) ov[r] = (bf16_t)v[r];
-      *reinterpret_cast<bf16x8 *>(op) = ov;
-    } else {
-      *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-    }
-  }
-  Y3_COARSE(3);
-  Y3_STAMP_COUNT();
-}
-
-// ------------------------------------------------------------------------------------------------
-// 32-channel-chunk variant ("halo32"): 64-byte LDS rows.  The halo of a chunk is then 4x smaller, which buys
-// what the 128-byte version cannot afford at W = 76: a 5-slot weight ring (loads issued 3 K-steps ahead, so
-// the counted vmcnt wait at the top of a step is normally free) next to the double-buffered halo, in 112 KiB.
-// One K-step = one filter tap x 32 channels = ONE MFMA k-step: 16 MFMAs per wave, whose gaps carry the 8
-// fragment reads of the NEXT step (double-buffered registers, loop unrolled by two) and the step's two LDS-DMA
-// instructions (branch-free issue; a dummy goes to a dump region when there is nothing to fetch).
-template <typename T>
-__global__ __launch_bounds__(512) void conv_halo32_kernel(HaloArgs p) {
-  constexpr int BM = 256, BN = 128, NT = 512, NSB = 5, D = NSB - 2;
-  constexpr int ES = sizeof(T);
-  constexpr int RB = 64;                              // bytes per LDS row
-  constexpr int BKE = RB / ES;                        // channels per chunk (32 bf16 / 16 fp32)
-  constexpr int RPP = NT / 4;                         // rows per loader pass (4 chunks of 16 B per row)
-  constexpr int B_BYTES = BN * RB;                    // 8 KiB per weight slot: exactly one DMA per thread
-  constexpr int MI = 4, NI = 4;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *sB = smem;                                    // [NSB][128][64]
-  char *sDump = smem + NSB * B_BYTES;                 // [8 waves][1 KiB] target of dummy DMAs
-  char *sA = sDump + 8 * 1024;                        // [2][hr_pad][64]
-
-  Y3_STAMP_DECL
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 15, fq = lane >> 4;
-
-  const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / p.n_tiles) * BM;
-  const int n0 = (tile % p.n_tiles) * BN;
-
-  const int slot = tid & 3;
-  const int row0 = tid >> 2;                          // 0..127
-  const int kc = slot ^ ((row0 >> 1) & 3);            // RPP % 8 == 0: later passes keep (row >> 1) & 3
-  const long long q0 = (long long)m0 - p.W - 1;
-
-  auto issue_halo_pass = [&](int chunk, int pass, bool live) {
-    const long long q = q0 + row0 + pass * RPP;
-    const bool ok = live && q >= 0 && q < p.M;
-    const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
-    char *dst = live ? sA + (chunk & 1) * p.a_bytes + pass * (NT * 16) + wave * 1024 : sDump + wave * 1024;
-    __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
-  };
-  const char *b_src = p.wgt + ((long long)(n0 + row0) * p.k_ld) * ES + kc * 16;
-  auto issue_weights = [&](int it, int slot_it) {     // it = chunk*9 + tap
-    const int chunk = it / 9, tap = it - chunk * 9;
-    const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
-    __builtin_amdgcn_global_load_lds((gbl_void *)(b_src + koff), (lds_void *)(sB + (slot_it % NSB) * B_BYTES + wave * 1024), 16, 0, 0);
-  };
-
-  const int nit = p.nchunks * 9;                      // even (the launcher requires an even chunk count)
-  for (int pass = 0; pass < p.na; ++pass) issue_halo_pass(0, pass, true);
-#pragma unroll
-  for (int j = 0; j <= D; ++j) issue_weights(j, j);
-
-  uint32_t tapmask[MI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const uint32_t m = (uint32_t)(m0 + wm * 64 + mi * 16 + fr);
-    uint32_t mask = 0u;
-    if (m < (uint32_t)p.M) {
-      const uint32_t img = (__umulhi(m, p.mul_hw) + m) >> p.sh_hw;
-      const uint32_t rem = m - img * (uint32_t)p.HW;
-      const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
-      const uint32_t ox = rem - oy * (uint32_t)p.W;
-      const uint32_t vx = (ox >= 1u ? 1u : 0u) | 2u | (ox + 1u < (uint32_t)p.W ? 4u : 0u);
-      mask = (oy >= 1u ? vx : 0u) | (vx << 3) | (oy + 1u < (uint32_t)p.H ? vx << 6 : 0u);
-    }
-    tapmask[mi] = mask;
-  }
-  bool need_mask[MI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) need_mask[mi] = __any(tapmask[mi] != 0x1FFu);
-
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int a_lane_row = wm * 64 + fr;
-  const int b_lane_row = wn * 64 + fr;
-  const int b_off = b_lane_row * RB + ((fq ^ ((b_lane_row >> 1) & 3)) << 4);
-
-  // fragment pointers of step `it` (tap, chunk): A rows shift with the tap, B comes from the ring slot
-  auto a_ptr = [&](int chunk, int tap) -> const char * {
-    const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
-    const int r0 = a_lane_row + ky * p.W + kx;
-    return sA + (chunk & 1) * p.a_bytes + r0 * RB + ((fq ^ ((r0 >> 1) & 3)) << 4);
-  };
-
-  Y3_COARSE(0);
-  // halo(0) and weights(0..D-1) landed; only weights(D) may still fly.  (Waiting for just weights(1) would
-  // break the steady-state count at step 1, whose weights(2) would then have D younger loads, not 2(D-1).)
-  wait_vmcnt<1>();
-  __builtin_amdgcn_s_barrier();
-  Y3_COARSE(1);
-
-  u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
-  {
-    const char *ap = a_ptr(0, 0);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) xf0[mi] = *reinterpret_cast<const u32x4 *>(ap + mi * 16 * RB);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) wf0[ni] = *reinterpret_cast<const u32x4 *>(sB + b_off + ni * 16 * RB);
-  }
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-
-  // one K-step: MFMAs on (xc, wc) while (xn, wn_) receive the next step's fragments and the step's DMA goes out
-  auto step = [&](int it, int tap, int chunk, u32x4 (&xc)[MI], u32x4 (&wc)[NI], u32x4 (&xn)[MI], u32x4 (&wn_)[NI]) {
-    wait_vmcnt<2 * (D - 1)>();                        // weights(it+1) (+ a due halo) landed; D-1 steps' loads may fly
-    __builtin_amdgcn_s_barrier();
-    const int tap_n = tap == 8 ? 0 : tap + 1;
-    const int chunk_n = tap == 8 ? chunk + 1 : chunk;
-    const char *ap = a_ptr(chunk_n, tap_n);
-    const char *bp = sB + ((it + 1) % NSB) * B_BYTES + b_off;
-    const bool live = chunk + 1 < p.nchunks && tap < p.na;
-    const int itw = it + 1 + D < nit ? it + 1 + D : nit - 1;
-    __builtin_amdgcn_sched_barrier(0);
-    xn[0] = *reinterpret_cast<const u32x4 *>(ap);
-    xn[1] = *reinterpret_cast<const u32x4 *>(ap + 16 * RB);
-    issue_halo_pass(chunk + 1, tap < p.na ? tap : 0, live);
-    xn[2] = *reinterpret_cast<const u32x4 *>(ap + 32 * RB);
-    xn[3] = *reinterpret_cast<const u32x4 *>(ap + 48 * RB);
-    wn_[0] = *reinterpret_cast<const u32x4 *>(bp);
-    wn_[1] = *reinterpret_cast<const u32x4 *>(bp + 16 * RB);
-    issue_weights(itw, it + 1 + D);
-    wn_[2] = *reinterpret_cast<const u32x4 *>(bp + 32 * RB);
-    wn_[3] = *reinterpret_cast<const u32x4 *>(bp + 48 * RB);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-      if (need_mask[mi] && !((tapmask[mi] >> tap) & 1u)) xc[mi] = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) MmaH<T>::run(acc[mi][ni], wc[ni], xc[mi]);
-    // 2 DS reads, 4 MFMAs, 1 DMA | 2 DS, 4 MFMA | 2 DS, 4 MFMA, 1 DMA | 2 DS, 4 MFMA   (bf16 counts)
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
-    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
-    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 4 : 16, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);               // next fragments landed (16 MFMAs of cover)
-  };
-
-  int tap = 0, chunk = 0;
-#pragma unroll 1
-  for (int it = 0; it < nit; it += 2) {
-    step(it, tap, chunk, xf0, wf0, xf1, wf1);
-    const int tap1 = tap == 8 ? 0 : tap + 1;
-    const int chunk1 = tap == 8 ? chunk + 1 : chunk;
-    step(it + 1, tap1, chunk1, xf1, wf1, xf0, wf0);
-    tap = tap1 == 8 ? 0 : tap1 + 1;
-    chunk = tap1 == 8 ? chunk1 + 1 : chunk1;
-  }
-  wait_vmcnt<0>();                                    // dummy DMAs of the last steps
-  __syncthreads();
-  Y3_COARSE(2);
-
-  // ---- epilogue (as in the ping-pong kernel) ---------------------------------------------------------------
-  constexpr int SWZ = 15;
-  constexpr int OCT_PER_ROW = BN / 8;
-  constexpr int WR = BM * OCT_PER_ROW / NT;
-  float *sC = reinterpret_cast<float *>(smem);
-  const bool leaky = p.flags & Y3_F_LEAKY;
-  const bool has_res = p.flags & Y3_F_RESIDUAL;
-  const int oc_mine = tid & 15;
-  const int co = n0 + oc_mine * 8;
-  const f32x4 sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
-  const f32x4 sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
-  const f32x4 bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
-  const f32x4 bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
-  u32x4 resv[WR];
-  if (has_res) {
-#pragma unroll
-    for (int j = 0; j < WR; ++j) {
-      const int m = m0 + (tid >> 4) + j * (NT / 16);
-      const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
-      resv[j] = m < p.M ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
-    }
-  }
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int cl = wn * 64 + ni * 16 + fq * 4;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int pl = wm * 64 + mi * 16 + fr;
-      *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < WR; ++j) {
-    const int pl = (tid >> 4) + j * (NT / 16);
-    const int m = m0 + pl;
-    if (m >= p.M) continue;
-    const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
-    const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
-    float v[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[r] = lo[r] * sc_lo[r] + bi_lo[r];
-      v[4 + r] = hi[r] * sc_hi[r] + bi_hi[r];
-    }
-    if (leaky) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : Y3_LEAKY_SLOPE * v[r];
-    }
-    if (has_res) {
-      if constexpr (sizeof(T) == 2) {
-        const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[j]);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
-      } else {
-        const float *rp = reinterpret_cast<const float *>(p.res) + (long long)m * p.res_ld + co;
-        const f32x4 r0v = __builtin_bit_cast(f32x4, resv[j]), r1v = *reinterpret_cast<const f32x4 *>(rp + 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { v[r] += r0v[r]; v[4 + r] += r1v[r]; }
-      }
-    }
-    T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
-    if constexpr (sizeof(T) == 2) {
-      bf16x8 ov;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) ov[r] = (bf16_t)v[r];
-      *reinterpret_cast<bf16x8 *>(op) = ov;
-    } else {
-      *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-    }
-  }
-  Y3_COARSE(3);
-  Y3_STAMP_COUNT();
-}
-
-// n / d == (umulhi(n, mul) + n) >> sh for 0 <= n < 2^31 (round-up method, d >= 1)
-void fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
-  if (d <= 1) { mul = 0; sh = 0; return; }
-  sh = 0;
-  while ((1u << sh) < d) ++sh;
-  mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Wave-specialised variant (BM = 256, BN = 128): 8 consumer waves (wave tile 64 x 64, two per SIMD) that only
@@ -1470,88 +663,13 @@ __global__ __launch_bounds__(768, 3) void conv_halo_wsp_kernel(HaloArgs p, int n
   }
 }
 
-struct HaloGeom { int na, hr_pad, a_bytes, nsb; size_t lds; };
-
-// geometry / LDS budget of one tile configuration; nsb == 0: does not fit
-HaloGeom halo_geom(int bm, int w) {
-  HaloGeom g = {0, 0, 0, 0, 0};
-  const int nt = bm * 2, rpp = nt / 8, nb = (128 + rpp - 1) / rpp;
-  const int hr = bm + 2 * w + 2;
-  g.na = (hr + rpp - 1) / rpp;
-  g.hr_pad = g.na * rpp;
-  g.a_bytes = g.hr_pad * 128;
-  const size_t epi = (size_t)bm * 128 * 4;
-  for (int nsb = 4; nsb >= 3; --nsb) {
-    // the next chunk's halo slices go out at taps 0..na-1 and must be older than the last allowed loads
-    if (g.na > (nsb == 4 ? 7 : 8)) continue;
-    size_t lds = (size_t)nsb * nb * rpp * 128 + (size_t)2 * g.a_bytes;
-    if (lds < epi) lds = epi;
-    if (lds <= 160 * 1024) { g.nsb = nsb; g.lds = lds; return g; }
-  }
-  return g;
+// n / d == (umulhi(n, mul) + n) >> sh for 0 <= n < 2^31 (round-up method, d >= 1)
+void fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
+  if (d <= 1) { mul = 0; sh = 0; return; }
+  sh = 0;
+  while ((1u << sh) < d) ++sh;
+  mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
 }
-
-template <typename T, int BM, int NSB>
-int launch_halo(const HaloArgs &a0, const HaloGeom &g, hipStream_t s) {
-  HaloArgs a = a0;
-  a.na = g.na; a.hr_pad = g.hr_pad; a.a_bytes = g.a_bytes;
-  const int m_tiles = y3_ceil_div(a.M, BM);
-  static bool attr_set = false;
-  if (!attr_set) {
-    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo3x3_kernel<T, BM, NSB>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((conv_halo3x3_kernel<T, BM, NSB>), dim3(m_tiles * a.n_tiles), dim3(BM * 2), g.lds, s, a);
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
-}
-
-template <typename T>
-int launch_halo_pp(const HaloArgs &a0, hipStream_t s) {
-  HaloArgs a = a0;
-  const int hr = 256 + 2 * a.W + 2;
-  a.na = y3_ceil_div(hr, 64);
-  a.hr_pad = a.na * 64;
-  a.a_bytes = a.hr_pad * 128;
-  size_t lds = (size_t)3 * 128 * 128 + (size_t)2 * a.a_bytes;
-  if (lds < (size_t)256 * 128 * 4) lds = (size_t)256 * 128 * 4;
-  Y3_REQUIRE(a.na <= 8 && lds <= 160 * 1024, "halo ping-pong kernel: row width %d does not fit", a.W);
-  static bool attr_set = false;
-  if (!attr_set) {
-    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo3x3_pp_kernel<T>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((conv_halo3x3_pp_kernel<T>), dim3(y3_ceil_div(a.M, 256) * a.n_tiles), dim3(512), lds, s, a);
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
-}
-
-template <typename T>
-int launch_halo32(const HaloArgs &a0, hipStream_t s) {
-  HaloArgs a = a0;
-  constexpr int ES = sizeof(T);
-  const int hr = 256 + 2 * a.W + 2;
-  a.na = y3_ceil_div(hr, 128);
-  a.hr_pad = a.na * 128;
-  a.a_bytes = a.hr_pad * 64;
-  a.nchunks = a.Cin / (64 / ES);
-  size_t lds = (size_t)5 * 128 * 64 + 8 * 1024 + (size_t)2 * a.a_bytes;
-  if (lds < (size_t)256 * 128 * 4) lds = (size_t)256 * 128 * 4;
-  Y3_REQUIRE(a.na <= 4 && lds <= 160 * 1024 && a.nchunks % 2 == 0 && a.nchunks >= 2,
-             "halo32 kernel: shape does not fit (W %d, %d chunks)", a.W, a.nchunks);
-  static bool attr_set = false;
-  if (!attr_set) {
-    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo32_kernel<T>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((conv_halo32_kernel<T>), dim3(y3_ceil_div(a.M, 256) * a.n_tiles), dim3(512), lds, s, a);
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
-}
-
 
 template <typename T>
 int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
@@ -1622,10 +740,6 @@ int launch_halo_wsp(const HaloArgs &a0, hipStream_t s) {
 
 }  // namespace
 
-int g_y3_halo_pp = 1;
-int g_y3_halo_bm = 0;   // tuning knob "halo_pp": use the ping-pong schedule for 256-pixel tiles
-
-// picks the pixel-tile height (256 or 192) that wastes the fewest CU rounds; 0 = not applicable
 bool y3_conv_halo_eligible(const y3_op &op) {
   const int es = y3_elem_size(op.dtype);
   const int bke = 128 / es;
@@ -1638,51 +752,21 @@ bool y3_conv_halo_eligible(const y3_op &op) {
   return true;
 }
 
-// wave-specialised 256x128 halo kernel: additionally the halo image must fit (2 * (258 + 2W) rows + 3 weight slots)
+// additionally the halo image must fit: 2 x (258 + 2W rows, padded to 32) x 128 B + 3 weight slots <= 160 KiB, and all
+// real halo slices must be out by tap 6 of the previous chunk (<= 14 passes of 32 rows)
 bool y3_conv_halo_ws_fits(const y3_op &op) {
   if (!y3_conv_halo_eligible(op)) return false;
   const int na = y3_ceil_div(256 + 2 * op.in_w + 2, 32);
   return na <= 14 && (size_t)3 * 128 * 128 + (size_t)2 * na * 32 * 128 <= 160 * 1024;
 }
 
-int y3_conv_halo_bm(const y3_op &op) {
-  if (!y3_conv_halo_eligible(op)) return 0;
-  const long long m = (long long)op.batch * op.out_h * op.out_w;
-  const int n_tiles = op.out_c / 128;
-  int best = 0;
-  double best_eff = 0.0;
-  const int cands[2] = {256, 192};
-  const bool pp_only = g_y3_halo_pp && !g_y3_halo_bm;   // default: only the ping-pong 256-pixel tile, and only
-                                                         // where it fills the 256 CUs evenly (else implicit GEMM)
-  for (int bm : cands) {
-    const HaloGeom g = halo_geom(bm, op.in_w);
-    if (g.nsb == 0) continue;
-    if (g_y3_halo_bm && bm != g_y3_halo_bm) continue;
-    if (pp_only && bm != 256) continue;
-    const double blocks = (double)((m + bm - 1) / bm) * n_tiles;
-    const double rounds = blocks / 256.0;
-    const double eff = rounds / (double)(long long)(rounds + 0.999999);
-    const double score = eff * (bm == 256 ? 1.04 : 1.0) * (g.nsb == 4 ? 1.03 : 1.0);
-    if (pp_only && eff < 0.9) continue;
-    if (score > best_eff) { best_eff = score; best = bm; }
-  }
-  return best;
-}
-
-int y3_launch_conv_halo(const y3_op &op, int bm, const void *d_in, const void *d_zero, hipStream_t s,
-                        const char **kernel_name, bool dry_run, int variant) {
-  const int pp = variant >= 0 ? variant : g_y3_halo_pp;
+int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
+                        const char **kernel_name, bool dry_run, bool persistent) {
   const int es = y3_elem_size(op.dtype);
   const bool bf = op.dtype == Y3_BF16;
-  Y3_REQUIRE(bm == 256 || bm == 192, "conv block %d: bad halo tile %d", op.block_idx, bm);
-  if (bm == 256) *kernel_name = bf ? "conv_halo3x3_bf16_256x128" : "conv_halo3x3_f32_256x128";
-  else *kernel_name = bf ? "conv_halo3x3_bf16_192x128" : "conv_halo3x3_f32_192x128";
-  const bool use32 = bm == 256 && pp == 2 && op.in_w <= 126 && (op.in_c / (64 / es)) % 2 == 0;
-  if (use32) *kernel_name = bf ? "conv_halo32_bf16_256x128" : "conv_halo32_f32_256x128";
-  const bool use_ws = bm == 256 && pp == 3;
-  if (use_ws) *kernel_name = bf ? "conv_halo_ws_bf16_256x128" : "conv_halo_ws_f32_256x128";
-  const bool use_wsp = bm == 256 && pp == 4;
-  if (use_wsp) *kernel_name = bf ? "conv_halo_wsp_bf16_256x128" : "conv_halo_wsp_f32_256x128";
+  Y3_REQUIRE(y3_conv_halo_ws_fits(op), "conv block %d: shape not supported by the halo kernel", op.block_idx);
+  if (persistent) *kernel_name = bf ? "conv_halo_wsp_bf16_256x128" : "conv_halo_wsp_f32_256x128";
+  else *kernel_name = bf ? "conv_halo_ws_bf16_256x128" : "conv_halo_ws_f32_256x128";
   if (dry_run) return Y3_OK;
   HaloArgs a;
   a.in = static_cast<const char *>(d_in);
@@ -1703,18 +787,8 @@ int y3_launch_conv_halo(const y3_op &op, int bm, const void *d_in, const void *d
   fast_div((uint32_t)a.W, a.mul_w, a.sh_w);
   a.flags = op.flags;
   Y3_REQUIRE((long long)op.batch * a.HW < (1ll << 31), "conv block %d: too many pixels for the 32-bit tile index", op.block_idx);
-  const HaloGeom g = halo_geom(bm, op.in_w);
-  Y3_REQUIRE(g.nsb != 0, "conv block %d: halo tile does not fit in LDS", op.block_idx);
-  if (use32) return bf ? launch_halo32<bf16_t>(a, s) : launch_halo32<float>(a, s);
-  if (use_ws) return bf ? launch_halo_ws<bf16_t>(a, s) : launch_halo_ws<float>(a, s);
-  if (use_wsp) return bf ? launch_halo_wsp<bf16_t>(a, s) : launch_halo_wsp<float>(a, s);
-  if (bm == 256 && pp) return bf ? launch_halo_pp<bf16_t>(a, s) : launch_halo_pp<float>(a, s);
-  if (bf) {
-    if (bm == 256) return g.nsb == 4 ? launch_halo<bf16_t, 256, 4>(a, g, s) : launch_halo<bf16_t, 256, 3>(a, g, s);
-    return g.nsb == 4 ? launch_halo<bf16_t, 192, 4>(a, g, s) : launch_halo<bf16_t, 192, 3>(a, g, s);
-  }
-  if (bm == 256) return g.nsb == 4 ? launch_halo<float, 256, 4>(a, g, s) : launch_halo<float, 256, 3>(a, g, s);
-  return g.nsb == 4 ? launch_halo<float, 192, 4>(a, g, s) : launch_halo<float, 192, 3>(a, g, s);
+  if (persistent) return bf ? launch_halo_wsp<bf16_t>(a, s) : launch_halo_wsp<float>(a, s);
+  return bf ? launch_halo_ws<bf16_t>(a, s) : launch_halo_ws<float>(a, s);
 }
 
 Y3_STAMP_READER(y3_debug_stamps_halo)

@@ -271,11 +271,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
 //     as whole 16-byte NHWC chunks (a pixel's channels are contiguous), residual read the same way.
 // KMODE 0: Cin % BKE == 0 (one tap per K-tile)   1: any Cin % CE == 0 (per-chunk tap, slow)
 //       2: BKE % Cin == 0, Cin < BKE (several whole taps per K-tile, e.g. Cin = 32 with bf16)
-// ST: 0 = LDS-DMA, two stages (default);  1 = register-staged, ONE stage (half the LDS -> more workgroups per CU)
-// RB: bytes of K per tile row: 128 (default) or 64 (half the LDS per workgroup -> 3 workgroups per CU; the LDS image
-// then swizzles 16-byte chunks with (row >> 1) & 3, conflict-free for the 16-rows x 4-chunks fragment read)
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, int ST, int RB>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RB == 64 ? 3 : 1) void conv_igemm2_kernel(IgemmArgs p) {
+// (Measured and removed: a register-staged single-stage form, 64-byte K rows for three workgroups per CU, and a
+// 256x128 eight-wave tile -- all within +-8 % of this one, none better: profiles/r01_convbench_variants.txt.)
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KMODE>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(IgemmArgs p) {
+  constexpr int RB = 128;                            // bytes of K per tile row
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int ES = sizeof(T);
   constexpr int CE = 16 / ES;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RB == 64 ? 3 : 1) void conv
   constexpr int STAGE = (BM + BN) * RB;
   static_assert(MI >= 1 && NI >= 1 && A_CH >= 1 && B_CH >= 1, "tile too small");
   // the fp32 output tile is written out in EP passes of RP pixel rows each (it must fit in the stages)
-  constexpr int LDS_BYTES = (ST == 0 ? 2 : 1) * STAGE;
+  constexpr int LDS_BYTES = 2 * STAGE;
   constexpr int EP = (BM * BN * 4 + LDS_BYTES - 1) / LDS_BYTES <= 1 ? 1 : ((BM * BN * 4 + LDS_BYTES - 1) / LDS_BYTES <= 2 ? 2 : 4);
   constexpr int RP = BM / EP;
   static_assert(RP * BN * 4 <= LDS_BYTES && (RP % TM == 0 || TM % RP == 0), "epilogue tile must fit in the operand stages");
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RB == 64 ? 3 : 1) void conv
   const int slot = tid % CPRW;
   const int row0 = tid / CPRW;
   // logical chunk held at this LDS position (source-side swizzle); rows of later passes keep the same low bits
-  const int kc = RB == 128 ? (slot ^ (row0 & 7)) : (slot ^ ((row0 >> 1) & 3));
+  const int kc = slot ^ (row0 & 7);
 
   const char *a_base[A_CH];
   uint32_t a_taps[A_CH];
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RB == 64 ? 3 : 1) void conv
       src[i] = ok ? a_base[i] + tap_off : p.zero;
     }
   };
-  auto issue = [&](int kt, int stage) {   // ST == 0: straight into LDS
+  auto issue = [&](int kt, int stage) {   // straight into LDS
     char *sA = smem + stage * STAGE;
     char *sB = sA + BM * RB;
     const char *src[A_CH];
@@ -396,19 +396,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RB == 64 ? 3 : 1) void conv
     for (int i = 0; i < B_CH; ++i)
       __builtin_amdgcn_global_load_lds((gbl_void *)(b_base[i] + koff), (lds_void *)(sB + wave * 1024 + i * (NT * 16)), 16, 0, 0);
   };
-  u32x4 a_reg[ST == 1 ? A_CH : 1], b_reg[ST == 1 ? B_CH : 1];
-  auto fetch = [&](int kt) {              // ST == 1: into registers, written to LDS one step later
-    if constexpr (ST == 1) {
-      const char *src[A_CH];
-      a_sources(kt, src);
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i) a_reg[i] = *reinterpret_cast<const u32x4 *>(src[i]);
-      const long long koff = (long long)kt * RB;
-#pragma unroll
-      for (int i = 0; i < B_CH; ++i) b_reg[i] = *reinterpret_cast<const u32x4 *>(b_base[i] + koff);
-    }
-  };
-
   f32x4 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -436,13 +423,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RB == 64 ? 3 : 1) void conv
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int row = wm * TM + mi * 16 + fr;
-        const int ch = RB == 128 ? ((g * 4 + fq) ^ (row & 7)) : (fq ^ ((row >> 1) & 3));
+        const int ch = (g * 4 + fq) ^ (row & 7);
         xf[mi] = *reinterpret_cast<const u32x4 *>(sA + row * RB + (ch << 4));
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int row = wn * TN + ni * 16 + fr;
-        const int ch = RB == 128 ? ((g * 4 + fq) ^ (row & 7)) : (fq ^ ((row >> 1) & 3));
+        const int ch = (g * 4 + fq) ^ (row & 7);
         wf[ni] = *reinterpret_cast<const u32x4 *>(sB + row * RB + (ch << 4));
       }
       __builtin_amdgcn_s_setprio(1);
@@ -455,29 +442,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, RB == 64 ? 3 : 1) void conv
   };
 
   Y3_STAMP(0);
-  if constexpr (ST == 0) {
-    issue(0, 0);
-    for (int kt = 0; kt < p.n_ktiles; ++kt) {
-      const int cur = kt & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt has landed (this wave's pieces)
-      __syncthreads();                                   // ... everyone's; stage cur^1 is free again
-      if (kt == 0) Y3_STAMP(1);
-      if (kt + 1 < p.n_ktiles) issue(kt + 1, cur ^ 1);
-      compute(smem + cur * STAGE, smem + cur * STAGE + BM * RB);
-    }
-  } else {
-    fetch(0);
-    for (int kt = 0; kt < p.n_ktiles; ++kt) {
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4 *>(smem + tid * 16 + i * (NT * 16)) = a_reg[i];
-#pragma unroll
-      for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4 *>(smem + BM * RB + tid * 16 + i * (NT * 16)) = b_reg[i];
-      __syncthreads();
-      if (kt == 0) Y3_STAMP(1);
-      if (kt + 1 < p.n_ktiles) fetch(kt + 1);            // next tile's loads fly during the MFMAs
-      compute(smem, smem + BM * RB);
-      __syncthreads();
-    }
+  issue(0, 0);
+  for (int kt = 0; kt < p.n_ktiles; ++kt) {
+    const int cur = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt has landed (this wave's pieces)
+    __syncthreads();                                   // ... everyone's; stage cur^1 is free again
+    if (kt == 0) Y3_STAMP(1);
+    if (kt + 1 < p.n_ktiles) issue(kt + 1, cur ^ 1);
+    compute(smem + cur * STAGE, smem + cur * STAGE + BM * RB);
   }
   // the epilogue's global reads go out first; a raw barrier (no vmcnt drain) lets them fly while the
   // accumulators are parked in LDS
@@ -887,9 +859,7 @@ void conv_igemm3_kernel(IgemmArgs p) {
 }
 
 static int g_igemm_version = 2;   // 1 = register-staged single buffer, 2 = LDS-DMA double buffer
-static int g_igemm_bm = 0;        // 0 = heuristic, else 128 / 256 (256 = 8-wave tile, v2 bf16 only)
-static int g_igemm_staging = 0;    // 0 = LDS-DMA two stages, 1 = register-staged one stage
-static int g_igemm_rb = 128;       // bytes of K per tile row (128 or 64)
+static int g_igemm_bm = 0;        // 64 = 64-pixel tiles for the wave-specialised kernel (v3, bf16), else 128
 static int g_igemm_ns = 2;         // v3: LDS stages (2 or 3)
 
 template <typename T, int BM, int BN, int WM, int WN, int NS>
@@ -911,22 +881,16 @@ int launch_cfg3(const IgemmArgs &a, int kmode, int ns, hipStream_t s) {
   return launch_cfg3x<T, BM, BN, WM, WN, 2>(a, kmode, s);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int ST, int RB>
-int launch_cfg2x(IgemmArgs a, int kmode, hipStream_t s) {
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_cfg2(IgemmArgs a, int kmode, hipStream_t s) {
   a.m_tiles = y3_ceil_div(a.M, BM);
   a.n_tiles = y3_ceil_div(a.Cout, BN);
   const dim3 grid(a.m_tiles * a.n_tiles), block(64 * WM * WN);
-  if (kmode == 0) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 0, ST, RB>), grid, block, 0, s, a);
-  else if (kmode == 2) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 2, ST, RB>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 1, ST, RB>), grid, block, 0, s, a);
+  if (kmode == 0) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 0>), grid, block, 0, s, a);
+  else if (kmode == 2) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 2>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 1>), grid, block, 0, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
-}
-
-template <typename T, int BM, int BN, int WM, int WN>
-int launch_cfg2(const IgemmArgs &a, int kmode, hipStream_t s) {
-  if (g_igemm_staging == 1 && BM == 128) return launch_cfg2x<T, BM, BN, WM, WN, 1, 128>(a, kmode, s);
-  return launch_cfg2x<T, BM, BN, WM, WN, 0, 128>(a, kmode, s);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -973,14 +937,9 @@ extern "C" int y3_set_tuning(const char *key, int value) {
   if (!key) return Y3_ERR_INVALID;
   if (!strcmp(key, "igemm_version")) { g_igemm_version = value; return Y3_OK; }
   if (!strcmp(key, "igemm_bm")) { g_igemm_bm = value; return Y3_OK; }
-  if (!strcmp(key, "igemm_staging")) { g_igemm_staging = value; return Y3_OK; }
-  if (!strcmp(key, "igemm_rb")) { g_igemm_rb = value; return Y3_OK; }
   if (!strcmp(key, "igemm_ns")) { g_igemm_ns = value; return Y3_OK; }
   if (!strcmp(key, "auto_mask")) { g_y3_auto_mask = value; return Y3_OK; }
-  if (!strcmp(key, "halo_ws_variant")) { g_y3_halo_ws_variant = value; return Y3_OK; }
-  if (!strcmp(key, "conv_halo")) { g_y3_use_halo = value; return Y3_OK; }
-  if (!strcmp(key, "halo_pp")) { g_y3_halo_pp = value; return Y3_OK; }
-  if (!strcmp(key, "halo_bm")) { g_y3_halo_bm = value; return Y3_OK; }
+  if (!strcmp(key, "halo_persistent")) { g_y3_halo_persistent = value; return Y3_OK; }
   y3_set_error("y3_set_tuning: unknown key %s", key);
   return Y3_ERR_INVALID;
 }
@@ -993,10 +952,7 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
   Y3_REQUIRE(y3_conv_igemm_supported(op), "conv block %d: shape not supported by the igemm kernel",
              op.block_idx);
   const int es = y3_elem_size(op.dtype);
-  // K-tile row: 128 bytes, or 64 bytes (tuning knob "igemm_rb": 3 workgroups per CU) for the 128-wide tile
-  const bool rb64 = g_igemm_rb == 64 && version == 2 && op.out_c > 64 && !(op.flags & Y3_F_OUT_F32) &&
-                    bm_knob != 256;
-  const int bke = (rb64 ? 64 : 128) / es;
+  const int bke = 128 / es;
   IgemmArgs a;
   a.in = static_cast<const char *>(d_in);
   a.wgt = static_cast<const char *>(op.d_weight);
@@ -1058,16 +1014,6 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
     return bf ? launch_cfg3<bf16_t, 128, 128, 2, 2>(a, kmode, ns, s) : launch_cfg3<float, 128, 128, 2, 2>(a, kmode, ns, s);
   }
   if (bn == 128) {
-    if (bf && bm_knob == 256) {
-      *kernel_name = "conv_igemm2_bf16_256x128";
-      if (dry_run) return Y3_OK;
-      return launch_cfg2<bf16_t, 256, 128, 4, 2>(a, kmode, s);
-    }
-    if (rb64) {
-      *kernel_name = bf ? "conv_igemm2_bf16_128x128_k32" : "conv_igemm2_f32_128x128_k16";
-      if (dry_run) return Y3_OK;
-      return bf ? launch_cfg2x<bf16_t, 128, 128, 2, 2, 0, 64>(a, kmode, s) : launch_cfg2x<float, 128, 128, 2, 2, 0, 64>(a, kmode, s);
-    }
     *kernel_name = bf ? "conv_igemm2_bf16_128x128" : "conv_igemm2_f32_128x128";
     if (dry_run) return Y3_OK;
     return bf ? launch_cfg2<bf16_t, 128, 128, 2, 2>(a, kmode, s) : launch_cfg2<float, 128, 128, 2, 2>(a, kmode, s);

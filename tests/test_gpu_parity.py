@@ -98,6 +98,9 @@ def test_mini_bf16_uint8_stem_matches_bf16_float_stem():
     assert (a["class_idx"] == b["class_idx"]).float().mean() > 0.97
 
 
+DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 21, "halo_persistent": 0}
+
+
 def test_tuning_knobs_do_not_change_results():
     """Every kernel variant behind y3_set_tuning computes the same convolution (fp32: same values up to
     summation order)."""
@@ -107,10 +110,9 @@ def test_tuning_knobs_do_not_change_results():
     x = torch.from_numpy(g["input"])
     ref = _net("mini").forward(x)
     try:
-        for knobs in ({"auto_mask": 0}, {"auto_mask": 63}, {"igemm_version": 1}, {"igemm_version": 3}, {"igemm_staging": 1}, {"igemm_rb": 64}, {"conv_halo": 1, "halo_pp": 0},
-                      {"conv_halo": 1, "halo_pp": 1, "halo_bm": 256}, {"conv_halo": 1, "halo_pp": 2, "halo_bm": 256},
-                      {"conv_halo": 1, "halo_pp": 3, "halo_bm": 256}, {"conv_halo": 1, "halo_pp": 4, "halo_bm": 256},
-                      {"halo_ws_variant": 4}):
+        for knobs in ({"auto_mask": 0}, {"auto_mask": 63}, {"auto_mask": 127}, {"igemm_version": 1},
+                      {"igemm_version": 3, "auto_mask": 0}, {"igemm_version": 3, "igemm_bm": 64, "igemm_ns": 3, "auto_mask": 0},
+                      {"halo_persistent": 1}):
             for k, v in knobs.items():
                 _hip.check(lib.y3_set_tuning(k.encode(), v))
             out = _net("mini").forward(x)
@@ -119,10 +121,9 @@ def test_tuning_knobs_do_not_change_results():
             np.testing.assert_allclose(out["bbox_xywh"].cpu().numpy(), ref["bbox_xywh"].cpu().numpy(), rtol=1e-4,
                                        atol=1e-5, err_msg=str(knobs))
             for k in knobs:
-                _hip.check(lib.y3_set_tuning(k.encode(), {"igemm_version": 2, "igemm_rb": 128, "auto_mask": 21, "halo_ws_variant": 3}.get(k, 0)))
+                _hip.check(lib.y3_set_tuning(k.encode(), DEFAULT_KNOBS[k]))
     finally:
-        for k, v in (("igemm_version", 2), ("igemm_staging", 0), ("igemm_rb", 128), ("conv_halo", 0), ("halo_pp", 1),
-                     ("halo_bm", 0), ("igemm_bm", 0), ("auto_mask", 21), ("halo_ws_variant", 3)):
+        for k, v in DEFAULT_KNOBS.items():
             lib.y3_set_tuning(k.encode(), v)
     assert lib.y3_set_tuning(b"no_such_knob", 1) != 0
 
@@ -276,24 +277,23 @@ def test_shape_sweep_bf16(model, dim, batch):
     assert int(out["class_idx"].min()) >= 0 and int(out["class_idx"].max()) < 80
 
 
-def test_halo_kernels_match_igemm_on_yolov3_fp32():
-    """The experimental halo-reuse 3x3 kernels (off by default) against the goldens, whole network."""
+def test_halo_kernels_match_goldens_on_yolov3_fp32():
+    """Both forms of the halo-reuse 3x3 kernel (one tile per workgroup [default], persistent tile loop) against the
+    goldens, whole network, fp32."""
     from yolov3 import _hip
     lib = _hip.lib()
     g = np.load(os.path.join(GOLDEN, "forward_yolov3.npz"))
     frames = np.stack([resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), 608, 608), synth_frames(5, 1, 608, 608)[0]])
     try:
-        for pp in (0, 1, 2, 3, 4):
-            _hip.check(lib.y3_set_tuning(b"conv_halo", 1))
-            _hip.check(lib.y3_set_tuning(b"halo_bm", 256 if pp >= 2 else 0))
-            _hip.check(lib.y3_set_tuning(b"halo_pp", pp))
-            out = _net("yolov3").forward(torch.from_numpy(orc.frames_to_input(list(frames))))
+        for persistent in (0, 1):
+            _hip.check(lib.y3_set_tuning(b"halo_persistent", persistent))
+            net = _net("yolov3")
+            out = net.forward(torch.from_numpy(orc.frames_to_input(list(frames))))
+            assert any("halo_ws" in r["kernel"] for r in net.plan_report())
             np.testing.assert_allclose(out["bbox_xywh"].cpu().numpy(), g["bbox_xywh"], rtol=1e-4, atol=BOX_ATOL)
             np.testing.assert_allclose(out["class_prob"].cpu().numpy(), g["class_prob"], atol=SCORE_ATOL)
     finally:
-        lib.y3_set_tuning(b"conv_halo", 0)
-        lib.y3_set_tuning(b"halo_pp", 1)
-        lib.y3_set_tuning(b"halo_bm", 0)
+        lib.y3_set_tuning(b"halo_persistent", 0)
 
 
 def test_wave_specialised_igemm_is_bit_identical():

@@ -40,11 +40,13 @@ LAYERS = [
     ("s76_256-255_k1_head", 76, 256, 255, 1, 1, False, True),
 ]
 
+# knob sets (y3_set_tuning) compared per layer; auto_mask 0 = implicit GEMM everywhere, 21 = halo kernel where it fits
+BASE = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 0, "halo_persistent": 0}
 VARIANTS = [
-    ("v2_ldsdma", {"igemm_version": 2, "igemm_bm": 0, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128, "igemm_ns": 2, "auto_mask": 0}),
-    ("v3_64_ns3", {"igemm_version": 3, "igemm_bm": 64, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128, "igemm_ns": 3, "auto_mask": 0}),
-    ("v3_64_ns2", {"igemm_version": 3, "igemm_bm": 64, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128, "igemm_ns": 2, "auto_mask": 0}),
-    ("v3_64_ns4", {"igemm_version": 3, "igemm_bm": 64, "conv_halo": 0, "halo_pp": 1, "halo_bm": 0, "igemm_staging": 0, "igemm_rb": 128, "igemm_ns": 4, "auto_mask": 0}),
+    ("igemm_v2", dict(BASE)),
+    ("halo_ws", dict(BASE, auto_mask=21)),
+    ("halo_wsp", dict(BASE, auto_mask=21, halo_persistent=1)),
+    ("igemm_v3_ns3", dict(BASE, igemm_version=3, igemm_ns=3)),
 ]
 
 
