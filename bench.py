@@ -193,7 +193,7 @@ def main():
         cpu_frames = [f for f in synth_frames(123, args.cpu_frames, dim, dim)]
         orc.inference(onet, cpu_frames[:1], 0.05, 0.3)           # warm-up
         reps, t_cpu = 0, 0.0
-        while reps < 2 or (t_cpu < 8.0 and reps < 20):
+        while reps < 2 or (t_cpu < 12.0 and reps < 200):     # ~12 s of CPU work on the bounded sample
             c0 = time.perf_counter()
             orc.inference(onet, cpu_frames, 0.05, 0.3)
             t_cpu += time.perf_counter() - c0

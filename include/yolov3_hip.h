@@ -56,6 +56,8 @@ extern "C" {
 #define Y3_F_IN_NCHW_F32 8u    /* conv input is the network input, float32 (B,C,H,W) in [0,1]  (inference.py:332-335) */
 #define Y3_F_IN_NHWC_U8BGR 16u /* conv input is uint8 (B,H,W,3) BGR frames; kernel applies BGR->RGB and /255.0 (inference.py:332-333) */
 #define Y3_F_PLAN_INPUT 32u    /* d_in is supplied at y3_plan_run time                  */
+#define Y3_F_FUSE_NEXT 64u     /* plan hint: this conv's output is read by the NEXT op only, so the executor may run
+                                  both as one kernel (stem + stride-2 conv) and never materialise d_out      */
 
 /*
  * One unit of work.  POD, 8-byte aligned, zero-initialise unused fields.

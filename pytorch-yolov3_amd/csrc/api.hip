@@ -34,6 +34,7 @@ struct y3_plan {
   std::vector<y3_op> ops;
   std::vector<const char *> kernel;
   const void *d_zero;
+  std::vector<char> fuse;   // per op: 0 = launch normally, 1 = launch fused with the next op, 2 = nothing (fused into the previous op)
   std::vector<hipEvent_t> events;
 };
 
@@ -99,6 +100,18 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
   return Y3_ERR_INVALID;
 }
 
+// one op of a plan, honouring fusion decisions taken at plan creation
+int run_op(y3_plan *plan, size_t i, const void *d_input, hipStream_t s, const char **name) {
+  if (plan->fuse[i] == 2) return Y3_OK;
+  if (plan->fuse[i] == 1) {
+    const y3_op &op0 = plan->ops[i];
+    const void *in = (op0.flags & Y3_F_PLAN_INPUT) ? d_input : op0.d_in;
+    Y3_REQUIRE(in != nullptr, "op for block %d has no input pointer", op0.block_idx);
+    return y3_launch_conv_fused_stem_s2(op0, plan->ops[i + 1], in, s, name, false);
+  }
+  return dispatch(plan->ops[i], d_input, plan->d_zero, s, name, false);
+}
+
 }  // namespace
 
 extern "C" {
@@ -133,7 +146,19 @@ int y3_plan_create(const y3_op *ops, int n_ops, const void *d_zero, y3_plan **ou
   p->ops.assign(ops, ops + n_ops);
   p->kernel.assign(n_ops, "");
   p->d_zero = d_zero;
+  p->fuse.assign(n_ops, 0);
+  for (int i = 0; i + 1 < n_ops; ++i)
+    if ((p->ops[i].flags & Y3_F_FUSE_NEXT) && p->ops[i].kind == Y3_OP_CONV &&
+        y3_conv_fused_stem_s2_supported(p->ops[i], p->ops[i + 1])) {
+      p->fuse[i] = 1;
+      p->fuse[i + 1] = 2;
+    }
   for (int i = 0; i < n_ops; ++i) {
+    if (p->fuse[i] == 2) { p->kernel[i] = "(fused into the previous op)"; continue; }
+    if (p->fuse[i] == 1) {
+      (void)y3_launch_conv_fused_stem_s2(p->ops[i], p->ops[i + 1], nullptr, nullptr, &p->kernel[i], true);
+      continue;
+    }
     const int rc = dispatch(p->ops[i], nullptr, d_zero, nullptr, &p->kernel[i], true);
     if (rc != Y3_OK) {
       delete p;
@@ -154,7 +179,7 @@ int y3_plan_run(y3_plan *plan, const void *d_input, void *stream) {
   Y3_REQUIRE(plan, "y3_plan_run: null plan");
   const char *name = nullptr;
   for (size_t i = 0; i < plan->ops.size(); ++i) {
-    const int rc = dispatch(plan->ops[i], d_input, plan->d_zero, static_cast<hipStream_t>(stream), &name, false);
+    const int rc = run_op(plan, i, d_input, static_cast<hipStream_t>(stream), &name);
     if (rc != Y3_OK) return rc;
   }
   return Y3_OK;
@@ -172,7 +197,7 @@ int y3_plan_run_timed(y3_plan *plan, const void *d_input, void *stream, float *m
   const char *name = nullptr;
   Y3_HIP_CHECK(hipEventRecord(plan->events[0], s));
   for (size_t i = 0; i < n; ++i) {
-    const int rc = dispatch(plan->ops[i], d_input, plan->d_zero, s, &name, false);
+    const int rc = run_op(plan, i, d_input, s, &name);
     if (rc != Y3_OK) return rc;
     Y3_HIP_CHECK(hipEventRecord(plan->events[i + 1], s));
   }
@@ -188,13 +213,23 @@ const char *y3_plan_op_kernel(const y3_plan *plan, int op_index) {
 
 double y3_plan_op_flops(const y3_plan *plan, int op_index) {
   if (!plan || op_index < 0 || (size_t)op_index >= plan->ops.size()) return 0.0;
-  const y3_op &o = plan->ops[op_index];
-  if (o.kind != Y3_OP_CONV) return 0.0;
-  return 2.0 * o.ksize * o.ksize * o.in_c * (double)o.out_c * o.out_h * o.out_w * o.batch;
+  if (plan->fuse[op_index] == 2) return 0.0;
+  auto conv_flops = [](const y3_op &o) {
+    return o.kind != Y3_OP_CONV ? 0.0 : 2.0 * o.ksize * o.ksize * o.in_c * (double)o.out_c * o.out_h * o.out_w * o.batch;
+  };
+  double f = conv_flops(plan->ops[op_index]);
+  if (plan->fuse[op_index] == 1) f += conv_flops(plan->ops[op_index + 1]);
+  return f;
 }
 
 double y3_plan_op_bytes(const y3_plan *plan, int op_index) {
   if (!plan || op_index < 0 || (size_t)op_index >= plan->ops.size()) return 0.0;
+  if (plan->fuse[op_index] == 2) return 0.0;
+  if (plan->fuse[op_index] == 1) {   // frames in, second conv's output out, both weight sets; nothing in between
+    const y3_op &a = plan->ops[op_index], &b = plan->ops[op_index + 1];
+    return (double)a.batch * a.in_h * a.in_w * a.in_c + (double)b.batch * b.out_h * b.out_w * b.out_c * 2.0 +
+           27.0 * a.out_c * 2.0 + 9.0 * b.in_c * b.out_c * 2.0;
+  }
   const y3_op &o = plan->ops[op_index];
   const double es = y3_elem_size(o.dtype);
   const double in_px = (double)o.batch * o.in_h * o.in_w, out_px = (double)o.batch * o.out_h * o.out_w;

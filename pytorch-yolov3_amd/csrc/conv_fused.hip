@@ -1,0 +1,280 @@
+// First two layers of Darknet-53 in one kernel (gfx950, bf16): uint8 BGR frames -> conv 3x3 s1 (3 -> 32) + BN + leaky
+// -> conv 3x3 s2 (32 -> 64) + BN + leaky, NHWC bf16 out.  Replaces the first two conv blocks of
+// /root/reference/yolov3/darknet.py:244-257 (models/yolov3.cfg:25-39) plus inference.py:332-333's flip / 255.
+//
+// Why: at 608x608 x 16 frames the stem's 32-channel output is 379 MB -- written by one kernel and read back (9/4 x
+// through L2) by the next, both HBM-bound (0.125 + 0.18 ms, profiles/r01c_per_op.txt).  Here a workgroup owns a
+// 16 x 16 tile of the SECOND conv's output, recomputes the 33 x 33 stem pixels it needs from a 35 x 35 x 3 byte
+// input patch (6 % extra stem work), keeps them in LDS, and runs the stride-2 conv from there: HBM sees 18 MB of
+// input bytes and the 189 MB output only.
+//
+// Per tile (persistent workgroups, 8 waves, one per CU):
+//   phase 1  stem: 69 fragments of 16 stem pixels, K = 27 (one v_mfma_f32_16x16x32_bf16 per 16 channels), operands
+//            gathered from the normalised bf16 input patch in LDS exactly like conv_stem_mfma_kernel; result ->
+//            scale/bias/leaky -> bf16 -> stem image in LDS (80-byte pixel pitch: the stride-2 fragment reads of
+//            phase 2 are then bank-conflict-free); stem pixels outside the frame are the second conv's zero padding
+//   phase 2  stride-2 conv: wave w owns output rows 2w, 2w+1 (2 x 16 pixels) x 64 channels; one MFMA K-step per
+//            filter tap (32 input channels = 64 bytes); weights [64][9][32] live in LDS (608-byte channel pitch)
+//   phase 3  scale/bias/leaky -> bf16 -> staged through LDS (the stem image is dead by then) -> 16-byte NHWC stores
+// The next tile's input patch is fetched into registers during phase 2 and converted into the other patch buffer
+// afterwards, so no phase waits on HBM.  Accumulation order equals the unfused kernels' (tap-major, one MFMA per
+// tap), so the result is bit-identical to conv_stem_mfma_kernel followed by the implicit GEMM.
+#include "common.h"
+
+namespace {
+
+constexpr int kTO = 16;                 // output tile (second conv) is kTO x kTO
+constexpr int kSR = 2 * kTO + 1;        // stem rows / cols per tile (33)
+constexpr int kIR = kSR + 2;            // input rows / cols per tile (35)
+constexpr int kInPitch = 108;           // bf16 elements per input-patch row (35 * 3 = 105, padded)
+constexpr int kStemPitch = 80;          // bytes per stem pixel in LDS (64 used)
+constexpr int kW1Pitch = 608;           // bytes per output channel of the second conv's weights in LDS (576 used)
+constexpr int kNStem = kSR * kSR;       // 1089
+constexpr int kNFrag = (kNStem + 15) / 16;
+constexpr int kThreads = 512;
+constexpr int kInBytes = kIR * kInPitch * 2;                  // one input patch (bf16)
+constexpr int kPatchElems = kIR * kIR * 3;                    // 3675 bytes of the frame per patch
+constexpr int kPre = (kPatchElems + kThreads - 1) / kThreads; // bytes prefetched per thread (8)
+constexpr int kLds = 2 * kInBytes + kNStem * kStemPitch + 64 * kW1Pitch;
+
+struct FusedArgs {
+  const unsigned char *in;   // (B, H, W, 3) uint8 BGR
+  int H, W, batch;
+  const bf16_t *w0;          // stem weights [32][32]: k = ky*9 + kx*3 + byte channel, zero padded
+  const float *sc0, *bi0;
+  uint32_t flags0;
+  const bf16_t *w1;          // second conv [>= 64][k_ld1], k = (ky*3 + kx)*32 + ci
+  int k_ld1;
+  const float *sc1, *bi1;
+  uint32_t flags1;
+  bf16_t *out;
+  int out_ld, Ho, Wo;
+  int tiles_x, tiles_y, n_tiles;
+};
+
+__global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t *in_tile = reinterpret_cast<bf16_t *>(smem);                 // [2][kIR][kInPitch]
+  char *stem = smem + 2 * kInBytes;                                    // [kNStem][kStemPitch]
+  char *w1s = stem + kNStem * kStemPitch;                              // [64][kW1Pitch]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // ---- once per workgroup: second conv's weights -> LDS; stem weights / constants -> registers ----
+  for (int i = tid; i < 64 * 36; i += kThreads) {                      // 36 chunks of 16 bytes per output channel
+    const int co = i / 36, ch = i - co * 36;
+    *reinterpret_cast<u32x4 *>(w1s + co * kW1Pitch + ch * 16) =
+        *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.w1) + ((long long)co * p.k_ld1) * 2 + ch * 16);
+  }
+  const bf16x8 w0a = *reinterpret_cast<const bf16x8 *>(p.w0 + (0 + fr) * 32 + fq * 8);
+  const bf16x8 w0b = *reinterpret_cast<const bf16x8 *>(p.w0 + (16 + fr) * 32 + fq * 8);
+  int koff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = fq * 8 + j;
+    const int ky = k < 27 ? k / 9 : 0, jj = k < 27 ? k - ky * 9 : 0;   // padded k: any valid element (weight is 0)
+    koff[j] = ky * kInPitch + jj;
+  }
+  const int cq = fq * 4;
+  f32x4 sc0[2], bi0[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    sc0[ni] = *reinterpret_cast<const f32x4 *>(p.sc0 + ni * 16 + cq);
+    bi0[ni] = *reinterpret_cast<const f32x4 *>(p.bi0 + ni * 16 + cq);
+  }
+  const bool leaky0 = p.flags0 & Y3_F_LEAKY, leaky1 = p.flags1 & Y3_F_LEAKY;
+
+  // bytes of the frame patch of `tile` that this thread converts (kPre strided elements)
+  auto patch_fetch = [&](int tile, unsigned char (&pre)[kPre]) {
+    int t = tile;
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int b = t / p.tiles_y;
+    const int iy0 = 2 * ty * kTO - 2, ixb0 = (2 * tx * kTO - 2) * 3;
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) {
+      const int i = tid + j * kThreads;
+      const int r = i / (kIR * 3), cb = i - r * (kIR * 3);
+      const int iy = iy0 + r, ixb = ixb0 + cb;
+      unsigned char v = 0;
+      if (i < kPatchElems && (unsigned)iy < (unsigned)p.H && ixb >= 0 && ixb < p.W * 3)
+        v = p.in[((long long)b * p.H + iy) * p.W * 3 + ixb];
+      pre[j] = v;
+    }
+  };
+  auto patch_store = [&](int buf, const unsigned char (&pre)[kPre]) {
+    bf16_t *dst = in_tile + buf * (kIR * kInPitch);
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) {
+      const int i = tid + j * kThreads;
+      const int r = i / (kIR * 3), cb = i - r * (kIR * 3);
+      if (i < kPatchElems) dst[r * kInPitch + cb] = (bf16_t)((float)pre[j] / 255.0f);
+    }
+  };
+
+  int tile = blockIdx.x;
+  int buf = 0;
+  if (tile < p.n_tiles) {
+    unsigned char pre[kPre];
+    patch_fetch(tile, pre);
+    patch_store(0, pre);
+  }
+  for (; tile < p.n_tiles; tile += gridDim.x) {
+    int t = tile;
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int b = t / p.tiles_y;
+    const int oy0 = ty * kTO, ox0 = tx * kTO;
+    __syncthreads();   // B1: this tile's input patch (and, first time, the weights) are in LDS; stem image is free
+
+    // ---- phase 1: stem ------------------------------------------------------------------------------
+    const bf16_t *patch = in_tile + buf * (kIR * kInPitch);
+    for (int f = wave; f < kNFrag; f += kThreads / 64) {
+      const int q = f * 16 + fr;
+      const int qc = q < kNStem ? q : kNStem - 1;
+      const int sy = qc / kSR, sx = qc - sy * kSR;
+      const bf16_t *base = patch + sy * kInPitch + sx * 3;
+      bf16x8 xf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xf[j] = base[koff[j]];
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a, xf, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b, xf, acc1, 0, 0, 0);
+      const int gy = 2 * oy0 - 1 + sy, gx = 2 * ox0 - 1 + sx;          // stem pixel in frame coordinates
+      const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      if (q < kNStem) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const f32x4 a = ni ? acc1 : acc0;
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = a[r] * sc0[ni][r] + bi0[ni][r];
+            if (leaky0) v = v > 0.f ? v : Y3_LEAKY_SLOPE * v;
+            o[r] = (bf16_t)(inside ? v : 0.f);
+          }
+          *reinterpret_cast<bf16x4 *>(stem + q * kStemPitch + (ni * 16 + cq) * 2) = o;
+        }
+      }
+    }
+    // next tile's patch bytes start flying now; they are converted after phase 2
+    const int next_tile = tile + gridDim.x;
+    unsigned char pre[kPre];
+    if (next_tile < p.n_tiles) patch_fetch(next_tile, pre);
+    __syncthreads();   // B2: stem image complete
+
+    // ---- phase 2: 3x3 stride-2 conv from the stem image ---------------------------------------------
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) acc[mi][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      u32x4 xf[2], wf[4];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int q = (2 * (2 * wave + mi) + ky) * kSR + 2 * fr + kx;
+        xf[mi] = *reinterpret_cast<const u32x4 *>(stem + q * kStemPitch + fq * 16);
+      }
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+        wf[nf] = *reinterpret_cast<const u32x4 *>(w1s + (nf * 16 + fr) * kW1Pitch + tap * 64 + fq * 16);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+          acc[mi][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[nf]),
+                                                                __builtin_bit_cast(bf16x8, xf[mi]), acc[mi][nf], 0, 0, 0);
+    }
+    if (next_tile < p.n_tiles) patch_store(buf ^ 1, pre);
+    __syncthreads();   // B3: nobody reads the stem image any more
+
+    // ---- phase 3: epilogue through LDS (256 pixels x 128 bytes, 16-byte chunks XOR-swizzled with the pixel) ----
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const f32x4 s1 = *reinterpret_cast<const f32x4 *>(p.sc1 + nf * 16 + cq);
+      const f32x4 b1 = *reinterpret_cast<const f32x4 *>(p.bi1 + nf * 16 + cq);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[mi][nf][r] * s1[r] + b1[r];
+          if (leaky1) v = v > 0.f ? v : Y3_LEAKY_SLOPE * v;
+          o[r] = (bf16_t)v;
+        }
+        const int px = (2 * wave + mi) * kTO + fr;
+        const int co = nf * 16 + cq;                                   // 4 consecutive channels
+        *reinterpret_cast<bf16x4 *>(stem + px * 128 + (((co >> 3) ^ (px & 7)) << 4) + (co & 7) * 2) = o;
+      }
+    }
+    __syncthreads();   // B4
+#pragma unroll
+    for (int j = 0; j < kTO * kTO * 8 / kThreads; ++j) {
+      const int i = tid + j * kThreads;
+      const int px = i >> 3, ch = i & 7;
+      const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+      if (oy < p.Ho && ox < p.Wo) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(stem + px * 128 + ((ch ^ (px & 7)) << 4));
+        *reinterpret_cast<u32x4 *>(p.out + (((long long)b * p.Ho + oy) * p.Wo + ox) * p.out_ld + ch * 8) = v;
+      }
+    }
+    buf ^= 1;
+  }
+}
+
+}  // namespace
+
+int g_y3_fuse_stem = 1;   // tuning knob "fuse_stem"
+
+// op0: the MFMA stem conv (uint8 frames, 3 -> 32, bf16 out); op1: 3x3 stride-2 conv 32 -> 64 reading ONLY op0's output
+bool y3_conv_fused_stem_s2_supported(const y3_op &op0, const y3_op &op1) {
+  if (!g_y3_fuse_stem) return false;
+  if (!y3_conv_stem_mfma_supported(op0) || op0.out_c != 32 || (op0.flags & Y3_F_RESIDUAL)) return false;
+  if (op1.kind != Y3_OP_CONV || op1.dtype != Y3_BF16 || op1.ksize != 3 || op1.stride != 2 || op1.pad != 1) return false;
+  if (op1.in_c != 32 || op1.out_c != 64 || op1.out_ld % 8 != 0 || op1.out_ld < 64) return false;
+  if (op1.flags & (Y3_F_RESIDUAL | Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT)) return false;
+  if (op1.d_in != op0.d_out || op1.in_h != op0.out_h || op1.in_w != op0.out_w || op1.batch != op0.batch) return false;
+  if (op1.k_ld < 288 || op1.cout_pad < 64) return false;
+  if (op1.out_h != (op1.in_h + 2 - 3) / 2 + 1 || op1.out_w != (op1.in_w + 2 - 3) / 2 + 1) return false;
+  return true;
+}
+
+int y3_launch_conv_fused_stem_s2(const y3_op &op0, const y3_op &op1, const void *d_in, hipStream_t s,
+                                 const char **kernel_name, bool dry_run) {
+  *kernel_name = "conv_stem_s2_fused_u8_bf16";
+  if (dry_run) return Y3_OK;
+  FusedArgs a;
+  a.in = static_cast<const unsigned char *>(d_in);
+  a.H = op0.in_h; a.W = op0.in_w; a.batch = op0.batch;
+  a.w0 = static_cast<const bf16_t *>(op0.d_weight);
+  a.sc0 = op0.d_scale; a.bi0 = op0.d_bias; a.flags0 = op0.flags;
+  a.w1 = static_cast<const bf16_t *>(op1.d_weight);
+  a.k_ld1 = op1.k_ld;
+  a.sc1 = op1.d_scale; a.bi1 = op1.d_bias; a.flags1 = op1.flags;
+  a.out = static_cast<bf16_t *>(op1.d_out);
+  a.out_ld = op1.out_ld; a.Ho = op1.out_h; a.Wo = op1.out_w;
+  a.tiles_x = y3_ceil_div(a.Wo, kTO);
+  a.tiles_y = y3_ceil_div(a.Ho, kTO);
+  a.n_tiles = a.tiles_x * a.tiles_y * a.batch;
+  static bool attr_set = false;
+  static int n_cu = 0;
+  if (!attr_set) {
+    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_stem_s2_fused_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    int dev = 0;
+    Y3_HIP_CHECK(hipGetDevice(&dev));
+    Y3_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    attr_set = true;
+  }
+  const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
+  hipLaunchKernelGGL(conv_stem_s2_fused_kernel, dim3(grid), dim3(kThreads), kLds, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}

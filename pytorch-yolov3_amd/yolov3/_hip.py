@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("Y3_HIP_LIB") or os.path.join(_HERE, "..", "lib", "lib
 
 Y3_F32, Y3_BF16 = 0, 1
 OP_CONV, OP_MAXPOOL, OP_UPSAMPLE, OP_ADD, OP_COPY, OP_YOLO = 1, 2, 3, 4, 5, 6
-F_LEAKY, F_RESIDUAL, F_OUT_F32, F_IN_NCHW_F32, F_IN_NHWC_U8BGR, F_PLAN_INPUT = 1, 2, 4, 8, 16, 32
+F_LEAKY, F_RESIDUAL, F_OUT_F32, F_IN_NCHW_F32, F_IN_NHWC_U8BGR, F_PLAN_INPUT, F_FUSE_NEXT = 1, 2, 4, 8, 16, 32, 64
 PATH_IGEMM, PATH_STEM, PATH_DIRECT, PATH_STEM_MFMA = 0, 1, 2, 3
 
 

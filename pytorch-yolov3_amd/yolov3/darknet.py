@@ -276,6 +276,8 @@ class Darknet(object):
                 op.ksize, op.stride, op.pad = od["ksize"], od["stride"], od["pad"]
                 if od["leaky"]:
                     op.flags |= _hip.F_LEAKY
+                if od.get("fuse_next"):
+                    op.flags |= _hip.F_FUSE_NEXT
                 if res is not None:
                     op.flags |= _hip.F_RESIDUAL
                 c = self._convs[od["slot"]]

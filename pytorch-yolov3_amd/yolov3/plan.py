@@ -185,7 +185,12 @@ def build_plan(blocks, net_info, batch, height, width, elem_size, reuse=True):
                 res = tensor_of[sc + blocks[sc]["from"]]
             ops.append(dict(kind="conv", block=i, inp=prev_tensor(i), out=out, res=res, ksize=k, stride=s,
                             pad=(k - 1) // 2 if "pad" in blk else 0, leaky=blk["activation"] == "leaky",
-                            slot=conv_slot, bn=bool(blk.get("batch_normalize", 0)), net_input=(i == 0)))
+                            slot=conv_slot, bn=bool(blk.get("batch_normalize", 0)), net_input=(i == 0),
+                            # hint for the executor: the network's first conv feeds the next conv and nobody else,
+                            # so the pair may run as one kernel that never writes this tensor (needs arena reuse
+                            # semantics, i.e. not the keep-every-tensor debugging mode)
+                            fuse_next=bool(reuse and i == 0 and i not in conv_fused and n > 1 and
+                                           kinds[1] == "convolutional" and readers[0] == [(1, "in")])))
             conv_slot += 1
             if i in conv_fused:
                 tensor_of[i] = None                # never materialised

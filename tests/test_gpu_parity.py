@@ -98,7 +98,7 @@ def test_mini_bf16_uint8_stem_matches_bf16_float_stem():
     assert (a["class_idx"] == b["class_idx"]).float().mean() > 0.97
 
 
-DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 21, "halo_persistent": 0}
+DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 21, "halo_persistent": 0, "fuse_stem": 1}
 
 
 def test_tuning_knobs_do_not_change_results():
@@ -323,6 +323,30 @@ def test_wave_specialised_igemm_is_bit_identical():
         lib.y3_set_tuning(b"igemm_version", 2)
         lib.y3_set_tuning(b"igemm_ns", 2)
         lib.y3_set_tuning(b"auto_mask", 21)
+
+
+@pytest.mark.parametrize("dim,batch", [(608, 2), (416, 1), (320, 3)])
+def test_fused_stem_and_stride2_conv_is_bit_identical(dim, batch):
+    """The first two convs of yolov3 / yolov3-spp run as one kernel (uint8 frames -> 32-channel stem kept in LDS ->
+    stride-2 conv); same MFMA sequence per accumulator as the two separate kernels, so every network output must be
+    bit-identical with the fusion switched off."""
+    from yolov3 import _hip
+    lib = _hip.lib()
+    frames = synth_frames(31 + dim, batch, dim, dim)
+    try:
+        _hip.check(lib.y3_set_tuning(b"fuse_stem", 1))
+        net = _net("yolov3", dtype="bf16")
+        fused = {k: v.clone() for k, v in net.forward_frames(frames).items()}
+        names = [r["kernel"] for r in net.plan_report()]
+        assert names[0] == "conv_stem_s2_fused_u8_bf16" and names[1].startswith("(fused")
+        _hip.check(lib.y3_set_tuning(b"fuse_stem", 0))
+        net2 = _net("yolov3", dtype="bf16")
+        plain = net2.forward_frames(frames)
+        assert net2.plan_report()[0]["kernel"] == "conv_stem_mfma_u8_bf16"
+        for k in ("bbox_xywh", "class_prob", "class_idx"):
+            assert torch.equal(fused[k], plain[k]), k
+    finally:
+        lib.y3_set_tuning(b"fuse_stem", 1)
 
 
 def test_bf16_agreement_report_yolov3():
