@@ -9,16 +9,21 @@
 // input bytes and the 189 MB output only.
 //
 // Per tile (persistent workgroups, 8 waves, one per CU):
-//   phase 1  stem: 69 fragments of 16 stem pixels, K = 27 (one v_mfma_f32_16x16x32_bf16 per 16 channels), operands
-//            gathered from the normalised bf16 input patch in LDS exactly like conv_stem_mfma_kernel; result ->
+//   phase 1  stem: 69 fragments of 16 stem pixels.  The input patch is kept as 4 bf16 per pixel (B, G, R, 0), so a
+//            filter row is 12 contiguous elements and a lane's 8 consecutive K values are two aligned 8-byte LDS
+//            reads (k = ky*12 + kx*4 + c; K = 36 padded to 64 = two v_mfma_f32_16x16x32_bf16 steps per 16 channels,
+//            the second one only carrying ky = 2, kx = 2); the zero channel and zero-padded K multiply zero
+//            weights, so sums equal conv_stem_mfma_kernel's (which gathers 27 scalars per lane, 3x the LDS
+//            instructions) up to the order of exact-zero terms; result ->
 //            scale/bias/leaky -> bf16 -> stem image in LDS (80-byte pixel pitch: the stride-2 fragment reads of
 //            phase 2 are then bank-conflict-free); stem pixels outside the frame are the second conv's zero padding
 //   phase 2  stride-2 conv: wave w owns output rows 2w, 2w+1 (2 x 16 pixels) x 64 channels; one MFMA K-step per
 //            filter tap (32 input channels = 64 bytes); weights [64][9][32] live in LDS (608-byte channel pitch)
 //   phase 3  scale/bias/leaky -> bf16 -> staged through LDS (the stem image is dead by then) -> 16-byte NHWC stores
 // The next tile's input patch is fetched into registers during phase 2 and converted into the other patch buffer
-// afterwards, so no phase waits on HBM.  Accumulation order equals the unfused kernels' (tap-major, one MFMA per
-// tap), so the result is bit-identical to conv_stem_mfma_kernel followed by the implicit GEMM.
+// afterwards, so no phase waits on HBM.  Operands, fp32 accumulation and the tap-major order of the second conv equal
+// the unfused kernels'; the stem's 27 products sit at other K positions of the MFMA, so a few stem values differ by
+// one bf16 ulp (tests/test_gpu_parity.py::test_fused_first_two_convs_output).
 #include "common.h"
 
 namespace {
@@ -26,7 +31,7 @@ namespace {
 constexpr int kTO = 16;                 // output tile (second conv) is kTO x kTO
 constexpr int kSR = 2 * kTO + 1;        // stem rows / cols per tile (33)
 constexpr int kIR = kSR + 2;            // input rows / cols per tile (35)
-constexpr int kInPitch = 108;           // bf16 elements per input-patch row (35 * 3 = 105, padded)
+constexpr int kInPitch = 144;           // bf16 elements per input-patch row: 35 pixels x 4 (B, G, R, zero), padded
 constexpr int kStemPitch = 80;          // bytes per stem pixel in LDS (64 used)
 constexpr int kW1Pitch = 608;           // bytes per output channel of the second conv's weights in LDS (576 used)
 constexpr int kNStem = kSR * kSR;       // 1089
@@ -35,7 +40,7 @@ constexpr int kThreads = 512;
 constexpr int kInBytes = kIR * kInPitch * 2;                  // one input patch (bf16)
 constexpr int kPatchElems = kIR * kIR * 3;                    // 3675 bytes of the frame per patch
 constexpr int kPre = (kPatchElems + kThreads - 1) / kThreads; // bytes prefetched per thread (8)
-constexpr int kLds = 2 * kInBytes + kNStem * kStemPitch + 64 * kW1Pitch;
+constexpr int kLds = 2 * kInBytes + kNStem * kStemPitch + 64 * kW1Pitch + 512;   // + 256-entry byte -> bf16 table
 
 struct FusedArgs {
   const unsigned char *in;   // (B, H, W, 3) uint8 BGR
@@ -50,13 +55,27 @@ struct FusedArgs {
   bf16_t *out;
   int out_ld, Ho, Wo;
   int tiles_x, tiles_y, n_tiles;
+  int dbg;   // diagnostic: bit 0 skip phase 1, bit 1 skip phase 2, bit 2 skip phase 3 stores, bit 3 skip patch prefetch
 };
+
+// acc * scale + bias -> LeakyReLU(0.1) -> bf16, four channels at a time; written with 2-wide vectors so that hipcc
+// emits v_pk_fma_f32 / v_pk_mul_f32 (the epilogues are VALU-bound: 35 k stem values per tile)
+__device__ __forceinline__ u32x2 bn_leaky_bf16x4(const f32x4 &a, const f32x4 &sc, const f32x4 &bi) {
+  const f32x2 lo = f32x2{a[0], a[1]} * f32x2{sc[0], sc[1]} + f32x2{bi[0], bi[1]};
+  const f32x2 hi = f32x2{a[2], a[3]} * f32x2{sc[2], sc[3]} + f32x2{bi[2], bi[3]};
+  const f32x2 tl = lo * Y3_LEAKY_SLOPE, th = hi * Y3_LEAKY_SLOPE;
+  const bf16x4 o = {(bf16_t)fmaxf(lo[0], tl[0]), (bf16_t)fmaxf(lo[1], tl[1]), (bf16_t)fmaxf(hi[0], th[0]),
+                    (bf16_t)fmaxf(hi[1], th[1])};
+  return __builtin_bit_cast(u32x2, o);
+}
 
 __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t *in_tile = reinterpret_cast<bf16_t *>(smem);                 // [2][kIR][kInPitch]
   char *stem = smem + 2 * kInBytes;                                    // [kNStem][kStemPitch]
   char *w1s = stem + kNStem * kStemPitch;                              // [64][kW1Pitch]
+  bf16_t *lut = reinterpret_cast<bf16_t *>(w1s + 64 * kW1Pitch);       // lut[v] = bf16(v / 255.0f): one IEEE division per
+                                                                       // table entry instead of one per input byte
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,15 +87,29 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
     *reinterpret_cast<u32x4 *>(w1s + co * kW1Pitch + ch * 16) =
         *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.w1) + ((long long)co * p.k_ld1) * 2 + ch * 16);
   }
-  const bf16x8 w0a = *reinterpret_cast<const bf16x8 *>(p.w0 + (0 + fr) * 32 + fq * 8);
-  const bf16x8 w0b = *reinterpret_cast<const bf16x8 *>(p.w0 + (16 + fr) * 32 + fq * 8);
-  int koff[8];
+  // stem weights re-indexed to k = ky*12 + kx*4 + c (c == 3 and k >= 36: zero); A fragments for both K steps
+  bf16x8 w0a[2], w0b[2];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int k = fq * 8 + j;
-    const int ky = k < 27 ? k / 9 : 0, jj = k < 27 ? k - ky * 9 : 0;   // padded k: any valid element (weight is 0)
-    koff[j] = ky * kInPitch + jj;
+  for (int st = 0; st < 2; ++st)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = st * 32 + fq * 8 + j;
+      const int ky = k / 12, rem = k - ky * 12, kx = rem >> 2, c = rem & 3;
+      const bool live = k < 36 && c < 3;
+      const int kold = live ? ky * 9 + kx * 3 + c : 0;
+      const bf16_t za = p.w0[(0 + fr) * 32 + kold], zb = p.w0[(16 + fr) * 32 + kold];
+      w0a[st][j] = live ? za : (bf16_t)0.f;
+      w0b[st][j] = live ? zb : (bf16_t)0.f;
+    }
+  // element offsets (relative to the pixel's first element in its patch row) of this lane's two 4-element pieces
+  // of K step 0, and of its piece of K step 1 (only fq == 0 carries live values there: ky = 2, kx = 2)
+  int off_lo, off_hi;
+  {
+    const int k0 = fq * 8, k1 = fq * 8 + 4;
+    off_lo = (k0 / 12) * kInPitch + (k0 % 12);
+    off_hi = (k1 / 12) * kInPitch + (k1 % 12);
   }
+  const int off_s1 = 2 * kInPitch + 8;
   const int cq = fq * 4;
   f32x4 sc0[2], bi0[2];
 #pragma unroll
@@ -84,7 +117,6 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
     sc0[ni] = *reinterpret_cast<const f32x4 *>(p.sc0 + ni * 16 + cq);
     bi0[ni] = *reinterpret_cast<const f32x4 *>(p.bi0 + ni * 16 + cq);
   }
-  const bool leaky0 = p.flags0 & Y3_F_LEAKY, leaky1 = p.flags1 & Y3_F_LEAKY;
 
   // bytes of the frame patch of `tile` that this thread converts (kPre strided elements)
   auto patch_fetch = [&](int tile, unsigned char (&pre)[kPre]) {
@@ -111,10 +143,13 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
     for (int j = 0; j < kPre; ++j) {
       const int i = tid + j * kThreads;
       const int r = i / (kIR * 3), cb = i - r * (kIR * 3);
-      if (i < kPatchElems) dst[r * kInPitch + cb] = (bf16_t)((float)pre[j] / 255.0f);
+      if (i < kPatchElems) dst[r * kInPitch + (cb / 3) * 4 + (cb % 3)] = lut[pre[j]];
     }
   };
 
+  for (int i = tid; i < 2 * kIR * kInPitch / 2; i += kThreads) reinterpret_cast<uint32_t *>(in_tile)[i] = 0u;
+  if (tid < 256) lut[tid] = (bf16_t)((float)tid / 255.0f);
+  __syncthreads();   // the fourth channel of every patch pixel stays zero from here on
   int tile = blockIdx.x;
   int buf = 0;
   if (tile < p.n_tiles) {
@@ -133,38 +168,36 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
 
     // ---- phase 1: stem ------------------------------------------------------------------------------
     const bf16_t *patch = in_tile + buf * (kIR * kInPitch);
-    for (int f = wave; f < kNFrag; f += kThreads / 64) {
+    for (int f = wave; f < ((p.dbg & 1) ? 0 : kNFrag); f += kThreads / 64) {
       const int q = f * 16 + fr;
       const int qc = q < kNStem ? q : kNStem - 1;
       const int sy = qc / kSR, sx = qc - sy * kSR;
-      const bf16_t *base = patch + sy * kInPitch + sx * 3;
-      bf16x8 xf;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xf[j] = base[koff[j]];
+      const bf16_t *base = patch + sy * kInPitch + sx * 4;
+      const u32x2 lo = *reinterpret_cast<const u32x2 *>(base + off_lo);
+      const u32x2 hi = *reinterpret_cast<const u32x2 *>(base + off_hi);
+      const u32x2 s1 = *reinterpret_cast<const u32x2 *>(base + off_s1);
+      const bf16x8 xf0 = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+      const bf16x8 xf1 = __builtin_bit_cast(bf16x8, fq == 0 ? u32x4{s1[0], s1[1], 0u, 0u} : u32x4{0u, 0u, 0u, 0u});
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a, xf, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b, xf, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[0], xf0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b[0], xf0, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[1], xf1, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b[1], xf1, acc1, 0, 0, 0);
       const int gy = 2 * oy0 - 1 + sy, gx = 2 * ox0 - 1 + sx;          // stem pixel in frame coordinates
       const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
       if (q < kNStem) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          const f32x4 a = ni ? acc1 : acc0;
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = a[r] * sc0[ni][r] + bi0[ni][r];
-            if (leaky0) v = v > 0.f ? v : Y3_LEAKY_SLOPE * v;
-            o[r] = (bf16_t)(inside ? v : 0.f);
-          }
-          *reinterpret_cast<bf16x4 *>(stem + q * kStemPitch + (ni * 16 + cq) * 2) = o;
+          u32x2 o = bn_leaky_bf16x4(ni ? acc1 : acc0, sc0[ni], bi0[ni]);
+          if (!inside) o = u32x2{0u, 0u};                               // the second conv's zero padding
+          *reinterpret_cast<u32x2 *>(stem + q * kStemPitch + (ni * 16 + cq) * 2) = o;
         }
       }
     }
     // next tile's patch bytes start flying now; they are converted after phase 2
     const int next_tile = tile + gridDim.x;
     unsigned char pre[kPre];
-    if (next_tile < p.n_tiles) patch_fetch(next_tile, pre);
+    if (next_tile < p.n_tiles && !(p.dbg & 8)) patch_fetch(next_tile, pre);
     __syncthreads();   // B2: stem image complete
 
     // ---- phase 2: 3x3 stride-2 conv from the stem image ---------------------------------------------
@@ -174,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) acc[mi][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < ((p.dbg & 2) ? 0 : 9); ++tap) {
       const int ky = tap / 3, kx = tap - ky * 3;
       u32x4 xf[2], wf[4];
 #pragma unroll
@@ -202,16 +235,10 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
       const f32x4 b1 = *reinterpret_cast<const f32x4 *>(p.bi1 + nf * 16 + cq);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[mi][nf][r] * s1[r] + b1[r];
-          if (leaky1) v = v > 0.f ? v : Y3_LEAKY_SLOPE * v;
-          o[r] = (bf16_t)v;
-        }
         const int px = (2 * wave + mi) * kTO + fr;
         const int co = nf * 16 + cq;                                   // 4 consecutive channels
-        *reinterpret_cast<bf16x4 *>(stem + px * 128 + (((co >> 3) ^ (px & 7)) << 4) + (co & 7) * 2) = o;
+        *reinterpret_cast<u32x2 *>(stem + px * 128 + (((co >> 3) ^ (px & 7)) << 4) + (co & 7) * 2) =
+            bn_leaky_bf16x4(acc[mi][nf], s1, b1);
       }
     }
     __syncthreads();   // B4
@@ -220,7 +247,7 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
       const int i = tid + j * kThreads;
       const int px = i >> 3, ch = i & 7;
       const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
-      if (oy < p.Ho && ox < p.Wo) {
+      if (oy < p.Ho && ox < p.Wo && !(p.dbg & 4)) {
         const u32x4 v = *reinterpret_cast<const u32x4 *>(stem + px * 128 + ((ch ^ (px & 7)) << 4));
         *reinterpret_cast<u32x4 *>(p.out + (((long long)b * p.Ho + oy) * p.Wo + ox) * p.out_ld + ch * 8) = v;
       }
@@ -232,11 +259,13 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
 }  // namespace
 
 int g_y3_fuse_stem = 1;   // tuning knob "fuse_stem"
+int g_y3_fuse_dbg = 0;
 
 // op0: the MFMA stem conv (uint8 frames, 3 -> 32, bf16 out); op1: 3x3 stride-2 conv 32 -> 64 reading ONLY op0's output
 bool y3_conv_fused_stem_s2_supported(const y3_op &op0, const y3_op &op1) {
   if (!g_y3_fuse_stem) return false;
   if (!y3_conv_stem_mfma_supported(op0) || op0.out_c != 32 || (op0.flags & Y3_F_RESIDUAL)) return false;
+  if (!(op0.flags & Y3_F_LEAKY) || !(op1.flags & Y3_F_LEAKY)) return false;   // the kernel hard-wires LeakyReLU(0.1)
   if (op1.kind != Y3_OP_CONV || op1.dtype != Y3_BF16 || op1.ksize != 3 || op1.stride != 2 || op1.pad != 1) return false;
   if (op1.in_c != 32 || op1.out_c != 64 || op1.out_ld % 8 != 0 || op1.out_ld < 64) return false;
   if (op1.flags & (Y3_F_RESIDUAL | Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT)) return false;
@@ -263,6 +292,7 @@ int y3_launch_conv_fused_stem_s2(const y3_op &op0, const y3_op &op1, const void 
   a.tiles_x = y3_ceil_div(a.Wo, kTO);
   a.tiles_y = y3_ceil_div(a.Ho, kTO);
   a.n_tiles = a.tiles_x * a.tiles_y * a.batch;
+  a.dbg = g_y3_fuse_dbg;
   static bool attr_set = false;
   static int n_cu = 0;
   if (!attr_set) {

@@ -325,11 +325,65 @@ def test_wave_specialised_igemm_is_bit_identical():
         lib.y3_set_tuning(b"auto_mask", 21)
 
 
+def _first_two_convs_plan(net, frames, fuse, dev):
+    """A two-op plan (stem conv + stride-2 conv of yolov3) built by hand so the second conv's output can be read."""
+    import ctypes
+    from yolov3 import _hip
+    lib = _hip.lib()
+    b, h, w, _ = frames.shape
+    w0 = net._device_weights(0, _hip.PATH_STEM_MFMA, True, dev)
+    w1 = net._device_weights(1, _hip.PATH_IGEMM, True, dev)
+    mid = torch.zeros((b, h, w, 32), dtype=torch.bfloat16, device=dev)
+    out = torch.zeros((b, h // 2, w // 2, 64), dtype=torch.bfloat16, device=dev)
+    zero = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    ops = (_hip.Y3Op * 2)()
+    for op, (wt, cin, cout, k, st) in zip(ops, ((w0, 3, 32, 3, 1), (w1, 32, 64, 3, 2))):
+        op.kind, op.dtype, op.batch = _hip.OP_CONV, _hip.Y3_BF16, b
+        op.ksize, op.stride, op.pad = k, st, 1
+        op.in_c, op.out_c = cin, cout
+        op.cout_pad, op.k_ld = wt["cout_pad"], wt["k_ld"]
+        op.d_weight, op.d_scale, op.d_bias = wt["weight"].data_ptr(), wt["scale"].data_ptr(), wt["bias"].data_ptr()
+        op.flags = _hip.F_LEAKY
+    ops[0].in_h, ops[0].in_w, ops[0].in_ld = h, w, 3
+    ops[0].out_h, ops[0].out_w, ops[0].out_ld = h, w, 32
+    ops[0].flags |= _hip.F_PLAN_INPUT | _hip.F_IN_NHWC_U8BGR | (_hip.F_FUSE_NEXT if fuse else 0)
+    ops[0].d_out = mid.data_ptr()
+    ops[1].in_h, ops[1].in_w, ops[1].in_ld = h, w, 32
+    ops[1].out_h, ops[1].out_w, ops[1].out_ld = h // 2, w // 2, 64
+    ops[1].d_in, ops[1].d_out = mid.data_ptr(), out.data_ptr()
+    ops[1].block_idx = 1
+    handle = ctypes.c_void_p()
+    _hip.check(lib.y3_plan_create(ops, 2, zero.data_ptr(), ctypes.byref(handle)))
+    dfr = torch.from_numpy(frames).to(dev)
+    _hip.check(lib.y3_plan_run(handle, dfr.data_ptr(), _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    name0 = lib.y3_plan_op_kernel(handle, 0).decode()
+    lib.y3_plan_destroy(handle)
+    return out.float().cpu().numpy(), name0
+
+
+@pytest.mark.parametrize("dim,batch", [(608, 1), (96, 2), (80, 1)])
+def test_fused_first_two_convs_output(dim, batch):
+    """Output of the second conv, fused kernel against the two separate kernels, on frames whose borders and tile
+    edges matter (96 = 3 tiles per side at the second conv, 80 = 2.5).  A geometry error would show as O(1)
+    differences; what remains is bf16 rounding of a few stem values."""
+    net = _net("yolov3", dtype="bf16")
+    dev = net._torch_device()
+    frames = synth_frames(77 + dim, batch, dim, dim)
+    fused, n_f = _first_two_convs_plan(net, frames, True, dev)
+    plain, n_p = _first_two_convs_plan(net, frames, False, dev)
+    assert n_f == "conv_stem_s2_fused_u8_bf16" and n_p == "conv_stem_mfma_u8_bf16"
+    scale = np.abs(plain).mean()
+    d = np.abs(fused - plain)
+    assert d.max() <= 0.1 * max(1.0, np.abs(plain).max()) and d.mean() <= 2e-3 * scale, (d.max(), d.mean(), scale)
+    assert (d > 0).mean() < 0.2      # most values identical
+
+
 @pytest.mark.parametrize("dim,batch", [(608, 2), (416, 1), (320, 3)])
-def test_fused_stem_and_stride2_conv_is_bit_identical(dim, batch):
+def test_fused_stem_and_stride2_conv_matches_unfused(dim, batch):
     """The first two convs of yolov3 / yolov3-spp run as one kernel (uint8 frames -> 32-channel stem kept in LDS ->
-    stride-2 conv); same MFMA sequence per accumulator as the two separate kernels, so every network output must be
-    bit-identical with the fusion switched off."""
+    stride-2 conv).  Same bf16 operands and fp32 accumulation as the two separate kernels; only the position of the
+    27 stem products inside the MFMA K dimension differs, so outputs agree to bf16 rounding noise."""
     from yolov3 import _hip
     lib = _hip.lib()
     frames = synth_frames(31 + dim, batch, dim, dim)
@@ -343,8 +397,10 @@ def test_fused_stem_and_stride2_conv_is_bit_identical(dim, batch):
         net2 = _net("yolov3", dtype="bf16")
         plain = net2.forward_frames(frames)
         assert net2.plan_report()[0]["kernel"] == "conv_stem_mfma_u8_bf16"
-        for k in ("bbox_xywh", "class_prob", "class_idx"):
-            assert torch.equal(fused[k], plain[k]), k
+        d = (fused["class_prob"] - plain["class_prob"]).abs()
+        assert float(d.max()) < 0.1 and float(d.median()) < 2e-3, (float(d.max()), float(d.median()))
+        assert float((fused["class_idx"] == plain["class_idx"]).float().mean()) > 0.98
+        torch.testing.assert_close(fused["bbox_xywh"], plain["bbox_xywh"], rtol=5e-2, atol=5e-3)
     finally:
         lib.y3_set_tuning(b"fuse_stem", 1)
 
