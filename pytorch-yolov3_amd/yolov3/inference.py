@@ -102,10 +102,15 @@ class Detector(object):
         """out: Darknet.forward dict (device tensors).  orig_hw: (batch,2) int32 tensor/array."""
         if not isinstance(orig_hw, torch.Tensor):
             orig_hw = torch.from_numpy(np.ascontiguousarray(orig_hw, dtype=np.int32))
-        self.orig_hw.copy_(orig_hw, non_blocking=True)
+        if (orig_hw.device == self.orig_hw.device and orig_hw.dtype == torch.int32 and orig_hw.is_contiguous()
+                and tuple(orig_hw.shape) == (self.batch, 2)):
+            hw = orig_hw                       # already resident: no staging copy on the launch path
+        else:
+            self.orig_hw.copy_(orig_hw, non_blocking=True)
+            hw = self.orig_hw
         bbox, prob, cls = out["bbox_xywh"], out["class_prob"], out["class_idx"]
         _hip.check(_hip.lib().y3_detect(
-            bbox.data_ptr(), prob.data_ptr(), cls.data_ptr(), self.batch, self.rows, self.orig_hw.data_ptr(),
+            bbox.data_ptr(), prob.data_ptr(), cls.data_ptr(), self.batch, self.rows, hw.data_ptr(),
             ctypes.c_float(prob_thresh), ctypes.c_double(iou_thresh), self.ws.data_ptr(), self.ws_bytes,
             self.count.data_ptr(), self.tlbr.data_ptr(), self.prob.data_ptr(), self.cls.data_ptr(),
             self.row.data_ptr(), _hip.stream_ptr()))
