@@ -256,6 +256,201 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// One residual block of Darknet-53 in one kernel, for the block whose 3x3 weights fit in LDS (64 -> 32 -> 64 channels,
+// the 304^2 block of yolov3@608):   z = leaky(bn(conv3x3(leaky(bn(conv1x1(x)))))) + x      (darknet.py:244-257, :376-379;
+// models/yolov3.cfg:41-61).  Separately the 1x1 reads 189 MB and writes 95 MB, the 3x3 reads those 95 MB (9x through
+// L2) plus the 189 MB shortcut operand and writes 189 MB (0.06 + 0.16 ms, both HBM-bound); here a workgroup loads an
+// 18 x 18 x 64 patch of x once, keeps the 1x1's 32-channel output for it in LDS, runs the 3x3 from there and takes the
+// shortcut operand from the same patch: HBM sees x (1.27x for the halo) and z only.
+// Per 16 x 16 output tile (persistent workgroups, 8 waves):  phase A 1x1 over the 324 patch pixels (MFMA, pixels
+// outside the frame give the 3x3's zero padding) -> 96-byte-pitch image;  phase B 3x3, one MFMA K-step per tap, wave w
+// owns output rows 2w, 2w+1;  phase C bn + leaky + shortcut -> bf16 -> staged -> 16-byte NHWC stores.  The next tile's
+// patch is fetched into registers during phase B and written to LDS after phase C.
+constexpr int kRT = 16;                  // output tile
+constexpr int kRP = kRT + 2;             // patch rows / cols (18)
+constexpr int kRNP = kRP * kRP;          // 324 patch pixels
+constexpr int kRFrag = (kRNP + 15) / 16; // 21
+constexpr int kYPitch = 96;              // bytes per pixel of the 1x1's output image (64 used): conflict-free unit-stride reads
+constexpr int kXBytes = kRNP * 128;
+constexpr int kYBytes = 32768;           // >= kRNP * kYPitch, and holds the 256 x 128-byte staging tile
+constexpr int kRLds = kXBytes + kYBytes + 64 * kW1Pitch;
+constexpr int kXPre = (kRNP * 8 + kThreads - 1) / kThreads;   // 16-byte chunks of x prefetched per thread (6)
+static_assert(kRNP * kYPitch <= kYBytes && kRT * kRT * 128 <= kYBytes, "image / staging tile must fit");
+
+struct ResArgs {
+  const bf16_t *x;
+  int H, W, batch, x_ld;
+  const bf16_t *w2; int k_ld2; const float *sc2, *bi2;   // 1x1: [>= 32][k_ld2], k = ci
+  const bf16_t *w3; int k_ld3; const float *sc3, *bi3;   // 3x3: [>= 64][k_ld3], k = (ky*3 + kx)*32 + ci
+  bf16_t *out;
+  int out_ld;
+  int tiles_x, tiles_y, n_tiles;
+};
+
+__global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *xt = smem;                        // [kRNP][128], 16-byte chunks XOR-swizzled with (pixel & 7)
+  char *yt = smem + kXBytes;              // [kRNP][kYPitch]; later the staging tile
+  char *w3s = yt + kYBytes;               // [64][kW1Pitch]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4, cq = fq * 4;
+
+  for (int i = tid; i < 64 * 36; i += kThreads) {
+    const int co = i / 36, ch = i - co * 36;
+    *reinterpret_cast<u32x4 *>(w3s + co * kW1Pitch + ch * 16) =
+        *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.w3) + ((long long)co * p.k_ld3) * 2 + ch * 16);
+  }
+  // 1x1 weights: A fragments [co-frag][K step], lane (co = fr, k = ks*32 + fq*8 ..)
+  u32x4 w2f[2][2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      w2f[ni][ks] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.w2) +
+                                                    ((long long)(ni * 16 + fr) * p.k_ld2 + ks * 32 + fq * 8) * 2);
+  f32x4 sc2[2], bi2[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    sc2[ni] = *reinterpret_cast<const f32x4 *>(p.sc2 + ni * 16 + cq);
+    bi2[ni] = *reinterpret_cast<const f32x4 *>(p.bi2 + ni * 16 + cq);
+  }
+
+  auto tile_origin = [&](int tile, int &b, int &oy0, int &ox0) {
+    const int tx = tile % p.tiles_x;
+    tile /= p.tiles_x;
+    oy0 = (tile % p.tiles_y) * kRT;
+    b = tile / p.tiles_y;
+    ox0 = tx * kRT;
+  };
+  auto x_fetch = [&](int tile, u32x4 (&pre)[kXPre]) {
+    int b, oy0, ox0;
+    tile_origin(tile, b, oy0, ox0);
+#pragma unroll
+    for (int j = 0; j < kXPre; ++j) {
+      const int i = tid + j * kThreads;
+      const int px = i >> 3, c = i & 7;
+      const int r = px / kRP, cc = px - r * kRP;
+      const int gy = oy0 - 1 + r, gx = ox0 - 1 + cc;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (i < kRNP * 8 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+        v = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.x) +
+                                             ((((long long)b * p.H + gy) * p.W + gx) * p.x_ld) * 2 + c * 16);
+      pre[j] = v;
+    }
+  };
+  auto x_store = [&](const u32x4 (&pre)[kXPre]) {
+#pragma unroll
+    for (int j = 0; j < kXPre; ++j) {
+      const int i = tid + j * kThreads;
+      const int px = i >> 3, c = i & 7;
+      if (i < kRNP * 8) *reinterpret_cast<u32x4 *>(xt + px * 128 + ((c ^ (px & 7)) << 4)) = pre[j];
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < p.n_tiles) {
+    u32x4 pre[kXPre];
+    x_fetch(tile, pre);
+    x_store(pre);
+  }
+  for (; tile < p.n_tiles; tile += gridDim.x) {
+    int b, oy0, ox0;
+    tile_origin(tile, b, oy0, ox0);
+    __syncthreads();   // B1: x patch (and, first time, the weights) in LDS; image / staging region free
+
+    // ---- phase A: 1x1 conv over the patch ------------------------------------------------------------
+    for (int f = wave; f < kRFrag; f += kThreads / 64) {
+      const int q = f * 16 + fr;
+      const int qc = q < kRNP ? q : kRNP - 1;
+      const u32x4 xa = *reinterpret_cast<const u32x4 *>(xt + qc * 128 + (((0 + fq) ^ (qc & 7)) << 4));
+      const u32x4 xb = *reinterpret_cast<const u32x4 *>(xt + qc * 128 + (((4 + fq) ^ (qc & 7)) << 4));
+      const int r = qc / kRP, cc = qc - r * kRP;
+      const bool inside = (unsigned)(oy0 - 1 + r) < (unsigned)p.H && (unsigned)(ox0 - 1 + cc) < (unsigned)p.W;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2f[ni][0]), __builtin_bit_cast(bf16x8, xa), a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2f[ni][1]), __builtin_bit_cast(bf16x8, xb), a, 0, 0, 0);
+        u32x2 o = bn_leaky_bf16x4(a, sc2[ni], bi2[ni]);
+        if (!inside) o = u32x2{0u, 0u};                                  // the 3x3's zero padding
+        if (q < kRNP) *reinterpret_cast<u32x2 *>(yt + q * kYPitch + (ni * 16 + cq) * 2) = o;
+      }
+    }
+    const int next_tile = tile + gridDim.x;
+    u32x4 pre[kXPre];
+    if (next_tile < p.n_tiles) x_fetch(next_tile, pre);
+    __syncthreads();   // B2: image complete
+
+    // ---- phase B: 3x3 stride-1 conv from the image -----------------------------------------------------
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) acc[mi][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      u32x4 xf[2], wf[4];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int q = (2 * wave + mi + ky) * kRP + fr + kx;
+        xf[mi] = *reinterpret_cast<const u32x4 *>(yt + q * kYPitch + fq * 16);
+      }
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+        wf[nf] = *reinterpret_cast<const u32x4 *>(w3s + (nf * 16 + fr) * kW1Pitch + tap * 64 + fq * 16);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+          acc[mi][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[nf]),
+                                                                __builtin_bit_cast(bf16x8, xf[mi]), acc[mi][nf], 0, 0, 0);
+    }
+    __syncthreads();   // B3: nobody reads the image any more
+
+    // ---- phase C: bn + leaky, + shortcut operand from the x patch, -> bf16 -> staging ----------------------
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const f32x4 s3 = *reinterpret_cast<const f32x4 *>(p.sc3 + nf * 16 + cq);
+      const f32x4 b3 = *reinterpret_cast<const f32x4 *>(p.bi3 + nf * 16 + cq);
+      const int co = nf * 16 + cq;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int oyl = 2 * wave + mi;
+        const int pp = (oyl + 1) * kRP + fr + 1;                          // this output pixel inside the patch
+        const u32x2 xr = *reinterpret_cast<const u32x2 *>(xt + pp * 128 + (((co >> 3) ^ (pp & 7)) << 4) + (co & 7) * 2);
+        const bf16x4 xv = __builtin_bit_cast(bf16x4, xr);
+        const f32x4 a = acc[mi][nf];
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = a[r] * s3[r] + b3[r];
+          v = fmaxf(v, Y3_LEAKY_SLOPE * v);
+          o[r] = (bf16_t)(v + (float)xv[r]);
+        }
+        const int px = oyl * kRT + fr;
+        *reinterpret_cast<bf16x4 *>(yt + px * 128 + (((co >> 3) ^ (px & 7)) << 4) + (co & 7) * 2) = o;
+      }
+    }
+    __syncthreads();   // B4: staging complete; the x patch is dead
+#pragma unroll
+    for (int j = 0; j < kRT * kRT * 8 / kThreads; ++j) {
+      const int i = tid + j * kThreads;
+      const int px = i >> 3, ch = i & 7;
+      const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+      if (oy < p.H && ox < p.W) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(yt + px * 128 + ((ch ^ (px & 7)) << 4));
+        *reinterpret_cast<u32x4 *>(p.out + (((long long)b * p.H + oy) * p.W + ox) * p.out_ld + ch * 8) = v;
+      }
+    }
+    if (next_tile < p.n_tiles) x_store(pre);
+  }
+}
+
 }  // namespace
 
 int g_y3_fuse_stem = 1;   // tuning knob "fuse_stem"
@@ -305,6 +500,54 @@ int y3_launch_conv_fused_stem_s2(const y3_op &op0, const y3_op &op1, const void 
   }
   const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
   hipLaunchKernelGGL(conv_stem_s2_fused_kernel, dim3(grid), dim3(kThreads), kLds, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+// op0: 1x1 conv 64 -> 32 whose output only op1 reads; op1: 3x3 stride-1 conv 32 -> 64 with the shortcut operand == op0's
+// input (one Darknet-53 residual block, bf16, LeakyReLU on both)
+bool y3_conv_fused_resblock_supported(const y3_op &op0, const y3_op &op1) {
+  if (!g_y3_fuse_stem) return false;
+  if (op0.kind != Y3_OP_CONV || op1.kind != Y3_OP_CONV || op0.dtype != Y3_BF16 || op1.dtype != Y3_BF16) return false;
+  if (op0.ksize != 1 || op0.stride != 1 || op0.in_c != 64 || op0.out_c != 32) return false;
+  if (op1.ksize != 3 || op1.stride != 1 || op1.pad != 1 || op1.in_c != 32 || op1.out_c != 64) return false;
+  const uint32_t bad = Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT;
+  if ((op0.flags & (bad | Y3_F_RESIDUAL)) || (op1.flags & bad)) return false;
+  if (!(op0.flags & Y3_F_LEAKY) || !(op1.flags & Y3_F_LEAKY) || !(op1.flags & Y3_F_RESIDUAL)) return false;
+  if (op1.d_in != op0.d_out || op1.d_res != op0.d_in || op1.res_ld != op0.in_ld) return false;
+  if (op0.in_h != op1.in_h || op0.in_w != op1.in_w || op0.batch != op1.batch) return false;
+  if (op0.out_h != op0.in_h || op0.out_w != op0.in_w || op1.out_h != op1.in_h || op1.out_w != op1.in_w) return false;
+  if (op0.in_ld % 8 != 0 || op1.out_ld % 8 != 0 || op0.in_ld < 64 || op1.out_ld < 64) return false;
+  if (op0.k_ld < 64 || op1.k_ld < 288 || op0.cout_pad < 32 || op1.cout_pad < 64) return false;
+  return true;
+}
+
+int y3_launch_conv_fused_resblock(const y3_op &op0, const y3_op &op1, hipStream_t s, const char **kernel_name,
+                                  bool dry_run) {
+  *kernel_name = "conv_resblock_fused_bf16_64_32_64";
+  if (dry_run) return Y3_OK;
+  ResArgs a;
+  a.x = static_cast<const bf16_t *>(op0.d_in);
+  a.H = op0.in_h; a.W = op0.in_w; a.batch = op0.batch; a.x_ld = op0.in_ld;
+  a.w2 = static_cast<const bf16_t *>(op0.d_weight); a.k_ld2 = op0.k_ld; a.sc2 = op0.d_scale; a.bi2 = op0.d_bias;
+  a.w3 = static_cast<const bf16_t *>(op1.d_weight); a.k_ld3 = op1.k_ld; a.sc3 = op1.d_scale; a.bi3 = op1.d_bias;
+  a.out = static_cast<bf16_t *>(op1.d_out);
+  a.out_ld = op1.out_ld;
+  a.tiles_x = y3_ceil_div(a.W, kRT);
+  a.tiles_y = y3_ceil_div(a.H, kRT);
+  a.n_tiles = a.tiles_x * a.tiles_y * a.batch;
+  static bool attr_set = false;
+  static int n_cu = 0;
+  if (!attr_set) {
+    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_resblock_fused_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kRLds));
+    int dev = 0;
+    Y3_HIP_CHECK(hipGetDevice(&dev));
+    Y3_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    attr_set = true;
+  }
+  const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
+  hipLaunchKernelGGL(conv_resblock_fused_kernel, dim3(grid), dim3(kThreads), kRLds, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }

@@ -186,11 +186,12 @@ def build_plan(blocks, net_info, batch, height, width, elem_size, reuse=True):
             ops.append(dict(kind="conv", block=i, inp=prev_tensor(i), out=out, res=res, ksize=k, stride=s,
                             pad=(k - 1) // 2 if "pad" in blk else 0, leaky=blk["activation"] == "leaky",
                             slot=conv_slot, bn=bool(blk.get("batch_normalize", 0)), net_input=(i == 0),
-                            # hint for the executor: the network's first conv feeds the next conv and nobody else,
-                            # so the pair may run as one kernel that never writes this tensor (needs arena reuse
-                            # semantics, i.e. not the keep-every-tensor debugging mode)
-                            fuse_next=bool(reuse and i == 0 and i not in conv_fused and n > 1 and
-                                           kinds[1] == "convolutional" and readers[0] == [(1, "in")])))
+                            # hint for the executor: the next op is a conv and the ONLY reader of this conv's
+                            # output, so the pair may run as one kernel that never writes this tensor (stem + stride-2
+                            # conv, 1x1 + 3x3 of a residual block); needs arena reuse semantics, i.e. not the
+                            # keep-every-tensor debugging mode.  Whether a fused kernel exists is the executor's call.
+                            fuse_next=bool(reuse and i not in conv_fused and i + 1 < n and
+                                           kinds[i + 1] == "convolutional" and readers[i] == [(i + 1, "in")])))
             conv_slot += 1
             if i in conv_fused:
                 tensor_of[i] = None                # never materialised

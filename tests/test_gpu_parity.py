@@ -325,6 +325,55 @@ def test_wave_specialised_igemm_is_bit_identical():
         lib.y3_set_tuning(b"auto_mask", 21)
 
 
+def _resblock_plan(net, x, fuse, dev):
+    """1x1 (64 -> 32) + 3x3 (32 -> 64) + shortcut of yolov3's first residual block as a hand-built two-op plan."""
+    import ctypes
+    from yolov3 import _hip
+    lib = _hip.lib()
+    b, h, w, _ = x.shape
+    w2 = net._device_weights(2, _hip.PATH_IGEMM, True, dev)
+    w3 = net._device_weights(3, _hip.PATH_IGEMM, True, dev)
+    mid = torch.zeros((b, h, w, 32), dtype=torch.bfloat16, device=dev)
+    out = torch.zeros((b, h, w, 64), dtype=torch.bfloat16, device=dev)
+    zero = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    ops = (_hip.Y3Op * 2)()
+    for op, (wt, cin, cout, k) in zip(ops, ((w2, 64, 32, 1), (w3, 32, 64, 3))):
+        op.kind, op.dtype, op.batch = _hip.OP_CONV, _hip.Y3_BF16, b
+        op.ksize, op.stride, op.pad = k, 1, (k - 1) // 2
+        op.in_c, op.out_c, op.in_ld, op.out_ld = cin, cout, cin, cout
+        op.in_h = op.out_h = h
+        op.in_w = op.out_w = w
+        op.cout_pad, op.k_ld = wt["cout_pad"], wt["k_ld"]
+        op.d_weight, op.d_scale, op.d_bias = wt["weight"].data_ptr(), wt["scale"].data_ptr(), wt["bias"].data_ptr()
+        op.flags = _hip.F_LEAKY
+    ops[0].d_in, ops[0].d_out = x.data_ptr(), mid.data_ptr()
+    ops[0].flags |= _hip.F_FUSE_NEXT if fuse else 0
+    ops[1].d_in, ops[1].d_out, ops[1].d_res, ops[1].res_ld = mid.data_ptr(), out.data_ptr(), x.data_ptr(), 64
+    ops[1].flags |= _hip.F_RESIDUAL
+    ops[1].block_idx = 1
+    handle = ctypes.c_void_p()
+    _hip.check(lib.y3_plan_create(ops, 2, zero.data_ptr(), ctypes.byref(handle)))
+    _hip.check(lib.y3_plan_run(handle, None, _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    name0 = lib.y3_plan_op_kernel(handle, 0).decode()
+    lib.y3_plan_destroy(handle)
+    return out, name0
+
+
+@pytest.mark.parametrize("dim,batch", [(304, 1), (48, 2), (40, 3)])
+def test_fused_residual_block_is_bit_identical(dim, batch):
+    """One kernel for 1x1 + 3x3 + shortcut (64 -> 32 -> 64): same operands, MFMA order and epilogue arithmetic as the
+    two implicit-GEMM launches, so the block's output must match bit for bit (40 = 2.5 tiles per side)."""
+    net = _net("yolov3", dtype="bf16")
+    dev = net._torch_device()
+    g = torch.Generator().manual_seed(dim)
+    x = (torch.randn((batch, dim, dim, 64), generator=g) * 0.7).to(torch.bfloat16).to(dev)
+    fused, n_f = _resblock_plan(net, x, True, dev)
+    plain, n_p = _resblock_plan(net, x, False, dev)
+    assert n_f == "conv_resblock_fused_bf16_64_32_64" and n_p.startswith("conv_igemm2")
+    assert torch.equal(fused, plain), float((fused.float() - plain.float()).abs().max())
+
+
 def _first_two_convs_plan(net, frames, fuse, dev):
     """A two-op plan (stem conv + stride-2 conv of yolov3) built by hand so the second conv's output can be read."""
     import ctypes
