@@ -26,7 +26,8 @@ namespace {
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
 constexpr int kIt = 8;          // 1024-row chunks handled per compaction pass (kIt * kWaves == 128)
-constexpr int kLdsSort = 4096;  // elements sorted in LDS; larger frames sort in global memory
+constexpr int kLdsSort = 4096;
+constexpr int kMaxFlags = 1024;  // chunk flags in LDS; classes beyond that run on one wave  // elements sorted in LDS; larger frames sort in global memory
 
 struct DetectArgs {
   // forward-output mode
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(kThreads) void detect_kernel(DetectArgs p) {
   __shared__ unsigned int spos[kLdsSort];
   __shared__ int wave_tot[kWaves];
   __shared__ int chunk_tot[kIt * kWaves];
-  __shared__ int nseg_sh;
+  __shared__ int nitem_sh, nflag_sh;
+  __shared__ int flags_sh[kMaxFlags];   // "chunk is final" flags of classes that span several chunks
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(kThreads) void detect_kernel(DetectArgs p) {
   unsigned long long *s_key = p.s_key + (long long)b * p.rows_p2;
   unsigned int *s_pos = p.s_pos + (long long)b * p.rows_p2;
   unsigned char *keep = p.keep + (long long)b * R;
-  int *seg = p.seg + (long long)b * R;
+  int *seg = p.seg + (long long)b * (R + R / 64 + 2) * 4;
 
   // ---- phase 1: threshold + ordered compaction + scale / truncate / corners -----------------
   int n = 0;
@@ -287,29 +289,50 @@ __global__ __launch_bounds__(kThreads) void detect_kernel(DetectArgs p) {
         __syncthreads();
       }
   }
-  if (tid == 0) nseg_sh = 0;
+  if (tid == 0) { nitem_sh = 0; nflag_sh = 0; }
+  for (int i = tid; i < kMaxFlags; i += kThreads) flags_sh[i] = 0;
   __syncthreads();
 
-  // ---- phase 3: class segments ---------------------------------------------------------------
+  // ---- phase 3: class segments -> work items -----------------------------------------------------
+  // A class of nc candidates is nch = ceil(nc / 64) chunks in score order.  Chunk j needs the survivors of chunks
+  // 0..j-1, so chunks of one class form a dependency chain; the chain's links are handed to different wavefronts
+  // (item index mod 16) and synchronise through per-chunk "final" flags in LDS: while one wave runs chunk j's
+  // in-chunk greedy pass, the others are already suppressing their own chunks with the survivors of chunks < j.
+  // (A frame whose candidates nearly all share one class -- the bench regime -- was serial on ONE wave before.)
+  // item = {segment start, segment end, chunk j or -1 = whole segment on one wave, first flag of the segment}
+  int *items = seg;
   for (int i = tid; i < n; i += kThreads) {
     const unsigned int c = (unsigned int)(s_key[i] >> 32);
-    if (i == 0 || (unsigned int)(s_key[i - 1] >> 32) != c) seg[atomicAdd(&nseg_sh, 1)] = i;
+    if (i == 0 || (unsigned int)(s_key[i - 1] >> 32) != c) {
+      int lo = i + 1, hi = n;  // first index in (i, n] whose class differs
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((unsigned int)(s_key[mid] >> 32) == c) lo = mid + 1; else hi = mid;
+      }
+      const int nch = (lo - i + 63) >> 6;
+      int fb = -1;
+      if (nch > 1) {
+        fb = atomicAdd(&nflag_sh, nch);
+        if (fb + nch > kMaxFlags) fb = -1;            // out of flags: this class runs on one wave (as before)
+      }
+      const int cnt = fb >= 0 ? nch : 1;
+      const int i0 = atomicAdd(&nitem_sh, cnt);
+      for (int j = 0; j < cnt; ++j) {
+        items[(i0 + j) * 4 + 0] = i;
+        items[(i0 + j) * 4 + 1] = lo;
+        items[(i0 + j) * 4 + 2] = fb >= 0 ? j : -1;
+        items[(i0 + j) * 4 + 3] = fb;
+      }
+    }
   }
   __syncthreads();
-  const int nseg = nseg_sh;
+  const int nitem = nitem_sh;
 
-  // ---- phase 4: greedy NMS, one wavefront per class segment ----------------------------------
+  // ---- phase 4: greedy NMS --------------------------------------------------------------------------
   const double thr_m = fabs(p.iou_thresh) * 2.3e-16;
-  for (int s = wave; s < nseg; s += kWaves) {
-    const int start = seg[s];
-    const unsigned int c = (unsigned int)(s_key[start] >> 32);
-    int lo = start + 1, hi = n;  // first index in (start, n] whose class differs
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((unsigned int)(s_key[mid] >> 32) == c) lo = mid + 1; else hi = mid;
-    }
-    const int end = lo;
-    for (int c0 = start; c0 < end; c0 += 64) {
+  // one 64-candidate chunk of a class: suppress by the survivors of the earlier chunks, then greedy inside
+  auto do_chunk = [&](int start, int end, int j, int fb) {
+      const int c0 = start + 64 * j;
       const int idx = c0 + lane;
       const bool valid = idx < end;
       long long x1 = 0, y1 = 0, x2 = 0, y2 = 0;
@@ -324,7 +347,12 @@ __global__ __launch_bounds__(kThreads) void detect_kernel(DetectArgs p) {
       const int iarea = (ix2 - ix1 + 1) * (iy2 - iy1 + 1);
       bool dead = !valid;
       // survivors of earlier chunks of this class
-      for (int p0 = start; p0 < c0; p0 += 64) {
+      for (int jj = 0; jj < j; ++jj) {
+        if (fb >= 0) {
+          while (__hip_atomic_load(&flags_sh[fb + jj], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0)
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const int p0 = start + 64 * jj;
         unsigned long long kept = __ballot(keep[p0 + lane] != 0);
         if (kept == 0ull) continue;
         const long long *qp = c_box + (long long)s_pos[p0 + lane] * 4;
@@ -369,23 +397,38 @@ __global__ __launch_bounds__(kThreads) void detect_kernel(DetectArgs p) {
           alive &= ~__ballot(lane > k && hit);
         }
       } else {
-      for (int k = 0; k < 64; ++k) {
-        if (!((alive >> k) & 1ull)) continue;  // wave-uniform
-        const long long ax1 = shfl_ll(x1, k), ay1 = shfl_ll(y1, k);
-        const long long ax2 = shfl_ll(x2, k), ay2 = shfl_ll(y2, k);
-        const long long aarea = (ax2 - ax1 + 1) * (ay2 - ay1 + 1);
-        long long iw = (ax2 < x2 ? ax2 : x2) - (ax1 > x1 ? ax1 : x1) + 1;
-        long long ih = (ay2 < y2 ? ay2 : y2) - (ay1 > y1 ? ay1 : y1) + 1;
-        iw = iw > 0 ? iw : 0;
-        ih = ih > 0 ? ih : 0;
-        const long long inter = iw * ih;
-        const double iou = (double)inter / (double)(aarea + area - inter);
-        const bool hit = lane > k && (iou > p.iou_thresh);
-        alive &= ~__ballot(hit);
-      }
+        for (int k = 0; k < 64; ++k) {
+          if (!((alive >> k) & 1ull)) continue;  // wave-uniform
+          const long long ax1 = shfl_ll(x1, k), ay1 = shfl_ll(y1, k);
+          const long long ax2 = shfl_ll(x2, k), ay2 = shfl_ll(y2, k);
+          const long long aarea = (ax2 - ax1 + 1) * (ay2 - ay1 + 1);
+          long long iw = (ax2 < x2 ? ax2 : x2) - (ax1 > x1 ? ax1 : x1) + 1;
+          long long ih = (ay2 < y2 ? ay2 : y2) - (ay1 > y1 ? ay1 : y1) + 1;
+          iw = iw > 0 ? iw : 0;
+          ih = ih > 0 ? ih : 0;
+          const long long inter = iw * ih;
+          const double iou = (double)inter / (double)(aarea + area - inter);
+          const bool hit = lane > k && (iou > p.iou_thresh);
+          alive &= ~__ballot(hit);
+        }
       }
       if (valid) keep[idx] = (alive >> lane) & 1ull ? 1 : 0;
-      __threadfence_block();  // later chunks of this wavefront read these flags
+      // publish: the flags of this chunk's survivors first, then (release) the chunk's "final" flag -- every lane
+      // stores the same word (no lane-dependent branch inside a loop that uses cross-lane reads)
+      if (fb >= 0) __hip_atomic_store(&flags_sh[fb + j], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else __threadfence_block();  // later chunks of this wavefront read these flags
+  };
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  for (int it = wave_u; it < nitem; it += kWaves) {
+    const int start = __builtin_amdgcn_readfirstlane(items[it * 4 + 0]);
+    const int end = __builtin_amdgcn_readfirstlane(items[it * 4 + 1]);
+    const int j = __builtin_amdgcn_readfirstlane(items[it * 4 + 2]);
+    const int fb = __builtin_amdgcn_readfirstlane(items[it * 4 + 3]);
+    if (j >= 0) {
+      do_chunk(start, end, j, fb);
+    } else {
+      const int nch = (end - start + 63) >> 6;
+      for (int jj = 0; jj < nch; ++jj) do_chunk(start, end, jj, -1);
     }
   }
   __syncthreads();
@@ -469,7 +512,7 @@ WsLayout ws_layout(int batch, int rows) {
   w.key = off; off = align_up(off + B * P * sizeof(unsigned long long));
   w.pos = off; off = align_up(off + B * P * sizeof(unsigned int));
   w.keep = off; off = align_up(off + B * R);
-  w.seg = off; off = align_up(off + B * R * sizeof(int));
+  w.seg = off; off = align_up(off + B * (R + R / 64 + 2) * 4 * sizeof(int));   // work items: 4 ints each, <= R/64 + #classes
   w.total = off;
   return w;
 }
