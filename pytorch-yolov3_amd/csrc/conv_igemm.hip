@@ -940,6 +940,7 @@ extern "C" int y3_set_tuning(const char *key, int value) {
   if (!strcmp(key, "igemm_ns")) { g_igemm_ns = value; return Y3_OK; }
   if (!strcmp(key, "auto_mask")) { g_y3_auto_mask = value; return Y3_OK; }
   if (!strcmp(key, "halo_persistent")) { g_y3_halo_persistent = value; return Y3_OK; }
+  if (!strcmp(key, "decode_lanes")) { extern int g_y3_decode_lanes; g_y3_decode_lanes = value; return Y3_OK; }
   if (!strcmp(key, "fuse_dbg")) { extern int g_y3_fuse_dbg; g_y3_fuse_dbg = value; return Y3_OK; }
   if (!strcmp(key, "fuse_stem")) { g_y3_fuse_stem = value; return Y3_OK; }   // takes effect at y3_plan_create
   y3_set_error("y3_set_tuning: unknown key %s", key);

@@ -35,14 +35,21 @@ __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + e
 // (stride n_attr floats between threads) spread over the banks.
 constexpr int kPix = 32;
 
-__global__ __launch_bounds__(256) void yolo_decode_kernel(YoloArgs p) {
+// LANES threads per box.  LANES == 1: the reference's sequential class loop (float32 parity path).  LANES == 4
+// (bf16 throughput mode): the class range is split over four adjacent lanes -- maxima, exp-sums and the arg-max are
+// combined with xor-shuffles -- which quadruples the threads working out of the same LDS tile (the staging tile, not
+// registers, bounds the boxes in flight per CU); the exp-sum is then a tree of four partial sums instead of one
+// running sum, i.e. equal up to float32 rounding of the sum's last bits.
+template <int LANES>
+__global__ __launch_bounds__(LANES == 1 ? 256 : 384) void yolo_decode_kernel(YoloArgs p) {
+  constexpr int NT = LANES == 1 ? 256 : 384;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lds_ld = p.ld + 1;
   const long long npix = (long long)p.B * p.h * p.w;
   const long long pix0 = (long long)blockIdx.x * kPix;
   const int chunks_per_pix = p.ld >> 2;
   const int nchunks = kPix * chunks_per_pix;
-  for (int c = threadIdx.x; c < nchunks; c += 256) {
+  for (int c = threadIdx.x; c < nchunks; c += NT) {
     const int pl = c / chunks_per_pix, c4 = c - pl * chunks_per_pix;
     if (pix0 + pl < npix) {
       const f32x4 v = *reinterpret_cast<const f32x4 *>(p.in + (pix0 + pl) * p.ld + c4 * 4);
@@ -52,27 +59,31 @@ __global__ __launch_bounds__(256) void yolo_decode_kernel(YoloArgs p) {
   }
   __syncthreads();
   const int nbox = kPix * p.n_anchor;
-  for (int t = threadIdx.x; t < nbox; t += 256) {
-    const int pl = t / p.n_anchor, a = t - pl * p.n_anchor;
+  // (all lanes of a box group stay in the loop together: nbox * LANES is a multiple of LANES and the shuffles below
+  // only pair lanes of one group)
+  for (int t = threadIdx.x; t < nbox * LANES; t += NT) {
+    const int box = t / LANES, sub = t - box * LANES;
+    const int pl = box / p.n_anchor, a = box - pl * p.n_anchor;
     const long long pix = pix0 + pl;
-    if (pix >= npix) continue;
-    const int x = (int)(pix % p.w);
-    const int y = (int)((pix / p.w) % p.h);
-    const int b = (int)(pix / ((long long)p.w * p.h));
+    const bool live = pix < npix;
+    const long long pixc = live ? pix : npix - 1;
+    const int x = (int)(pixc % p.w);
+    const int y = (int)((pixc / p.w) % p.h);
+    const int b = (int)(pixc / ((long long)p.w * p.h));
     const float *t_ = sm + pl * lds_ld + a * p.n_attr;
 
-    const float bx = (sigmoidf_ref(t_[0]) + (float)x) / (float)p.w;
-    const float by = (sigmoidf_ref(t_[1]) + (float)y) / (float)p.h;
-    const float bw = (expf(t_[2]) * p.aw[a]) / p.net_w;
-    const float bh = (expf(t_[3]) * p.ah[a]) / p.net_h;
-    const float obj = sigmoidf_ref(t_[4]);
-
     const int ncls = p.n_attr - 5;
+    const int per = (ncls + LANES - 1) / LANES;
+    const int c_lo = sub * per, c_hi = c_lo + per < ncls ? c_lo + per : ncls;
     float mx = -INFINITY;
-    for (int c = 0; c < ncls; ++c) mx = fmaxf(mx, t_[5 + c]);
+    for (int c = c_lo; c < c_hi; ++c) mx = fmaxf(mx, t_[5 + c]);
+    if constexpr (LANES == 4) {
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    }
     float sum = 0.f, best = -1.f;
     int best_c = 0;
-    for (int c = 0; c < ncls; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
       const float e = expf(t_[5 + c] - mx);
       sum += e;
       if (e > best) {  // strict: first index wins ties, like torch.max
@@ -80,6 +91,24 @@ __global__ __launch_bounds__(256) void yolo_decode_kernel(YoloArgs p) {
         best_c = c;
       }
     }
+    if constexpr (LANES == 4) {
+#pragma unroll
+      for (int d = 1; d <= 2; d <<= 1) {
+        const float os = __shfl_xor(sum, d, 64), ob = __shfl_xor(best, d, 64);
+        const int oc = __shfl_xor(best_c, d, 64);
+        sum += os;                                       // both partners add the same two numbers: same result
+        if (ob > best || (ob == best && oc < best_c)) {  // lower class index wins ties
+          best = ob;
+          best_c = oc;
+        }
+      }
+    }
+    if (!live || sub != 0) continue;
+    const float bx = (sigmoidf_ref(t_[0]) + (float)x) / (float)p.w;
+    const float by = (sigmoidf_ref(t_[1]) + (float)y) / (float)p.h;
+    const float bw = (expf(t_[2]) * p.aw[a]) / p.net_w;
+    const float bh = (expf(t_[3]) * p.ah[a]) / p.net_h;
+    const float obj = sigmoidf_ref(t_[4]);
     const float score = (best / sum) * obj;
 
     const long long row = (long long)b * p.rows_total + p.row_offset + (long long)a * p.h * p.w + (long long)y * p.w + x;
@@ -90,6 +119,8 @@ __global__ __launch_bounds__(256) void yolo_decode_kernel(YoloArgs p) {
 }
 
 }  // namespace
+
+int g_y3_decode_lanes = 4;   // tuning knob "decode_lanes" (1 = sequential class loop everywhere)
 
 int y3_launch_yolo(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
                    bool dry_run) {
@@ -112,7 +143,10 @@ int y3_launch_yolo(const y3_op &op, const void *d_in, hipStream_t s, const char 
   if (dry_run) return Y3_OK;
   const long long npix = (long long)op.batch * op.in_h * op.in_w;
   const size_t lds = (size_t)kPix * (op.in_ld + 1) * sizeof(float);
-  hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)((npix + kPix - 1) / kPix)), dim3(256), lds, s, a);
+  const dim3 grid((unsigned)((npix + kPix - 1) / kPix));
+  // bf16 networks (throughput mode) take the four-lanes-per-box form; float32 networks keep the sequential class loop
+  if (op.dtype == Y3_BF16 && g_y3_decode_lanes != 1) hipLaunchKernelGGL(yolo_decode_kernel<4>, grid, dim3(384), lds, s, a);
+  else hipLaunchKernelGGL(yolo_decode_kernel<1>, grid, dim3(256), lds, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }

@@ -98,7 +98,7 @@ def test_mini_bf16_uint8_stem_matches_bf16_float_stem():
     assert (a["class_idx"] == b["class_idx"]).float().mean() > 0.97
 
 
-DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 21, "halo_persistent": 0, "fuse_stem": 1}
+DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 21, "halo_persistent": 0, "fuse_stem": 1, "decode_lanes": 4}
 
 
 def test_tuning_knobs_do_not_change_results():
@@ -452,6 +452,26 @@ def test_fused_stem_and_stride2_conv_matches_unfused(dim, batch):
         torch.testing.assert_close(fused["bbox_xywh"], plain["bbox_xywh"], rtol=5e-2, atol=5e-3)
     finally:
         lib.y3_set_tuning(b"fuse_stem", 1)
+
+
+def test_split_class_decode_matches_sequential_decode():
+    """bf16 networks decode every box with four lanes (class range split, shuffle-combined); against the sequential
+    class loop of the float32 path on the same head tensors: identical arg-max, scores equal to float32 rounding of
+    the exp-sum, boxes identical."""
+    from yolov3 import _hip
+    lib = _hip.lib()
+    frames = synth_frames(91, 2, 416, 416)
+    net = _net("yolov3", dtype="bf16")
+    try:
+        _hip.check(lib.y3_set_tuning(b"decode_lanes", 4))
+        fast = {k: v.clone() for k, v in net.forward_frames(frames).items()}
+        _hip.check(lib.y3_set_tuning(b"decode_lanes", 1))
+        seq = net.forward_frames(frames)
+        assert torch.equal(fast["class_idx"], seq["class_idx"])
+        assert torch.equal(fast["bbox_xywh"], seq["bbox_xywh"])
+        torch.testing.assert_close(fast["class_prob"], seq["class_prob"], rtol=2e-6, atol=1e-9)
+    finally:
+        lib.y3_set_tuning(b"decode_lanes", 4)
 
 
 def test_bf16_agreement_report_yolov3():
