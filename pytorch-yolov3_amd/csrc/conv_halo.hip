@@ -328,8 +328,6 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     }
 #endif
   }
-  __syncthreads();  // all operand reads and all LDS-DMA done: LDS can hold the output tile
-
   // ---- epilogue (the 512 consumer threads write out; the loaders only keep the barrier count) ----
   constexpr int SWZ = 15;
   constexpr int OCT_PER_ROW = BN / 8;
@@ -341,16 +339,9 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
   const int co = n0 + oc_mine * 8;
   f32x4 sc_lo, sc_hi, bi_lo, bi_hi;
   u32x4 resv[WR];
+  // the epilogue's global reads go out first; a raw barrier (LDS reads drained, no vmcnt drain -- the loaders waited
+  // for their LDS-DMA themselves) lets them fly while the accumulators are parked
   if (!loader) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int cl = wn * 64 + ni * 16 + fq * 4;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int pl = wm * 64 + mi * 16 + fr;
-        *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
-      }
-    }
     sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
     sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
     bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
@@ -363,6 +354,19 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
         if constexpr (sizeof(T) == 2) {
           resv[j] = m < p.M ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
         }
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();   // all operand reads and all LDS-DMA done: LDS can hold the output tile
+  if (!loader) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int cl = wn * 64 + ni * 16 + fq * 4;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int pl = wm * 64 + mi * 16 + fr;
+        *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
       }
     }
   }
