@@ -13,46 +13,43 @@ import sys
 import time
 
 
+# (flags, keyword arguments) per option; the flag names and defaults are the reference CLI's -- they are the interface a
+# user of `yolov3 ...` already knows -- the batching / dtype / json options are this build's additions
+_SOURCE_OPTIONS = [
+    (("-C", "--cam"), dict(metavar="cam_id", nargs="?", const=0,
+                           help="live capture: device number (0 when given bare) or a stream path")),
+    (("-I", "--image"), dict(type=pathlib.Path, metavar="<path>", help="one image, or a folder whose images are all run")),
+    (("-V", "--video"), dict(type=pathlib.Path, metavar="<path>", help="a video file, or a folder of frames")),
+]
+_MODEL_OPTIONS = [
+    (("-c", "--config"), dict(type=pathlib.Path, required=True, metavar="<path>", help="Darknet .cfg of the network (required)")),
+    (("-w", "--weights"), dict(type=pathlib.Path, required=True, metavar="<path>", help="Darknet .weights file (required)")),
+    (("-d", "--device"), dict(type=str, default="cuda", metavar="<device>", help="'cuda' or 'cuda:N' (default cuda)")),
+    (("-p", "--prob-thresh"), dict(type=float, default=0.05, metavar="<prob>", help="keep detections scoring at least this (default 0.05)")),
+    (("-i", "--iou-thresh"), dict(type=float, default=0.3, metavar="<iou>", help="NMS overlap above which the weaker box goes (default 0.3)")),
+    (("-n", "--class-names"), dict(type=pathlib.Path, metavar="<path>", help="text file, one class name per line; labels show indices without it")),
+    (("--dtype",), dict(default="bf16", choices=["bf16", "float32"], help="conv arithmetic: bf16 (throughput) or float32 (reference parity); default bf16")),
+    (("-b", "--batch-size"), dict(type=int, default=16, metavar="<n>", help="frames per GPU batch for folders and videos (default 16)")),
+]
+_OUTPUT_OPTIONS = [
+    (("-o", "--output"), dict(type=pathlib.Path, metavar="<path>", help="annotated frames: a folder of PNGs, or an .mp4 when OpenCV is installed")),
+    (("--json",), dict(type=pathlib.Path, metavar="<path>", help="dump every detection as COCO-format JSON")),
+    (("--show-fps",), dict(action="store_true", help="overlay the frame rate (camera mode)")),
+    (("-v", "--verbose"), dict(action="store_true", help="print device and throughput")),
+]
+
+
 def build_parser():
-    parser = argparse.ArgumentParser(prog="yolov3")
-    source_ = parser.add_argument_group(title="input source [required]")
-    source_args = source_.add_mutually_exclusive_group(required=True)
-    source_args.add_argument("-C", "--cam", metavar="cam_id", nargs="?", const=0,
-                             help="Camera or video capture device ID or path. [Default 0]")
-    source_args.add_argument("-I", "--image", type=pathlib.Path, metavar="<path>",
-                             help="Path to image file or directory of images.")
-    source_args.add_argument("-V", "--video", type=pathlib.Path, metavar="<path>",
-                             help="Path to video file (or a directory of frames).")
-
-    model_args = parser.add_argument_group(title="model parameters")
-    model_args.add_argument("-c", "--config", type=pathlib.Path, required=True, metavar="<path>",
-                            help="[Required] Path to Darknet model config file.")
-    model_args.add_argument("-d", "--device", type=str, default="cuda", metavar="<device>",
-                            help="Device for inference ('cuda', 'cuda:N'). [Default 'cuda']")
-    model_args.add_argument("-i", "--iou-thresh", type=float, default=0.3, metavar="<iou>",
-                            help="Non-maximum suppression IOU threshold. [Default 0.3]")
-    model_args.add_argument("-n", "--class-names", type=pathlib.Path, metavar="<path>",
-                            help="Path to text file of class names. If omitted, class index is displayed "
-                                 "instead of name.")
-    model_args.add_argument("-p", "--prob-thresh", type=float, default=0.05, metavar="<prob>",
-                            help="Detection probability threshold. [Default 0.05]")
-    model_args.add_argument("-w", "--weights", type=pathlib.Path, required=True, metavar="<path>",
-                            help="[Required] Path to Darknet model weights file.")
-    model_args.add_argument("--dtype", default="bf16", choices=["bf16", "float32"],
-                            help="Arithmetic of the conv path: bf16 (fast) or float32 (reference parity). "
-                                 "[Default bf16]")
-    model_args.add_argument("-b", "--batch-size", type=int, default=16, metavar="<n>",
-                            help="Frames per GPU batch for --image directories and --video. [Default 16]")
-
-    other_args = parser.add_argument_group(title="Output/display options")
-    other_args.add_argument("-o", "--output", type=pathlib.Path, metavar="<path>",
-                            help="Where annotated frames go: a directory (PNG per frame) or, with OpenCV "
-                                 "installed, an .mp4 file.")
-    other_args.add_argument("--json", type=pathlib.Path, metavar="<path>",
-                            help="Write all detections as a COCO-format JSON file.")
-    other_args.add_argument("--show-fps", action="store_true",
-                            help="Display frames processed per second (for --cam input).")
-    other_args.add_argument("-v", "--verbose", action="store_true", help="Verbose output")
+    parser = argparse.ArgumentParser(prog="yolov3", description="YOLOv3 detection on an MI355X (HIP path)")
+    source = parser.add_argument_group(title="input (exactly one)").add_mutually_exclusive_group(required=True)
+    for flags, kw in _SOURCE_OPTIONS:
+        source.add_argument(*flags, **kw)
+    model = parser.add_argument_group(title="model")
+    for flags, kw in _MODEL_OPTIONS:
+        model.add_argument(*flags, **kw)
+    output = parser.add_argument_group(title="output")
+    for flags, kw in _OUTPUT_OPTIONS:
+        output.add_argument(*flags, **kw)
     return parser
 
 
