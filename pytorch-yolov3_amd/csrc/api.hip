@@ -18,8 +18,9 @@ thread_local char g_err[512] = "";
 // kernel for 3x3 s1 layers with rows wider than 64; bit 1: wave-specialised igemm (3 stages) for 3x3 layers with rows of
 // 33..64; bit 2: halo kernel for rows <= 32; bit 3: wave-specialised igemm for 1x1 layers with Cin >= 1024;
 // bit 4: halo kernel for rows of 33..64 instead; bit 5: wave-specialised igemm for rows <= 32 instead;
+// bit 7: 2-D patch kernel (8 x 32 output tiles) for 3x3 stride-1 layers with rows wider than 128 px;
 // bit 6: wave-specialised igemm with 64-pixel tiles (3 stages, two workgroups per CU) for bf16 1x1 layers with Cin >= 256
-int g_y3_auto_mask = 21;  // measured best end to end (profiles/r01_ab_kernel_selection.txt): halo kernel at every row width
+int g_y3_auto_mask = 149;  // measured best end to end (profiles/r01_ab_kernel_selection.txt): halo kernel at every row width it fits, 2-D patch kernel for rows wider than 128 px
 int g_y3_halo_persistent = 0;   // halo kernel: 0 = one tile per workgroup, 1 = persistent tile loop (conv_halo.hip)   // experimental halo-reuse 3x3 kernels (conv_halo.hip); off: the implicit GEMM measured as fast
 
 
@@ -80,6 +81,8 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
             if ((am & 64) && op.ksize == 1 && op.in_c >= 256 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32) &&
                 op.dtype == Y3_BF16)
               return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3, 64);
+            if ((am & 128) && op.ksize == 3 && op.stride == 1 && w > 128 && op.out_c >= 128 && y3_conv_patch_fits(op))
+              return y3_launch_conv_patch(op, in, d_zero, s, name, dry_run);
             if (want_halo && halo_ok) return y3_launch_conv_halo(op, in, d_zero, s, name, dry_run, g_y3_halo_persistent != 0);
             if (want_ws) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
           }

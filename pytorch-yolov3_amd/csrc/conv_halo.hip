@@ -689,6 +689,289 @@ __global__ __launch_bounds__(768, 3) void conv_halo_wsp_kernel(HaloArgs p, int n
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 2-D patch form of the persistent wave-specialised kernel, for wide feature maps (rows of more than 128 pixels,
+// where the raster strip's halo of 2W + 2 rows no longer fits in LDS): a workgroup owns an 8 x 32 output tile and
+// stages the 10 x 34 input patch per channel chunk (one LDS row per patch pixel, out-of-frame pixels as zeros).  Tap
+// (ky, kx) of output (y, x) is patch row (y + ky) * 34 + x + kx: rows never wrap, so the fragment masking of the strip
+// kernels (56 of ~125 VALU instructions per wave and K-step) disappears.  Loaders, weight ring, barriers and the
+// per-wave epilogue are those of conv_halo_wsp_kernel.  Cost: tiles that hang over the right / bottom edge compute
+// pixels nobody stores (152 = 4.75 x 32: 5 %), which is why narrow maps stay on the strip kernels.
+template <typename T, int NSB>
+__global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int n_tiles_total, int tiles_x, int tiles_y) {
+  constexpr int BM = 256, BN = 128;
+  constexpr int TY = 8, TX = 32;                      // output tile: 8 rows x 32 columns
+  constexpr int PC = TX + 2, PROWS = (TY + 2) * PC;   // input patch: 10 x 34 pixels, one LDS row each
+  constexpr int WAVES_N = 2;
+  constexpr int NC = 512, NL = 256;
+  constexpr int ES = sizeof(T);
+  constexpr int BKE = 128 / ES;
+  constexpr int RPL = NL / 8;
+  constexpr int NBL = BN / RPL;
+  constexpr int HPS = 2;
+  constexpr int PER = NBL + HPS;
+  constexpr int B_BYTES = BN * 128;
+  constexpr int D = NSB - 2;
+  constexpr int MI = 4, NI = 4;
+  static_assert(NSB == 3 || NSB == 4, "weight ring has 3 or 4 slots");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *sB = smem;                                    // [NSB][BN][128]
+  char *sA = smem + NSB * B_BYTES;                    // [2][hr_pad][128]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= NC / 64;
+  const int nit = p.nchunks * 9;
+  const int grid = gridDim.x;
+  const int tile0 = y3_xcd_remap(blockIdx.x, grid);   // tiles of this workgroup: tile0, tile0 + grid, ...
+
+  if (loader) {
+    __builtin_amdgcn_s_setprio(3);
+    const int ltid = tid - NC;
+    const int lwave = wave - NC / 64;
+    const int slot = ltid & 7;
+    const int row0 = ltid >> 3;
+    const int kc = slot ^ (row0 & 7);
+    // patch slice `pass` (32 LDS rows = 32 patch pixels) of chunk `chunk` of the tile at (b, oy0, ox0), into buffer `buf`
+    auto issue_halo_pass = [&](int b, int oy0, int ox0, int chunk, int pass, int buf, bool live) {
+      const int r = row0 + pass * RPL;
+      const int pr = r / PC, pc = r - pr * PC;
+      const int gy = oy0 - 1 + pr, gx = ox0 - 1 + pc;
+      const bool ok = live && r < PROWS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      const long long q = ((long long)b * p.H + gy) * p.W + gx;
+      const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
+      char *dst = sA + buf * p.a_bytes + pass * (NL * 16) + lwave * 1024;
+      __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
+    };
+    auto issue_weights = [&](int n0, int it, int ring_slot) {
+      const int chunk = it / 9, tap = it - chunk * 9;
+      const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
+      const char *src0 = p.wgt + ((long long)(n0 + row0) * p.k_ld) * ES + kc * 16 + koff;
+      char *dst = sB + ring_slot * B_BYTES + lwave * 1024;
+#pragma unroll
+      for (int i = 0; i < NBL; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_void *)(src0 + (long long)i * RPL * p.k_ld * ES),
+                                         (lds_void *)(dst + i * (NL * 16)), 16, 0, 0);
+    };
+    // tile id -> (frame, tile row, tile column, channel tile); channel tiles innermost (they share the patch in L2)
+    auto tile_pos = [&](int tile, int &b, int &oy0, int &ox0) {
+      int t = tile / p.n_tiles;
+      ox0 = (t % tiles_x) * TX;
+      t /= tiles_x;
+      oy0 = (t % tiles_y) * TY;
+      b = t / tiles_y;
+    };
+    auto tile_n0 = [&](int tile) { return (tile % p.n_tiles) * BN; };
+    // prologue of the first tile only
+    {
+      int b0, oy00, ox00;
+      tile_pos(tile0, b0, oy00, ox00);
+      for (int pass = 0; pass < p.na; ++pass) issue_halo_pass(b0, oy00, ox00, 0, pass, 0, true);
+#pragma unroll
+      for (int j = 0; j <= D; ++j) issue_weights(tile_n0(tile0), j, j);
+    }
+    int ring = (D + 1) % NSB;                          // slot that receives the next weight tile
+    int gchunk = 0;                                    // chunks consumed so far (halo buffer = gchunk & 1)
+    int gstep = 0;                                     // K-steps issued so far, all tiles
+    for (int tile = tile0; tile < n_tiles_total; tile += grid) {
+      const int next_tile = tile + grid;
+      const bool has_next = next_tile < n_tiles_total;
+      int tb, toy, tox, nb, noy, nox;
+      tile_pos(tile, tb, toy, tox);
+      tile_pos(has_next ? next_tile : tile, nb, noy, nox);
+      const int n0 = tile_n0(tile), n0n = tile_n0(has_next ? next_tile : tile);
+      int tap = 0, chunk = 0;
+#pragma unroll 1
+      for (int it = 0; it < nit; ++it) {
+        // weights first, halo slices after: the counted wait leaves the youngest halo slices in flight (see above)
+        if (D == 2) { if (gstep == 0) wait_vmcnt<NBL>(); else if (gstep == 1) wait_vmcnt_n<PER>(); else wait_vmcnt_n<PER + HPS>(); }
+        else { if (gstep == 0) wait_vmcnt<0>(); else wait_vmcnt_n<HPS>(); }
+        ++gstep;
+        __builtin_amdgcn_s_barrier();
+        // weight tile D + 1 steps ahead: this tile's, the next tile's, or (nothing left) the last one again
+        const int itw = it + 1 + D;
+        if (itw < nit) issue_weights(n0, itw, ring);
+        else if (has_next) issue_weights(n0n, itw - nit, ring);
+        else issue_weights(n0, nit - 1, ring);
+        // two slices of the next chunk's halo: this tile's chunk + 1, or chunk 0 of the next tile
+        const bool in_tile = chunk + 1 < p.nchunks;
+        const bool live = in_tile || has_next;
+        const int p0 = 2 * tap < p.na ? 2 * tap : p.na - 1;
+        const int p1 = 2 * tap + 1 < p.na ? 2 * tap + 1 : p.na - 1;
+        const int nbuf = (gchunk + 1) & 1;
+        issue_halo_pass(in_tile ? tb : nb, in_tile ? toy : noy, in_tile ? tox : nox, in_tile ? chunk + 1 : 0, p0, nbuf, live);
+        issue_halo_pass(in_tile ? tb : nb, in_tile ? toy : noy, in_tile ? tox : nox, in_tile ? chunk + 1 : 0, p1, nbuf, live);
+        ring = ring + 1 == NSB ? 0 : ring + 1;
+        if (++tap == 9) { tap = 0; ++chunk; ++gchunk; }
+      }
+      __builtin_amdgcn_s_barrier();                    // E: consumers are done with the last chunk's halo buffer
+    }
+    wait_vmcnt<0>();
+    return;
+  }
+
+  // ---------------- consumer waves ----------------
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int a_lane_row = 2 * wm * PC + fr;            // patch row of (tile row 2*wm, column fr) at tap (0, 0)
+  const int b_lane_row = wn * 64 + fr;
+  const int b_off0 = b_lane_row * 128 + (((0 + fq) ^ (b_lane_row & 7)) << 4);
+  const int b_off1 = b_lane_row * 128 + (((4 + fq) ^ (b_lane_row & 7)) << 4);
+  const bool leaky = p.flags & Y3_F_LEAKY;
+  const bool has_res = p.flags & Y3_F_RESIDUAL;
+  int ring = 0, gchunk = 0;
+  for (int tile = tile0; tile < n_tiles_total; tile += grid) {
+    int tb, oy0, ox0;
+    {
+      int t = tile / p.n_tiles;
+      ox0 = (t % tiles_x) * TX;
+      t /= tiles_x;
+      oy0 = (t % tiles_y) * TY;
+      tb = t / tiles_y;
+    }
+    const int n0 = (tile % p.n_tiles) * BN;
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment mi of this wave: tile row 2*wm + (mi >> 1), columns (mi & 1) * 16 + fr; tap (ky, kx) shifts the patch
+    // row by ky * PC + kx.  No masking anywhere: out-of-frame patch pixels were loaded as zeros, rows do not wrap.
+    auto read_frags = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], const char *aBuf, const char *bBuf, int a_shift, int g) {
+      const int r0 = a_lane_row + a_shift, r1 = r0 + PC;
+      const char *ap0 = aBuf + r0 * 128 + (((g * 4 + fq) ^ (r0 & 7)) << 4);
+      const char *ap1 = aBuf + r1 * 128 + (((g * 4 + fq) ^ (r1 & 7)) << 4);
+      const char *bp = bBuf + (g ? b_off1 : b_off0);
+      xf[0] = *reinterpret_cast<const u32x4 *>(ap0);
+      xf[1] = *reinterpret_cast<const u32x4 *>(ap0 + 2048);
+      xf[2] = *reinterpret_cast<const u32x4 *>(ap1);
+      xf[3] = *reinterpret_cast<const u32x4 *>(ap1 + 2048);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
+    };
+    auto mma_all = [&](u32x4 (&xf)[MI], const u32x4 (&wf)[NI], int tap) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) MmaH<T>::run(acc[mi][ni], wf[ni], xf[mi]);
+    };
+    auto interleave = [&]() {
+#pragma unroll
+      for (int i = 0; i < MI + NI; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 2 : 8, 0);
+      }
+    };
+    __builtin_amdgcn_s_barrier();                      // B(0) of this tile
+    u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
+    read_frags(xf0, wf0, sA + (gchunk & 1) * p.a_bytes, sB + ring * B_BYTES, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    int tap = 0;
+#pragma unroll 1
+    for (int it = 0; it < nit; ++it) {
+      if (it) __builtin_amdgcn_s_barrier();
+      const char *aBuf = sA + (gchunk & 1) * p.a_bytes;
+      const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(xf1, wf1, aBuf, sB + ring * B_BYTES, ky * PC + kx, 1);
+      mma_all(xf0, wf0, tap);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      const int tap_n = tap == 8 ? 0 : tap + 1;
+      const int gchunk_n = tap == 8 ? gchunk + 1 : gchunk;
+      const int ring_n = ring + 1 == NSB ? 0 : ring + 1;
+      {
+        const int ky_n = (tap_n * 11) >> 5, kx_n = tap_n - ky_n * 3;
+        read_frags(xf0, wf0, sA + (gchunk_n & 1) * p.a_bytes, sB + ring_n * B_BYTES, ky_n * PC + kx_n, 0);
+      }
+      mma_all(xf1, wf1, tap);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      tap = tap_n;
+      gchunk = gchunk_n;
+      ring = ring_n;
+    }
+    __builtin_amdgcn_s_barrier();                      // E: every consumer is done reading the last chunk's halo
+    // ---- epilogue, per wave: 16 pixels x 64 channels at a time through a private 4 KiB slice of that buffer ----
+    float *sC = reinterpret_cast<float *>(sA + ((gchunk + 1) & 1) * p.a_bytes) + wave * 1024;
+    const int oc = lane & 7;                           // 8-channel group of this lane's write-out items
+    const int co = n0 + wn * 64 + oc * 8;
+    const f32x4 sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
+    const f32x4 sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+    const f32x4 bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
+    const f32x4 bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      // residual first: its latency hides behind the LDS round trip
+      u32x4 resv[2];
+      f32x4 resf[2][2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int oy = oy0 + 2 * wm + (mi >> 1), ox = ox0 + (mi & 1) * 16 + (lane >> 3) + r * 8;
+        const long long m = ((long long)tb * p.H + oy) * p.W + ox;
+        if (has_res && oy < p.H && ox < p.W) {
+          if constexpr (sizeof(T) == 2) {
+            resv[r] = *reinterpret_cast<const u32x4 *>(p.res + ((long long)m * p.res_ld + co) * ES);
+          } else {
+            const float *rp = reinterpret_cast<const float *>(p.res) + (long long)m * p.res_ld + co;
+            resf[r][0] = *reinterpret_cast<const f32x4 *>(rp);
+            resf[r][1] = *reinterpret_cast<const f32x4 *>(rp + 4);
+          }
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)                  // pixel fr, channels ni*16 + fq*4 .. +3; 16-B chunks XOR-swizzled
+        *reinterpret_cast<f32x4 *>(sC + fr * 64 + (((ni * 4 + fq) ^ fr) << 2)) = acc[mi][ni];
+      __builtin_amdgcn_s_waitcnt(0xC07F);              // (same wave reads below: LDS ops of a wave complete in order)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int pl = (lane >> 3) + r * 8;            // pixel inside the 16-row group
+        const int oy = oy0 + 2 * wm + (mi >> 1), ox = ox0 + (mi & 1) * 16 + pl;
+        const long long m = ((long long)tb * p.H + oy) * p.W + ox;
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * 64 + (((2 * oc) ^ pl) << 2));
+        const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * 64 + (((2 * oc + 1) ^ pl) << 2));
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] = lo[q] * sc_lo[q] + bi_lo[q];
+          v[4 + q] = hi[q] * sc_hi[q] + bi_hi[q];
+        }
+        if (leaky) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = v[q] > 0.f ? v[q] : Y3_LEAKY_SLOPE * v[q];
+        }
+        if (oy < p.H && ox < p.W) {
+          if (has_res) {
+            if constexpr (sizeof(T) == 2) {
+              const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[r]);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] += (float)rv[q];
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { v[q] += resf[r][0][q]; v[4 + q] += resf[r][1][q]; }
+            }
+          }
+          T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
+          if constexpr (sizeof(T) == 2) {
+            bf16x8 ov;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ov[q] = (bf16_t)v[q];
+            *reinterpret_cast<bf16x8 *>(op) = ov;
+          } else {
+            *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);              // reads done before the next group overwrites the slice
+    }
+  }
+}
+
 // n / d == (umulhi(n, mul) + n) >> sh for 0 <= n < 2^31 (round-up method, d >= 1)
 void fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
   if (d <= 1) { mul = 0; sh = 0; return; }
@@ -764,6 +1047,33 @@ int launch_halo_wsp(const HaloArgs &a0, hipStream_t s) {
   return Y3_OK;
 }
 
+template <typename T>
+int launch_patch_wsp(const HaloArgs &a0, hipStream_t s) {
+  HaloArgs a = a0;
+  constexpr int TY = 8, TX = 32, PROWS = (TY + 2) * (TX + 2);
+  a.na = y3_ceil_div(PROWS, 32);
+  a.hr_pad = a.na * 32;
+  a.a_bytes = a.hr_pad * 128;
+  const size_t lds = (size_t)4 * 128 * 128 + (size_t)2 * a.a_bytes;
+  static_assert(PROWS <= 12 * 32, "all patch slices must be out by tap 5 (4-slot ring)");
+  static bool attr_set = false;
+  static int n_cu = 0;
+  if (!attr_set) {
+    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_patch_wsp_kernel<T, 4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int dev = 0;
+    Y3_HIP_CHECK(hipGetDevice(&dev));
+    Y3_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    attr_set = true;
+  }
+  const int tiles_x = y3_ceil_div(a.W, TX), tiles_y = y3_ceil_div(a.H, TY);
+  const int tiles = tiles_x * tiles_y * (a.M / a.HW) * a.n_tiles;
+  const int grid = tiles < n_cu ? tiles : n_cu;
+  hipLaunchKernelGGL((conv_patch_wsp_kernel<T, 4>), dim3(grid), dim3(768), lds, s, a, tiles, tiles_x, tiles_y);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
 }  // namespace
 
 bool y3_conv_halo_eligible(const y3_op &op) {
@@ -784,6 +1094,44 @@ bool y3_conv_halo_ws_fits(const y3_op &op) {
   if (!y3_conv_halo_eligible(op)) return false;
   const int na = y3_ceil_div(256 + 2 * op.in_w + 2, 32);
   return na <= 14 && (size_t)3 * 128 * 128 + (size_t)2 * na * 32 * 128 <= 160 * 1024;
+}
+
+// 2-D patch kernel: same layer class, any number (>= 1) of channel chunks, any row width
+bool y3_conv_patch_fits(const y3_op &op) {
+  const int es = y3_elem_size(op.dtype);
+  const int bke = 128 / es;
+  if (op.ksize != 3 || op.stride != 1 || op.pad != 1) return false;
+  if (op.flags & (Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR)) return false;
+  if (op.in_c % bke != 0 || op.out_c % 128 != 0 || op.out_ld % 8 != 0 || op.in_ld % (16 / es) != 0) return false;
+  if ((op.flags & Y3_F_RESIDUAL) && op.res_ld % 8 != 0) return false;
+  return op.k_ld >= 9 * op.in_c;
+}
+
+int y3_launch_conv_patch(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
+                         const char **kernel_name, bool dry_run) {
+  const int es = y3_elem_size(op.dtype);
+  const bool bf = op.dtype == Y3_BF16;
+  Y3_REQUIRE(y3_conv_patch_fits(op), "conv block %d: shape not supported by the patch kernel", op.block_idx);
+  *kernel_name = bf ? "conv_patch_wsp_bf16_8x32x128" : "conv_patch_wsp_f32_8x32x128";
+  if (dry_run) return Y3_OK;
+  HaloArgs a;
+  a.in = static_cast<const char *>(d_in);
+  a.wgt = static_cast<const char *>(op.d_weight);
+  a.scale = op.d_scale; a.bias = op.d_bias;
+  a.res = static_cast<const char *>(op.d_res);
+  a.out = static_cast<char *>(op.d_out);
+  a.zero = static_cast<const char *>(d_zero);
+  a.H = op.in_h; a.W = op.in_w; a.Cin = op.in_c; a.in_ld = op.in_ld;
+  a.Cout = op.out_c; a.out_ld = op.out_ld; a.res_ld = op.res_ld;
+  a.HW = op.in_h * op.in_w;
+  a.M = op.batch * a.HW;
+  a.k_ld = op.k_ld;
+  a.nchunks = op.in_c / (128 / es);
+  a.n_tiles = op.out_c / 128;
+  a.hr_pad = a.na = a.a_bytes = 0;
+  a.mul_hw = a.sh_hw = a.mul_w = a.sh_w = 0;
+  a.flags = op.flags;
+  return bf ? launch_patch_wsp<bf16_t>(a, s) : launch_patch_wsp<float>(a, s);
 }
 
 int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,

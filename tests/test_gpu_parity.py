@@ -98,7 +98,7 @@ def test_mini_bf16_uint8_stem_matches_bf16_float_stem():
     assert (a["class_idx"] == b["class_idx"]).float().mean() > 0.97
 
 
-DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 21, "halo_persistent": 0, "fuse_stem": 1, "decode_lanes": 4}
+DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 149, "halo_persistent": 0, "fuse_stem": 1, "decode_lanes": 4}
 
 
 def test_tuning_knobs_do_not_change_results():
@@ -285,15 +285,19 @@ def test_halo_kernels_match_goldens_on_yolov3_fp32():
     g = np.load(os.path.join(GOLDEN, "forward_yolov3.npz"))
     frames = np.stack([resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), 608, 608), synth_frames(5, 1, 608, 608)[0]])
     try:
-        for persistent in (0, 1):
+        for persistent, mask in ((0, 21), (1, 21), (0, 21 | 128), (1, 21 | 128)):
             _hip.check(lib.y3_set_tuning(b"halo_persistent", persistent))
+            _hip.check(lib.y3_set_tuning(b"auto_mask", mask))
             net = _net("yolov3")
             out = net.forward(torch.from_numpy(orc.frames_to_input(list(frames))))
-            assert any("halo_ws" in r["kernel"] for r in net.plan_report())
+            names = [r["kernel"] for r in net.plan_report()]
+            assert any("halo_ws" in k for k in names)
+            assert any("conv_patch" in k for k in names) == bool(mask & 128)     # 2-D patch kernel on the 152^2 layers
             np.testing.assert_allclose(out["bbox_xywh"].cpu().numpy(), g["bbox_xywh"], rtol=1e-4, atol=BOX_ATOL)
             np.testing.assert_allclose(out["class_prob"].cpu().numpy(), g["class_prob"], atol=SCORE_ATOL)
     finally:
         lib.y3_set_tuning(b"halo_persistent", 0)
+        lib.y3_set_tuning(b"auto_mask", DEFAULT_KNOBS["auto_mask"])
 
 
 def test_wave_specialised_igemm_is_bit_identical():
@@ -322,7 +326,7 @@ def test_wave_specialised_igemm_is_bit_identical():
     finally:
         lib.y3_set_tuning(b"igemm_version", 2)
         lib.y3_set_tuning(b"igemm_ns", 2)
-        lib.y3_set_tuning(b"auto_mask", 21)
+        lib.y3_set_tuning(b"auto_mask", DEFAULT_KNOBS["auto_mask"])
 
 
 def _resblock_plan(net, x, fuse, dev):

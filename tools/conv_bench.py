@@ -40,13 +40,14 @@ LAYERS = [
     ("s76_256-255_k1_head", 76, 256, 255, 1, 1, False, True),
 ]
 
-# knob sets (y3_set_tuning) compared per layer; auto_mask 0 = implicit GEMM everywhere, 21 = halo kernel where it fits
+# knob sets (y3_set_tuning) compared per layer; auto_mask 0 = implicit GEMM everywhere, 21 = halo kernel where it fits,
+# +128 = 2-D patch kernel for rows wider than 128 px
 BASE = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 0, "halo_persistent": 0}
 VARIANTS = [
     ("igemm_v2", dict(BASE)),
     ("halo_ws", dict(BASE, auto_mask=21)),
     ("halo_wsp", dict(BASE, auto_mask=21, halo_persistent=1)),
-    ("igemm_v3_ns3", dict(BASE, igemm_version=3, igemm_ns=3)),
+    ("patch_8x32", dict(BASE, auto_mask=21 | 128)),
 ]
 
 
