@@ -300,6 +300,33 @@ def test_halo_kernels_match_goldens_on_yolov3_fp32():
         lib.y3_set_tuning(b"auto_mask", DEFAULT_KNOBS["auto_mask"])
 
 
+@pytest.mark.parametrize("dim,dtype", [(672, "float32"), (672, "bf16"), (1024, "bf16")])
+def test_patch_kernel_edge_tiles_match_implicit_gemm(dim, dtype):
+    """2-D patch kernel (8 x 32 output tiles) on maps that are not a multiple of the tile (672 -> 168 = 5.25 x 32 wide,
+    21 x 8 high) and on a 256-wide map against the run with those layers on the implicit GEMM: bit-identical in bf16
+    (64 input channels = one channel chunk: same K order per accumulator), equal up to summation order in float32
+    (two chunks: the patch kernel runs chunk-major, the implicit GEMM tap-major)."""
+    from yolov3 import _hip
+    lib = _hip.lib()
+    frames = synth_frames(dim, 1, dim, dim)
+    try:
+        outs = []
+        for mask in (21 | 128, 21):
+            _hip.check(lib.y3_set_tuning(b"auto_mask", mask))
+            net = _net("yolov3", dtype=dtype)
+            outs.append({k: v.clone() for k, v in net.forward_frames(frames).items()})
+            assert any("conv_patch" in r["kernel"] for r in net.plan_report()) == bool(mask & 128)
+        if dtype == "bf16":
+            for k in ("bbox_xywh", "class_prob", "class_idx"):
+                assert torch.equal(outs[0][k], outs[1][k]), k
+        else:
+            torch.testing.assert_close(outs[0]["bbox_xywh"], outs[1]["bbox_xywh"], rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(outs[0]["class_prob"], outs[1]["class_prob"], rtol=1e-4, atol=1e-5)
+            assert float((outs[0]["class_idx"] == outs[1]["class_idx"]).float().mean()) > 0.999
+    finally:
+        lib.y3_set_tuning(b"auto_mask", DEFAULT_KNOBS["auto_mask"])
+
+
 def test_wave_specialised_igemm_is_bit_identical():
     """igemm v3 (loader / consumer waves) runs the same MFMA sequence per accumulator as v2: whole-network
     outputs must be bit-identical, fp32 against the goldens too, for 2 and 3 LDS stages."""
