@@ -17,8 +17,11 @@
 // 128 B) changes per K-step; it streams through a 3- or 4-slot LDS ring.  Bytes through the LDS-DMA
 // path per FLOP drop ~3x versus the 128x128 implicit GEMM.
 //
-// Two kernels: conv_halo_ws_kernel (one tile per workgroup; default) and conv_halo_wsp_kernel
-// (persistent tile loop; faster alone, slower with several batches in flight).  Earlier schedules
+// Three kernels: conv_halo_ws_kernel (raster strip, one tile per workgroup; default for rows of up
+// to 128 pixels), conv_halo_wsp_kernel (same, persistent tile loop; faster alone, slower with several
+// batches in flight) and conv_patch_wsp_kernel (persistent, 8 x 32 output tiles with a 2-D input
+// patch and no fragment masking; default for wider rows, where the strip's halo outgrows LDS).
+// Earlier schedules
 // -- every wave loading and computing in lock step, ping-pong wave groups, 32-channel chunks with a
 // deeper ring -- measured 5-25 % slower (profiles/r01_convbench_v2_vs_halo.txt,
 // profiles/r01_convbench_variants.txt) and were removed.
@@ -699,7 +702,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_wsp_kernel(HaloArgs p, int n
 // pixels nobody stores (152 = 4.75 x 32: 5 %), which is why narrow maps stay on the strip kernels.
 template <typename T, int NSB>
 __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int n_tiles_total, int tiles_x, int tiles_y) {
-  constexpr int BM = 256, BN = 128;
+  constexpr int BN = 128;
   constexpr int TY = 8, TX = 32;                      // output tile: 8 rows x 32 columns
   constexpr int PC = TX + 2, PROWS = (TY + 2) * PC;   // input patch: 10 x 34 pixels, one LDS row each
   constexpr int WAVES_N = 2;
