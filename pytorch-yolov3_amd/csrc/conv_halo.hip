@@ -2,7 +2,7 @@
 //
 // Same contract as conv_igemm.hip (conv -> scale/bias -> LeakyReLU -> +residual; replaces
 // /root/reference/yolov3/darknet.py:244-257 and the shortcut at :376-379), specialised for the
-// layers that carry 61 % of Darknet-53's FLOPs: 3x3, stride 1, pad 1, Cin >= 2 K-tiles
+// layers that carry 70 % of Darknet-53's FLOPs: 3x3, stride 1, pad 1, Cin >= 2 K-tiles
 // (K-tile = 64 bf16 / 32 fp32 channels = 128 bytes), Cout a multiple of 128.
 //
 // Why: the generic implicit GEMM re-reads every input pixel once per filter tap (9x) and every
