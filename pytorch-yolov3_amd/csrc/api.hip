@@ -21,6 +21,9 @@ thread_local char g_err[512] = "";
 // bit 7: 2-D patch kernel (8 x 32 output tiles) for 3x3 stride-1 layers with rows wider than 128 px;
 // bit 6: wave-specialised igemm with 64-pixel tiles (3 stages, two workgroups per CU) for bf16 1x1 layers with Cin >= 256
 int g_y3_auto_mask = 149;  // measured best end to end (profiles/r01_ab_kernel_selection.txt): halo kernel at every row width it fits, 2-D patch kernel for rows wider than 128 px
+int g_y3_tuning_epoch = 0;      // bumped by every y3_set_tuning call: captured graphs bake the kernel choice in
+int g_y3_use_graph = 0;         // 1: y3_plan_run replays a captured hipGraph when it can (tuning knob "use_graph");
+                                // measured 1 % SLOWER than 78 individual launches (profiles/r01_ab_kernel_selection.txt)
 int g_y3_halo_persistent = 0;   // halo kernel: 0 = one tile per workgroup, 1 = persistent tile loop (conv_halo.hip)   // experimental halo-reuse 3x3 kernels (conv_halo.hip); off: the implicit GEMM measured as fast
 
 
@@ -38,6 +41,12 @@ struct y3_plan {
   std::vector<char> fuse;   // per op: 0 = launch normally, 1 / 3 = launch fused with the next op (stem pair / residual
                             // block), 2 = nothing (fused into the previous op)
   std::vector<hipEvent_t> events;
+  // hipGraph replay (one graph launch per forward instead of ~80 kernel launches): executable graphs keyed by the
+  // input pointer they were captured with; the first run of a plan is always eager (one-time function attributes)
+  struct GraphEntry { const void *input; hipGraphExec_t exec; };
+  std::vector<GraphEntry> graphs;
+  bool warmed = false, graph_ok = true;
+  int epoch = 0;            // value of g_y3_tuning_epoch the graphs were captured under
 };
 
 namespace {
@@ -184,16 +193,60 @@ int y3_plan_create(const y3_op *ops, int n_ops, const void *d_zero, y3_plan **ou
 void y3_plan_destroy(y3_plan *plan) {
   if (!plan) return;
   for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
+  for (auto &g : plan->graphs) (void)hipGraphExecDestroy(g.exec);
   delete plan;
+}
+
+static int plan_run_eager(y3_plan *plan, const void *d_input, hipStream_t s) {
+  const char *name = nullptr;
+  for (size_t i = 0; i < plan->ops.size(); ++i) {
+    const int rc = run_op(plan, i, d_input, s, &name);
+    if (rc != Y3_OK) return rc;
+  }
+  return Y3_OK;
 }
 
 int y3_plan_run(y3_plan *plan, const void *d_input, void *stream) {
   Y3_REQUIRE(plan, "y3_plan_run: null plan");
-  const char *name = nullptr;
-  for (size_t i = 0; i < plan->ops.size(); ++i) {
-    const int rc = run_op(plan, i, d_input, static_cast<hipStream_t>(stream), &name);
-    if (rc != Y3_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // graphs need a capturable (non-default) stream; the plan's pointers never change, only d_input may
+  if (!g_y3_use_graph || !plan->graph_ok || s == nullptr || !plan->warmed) {
+    plan->warmed = true;
+    return plan_run_eager(plan, d_input, s);
   }
+  if (plan->epoch != g_y3_tuning_epoch) {         // a knob changed since the capture: the launches may differ now
+    for (auto &g : plan->graphs) (void)hipGraphExecDestroy(g.exec);
+    plan->graphs.clear();
+    plan->epoch = g_y3_tuning_epoch;
+  }
+  for (auto &g : plan->graphs)
+    if (g.input == d_input) {
+      Y3_HIP_CHECK(hipGraphLaunch(g.exec, s));
+      return Y3_OK;
+    }
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    plan->graph_ok = false;
+    return plan_run_eager(plan, d_input, s);
+  }
+  const int rc = plan_run_eager(plan, d_input, s);
+  const hipError_t e_end = hipStreamEndCapture(s, &graph);
+  if (rc != Y3_OK || e_end != hipSuccess || graph == nullptr ||
+      hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    if (graph) (void)hipGraphDestroy(graph);
+    plan->graph_ok = false;                       // capture not possible here: stay eager from now on
+    return rc != Y3_OK ? rc : plan_run_eager(plan, d_input, s);
+  }
+  (void)hipGraphDestroy(graph);
+  if (plan->graphs.size() >= 8) {                 // callers cycle through a few input buffers at most
+    (void)hipGraphExecDestroy(plan->graphs.front().exec);
+    plan->graphs.erase(plan->graphs.begin());
+  }
+  plan->graphs.push_back({d_input, exec});
+  Y3_HIP_CHECK(hipGraphLaunch(exec, s));
   return Y3_OK;
 }
 

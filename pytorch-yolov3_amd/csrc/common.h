@@ -155,6 +155,8 @@ bool y3_conv_patch_fits(const y3_op &op);
 int y3_launch_conv_patch(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
                          const char **kernel_name, bool dry_run);
 // process-wide tuning knobs (y3_set_tuning)
+extern int g_y3_use_graph;
+extern int g_y3_tuning_epoch;
 extern int g_y3_halo_persistent;
 extern int g_y3_auto_mask; // per-layer kernel selection bits (api.hip)
 // true when the MFMA implicit-GEMM kernel can take this conv

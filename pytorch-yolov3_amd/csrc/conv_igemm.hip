@@ -935,10 +935,12 @@ static void igemm_fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
 
 extern "C" int y3_set_tuning(const char *key, int value) {
   if (!key) return Y3_ERR_INVALID;
+  ++g_y3_tuning_epoch;
   if (!strcmp(key, "igemm_version")) { g_igemm_version = value; return Y3_OK; }
   if (!strcmp(key, "igemm_bm")) { g_igemm_bm = value; return Y3_OK; }
   if (!strcmp(key, "igemm_ns")) { g_igemm_ns = value; return Y3_OK; }
   if (!strcmp(key, "auto_mask")) { g_y3_auto_mask = value; return Y3_OK; }
+  if (!strcmp(key, "use_graph")) { g_y3_use_graph = value; return Y3_OK; }
   if (!strcmp(key, "halo_persistent")) { g_y3_halo_persistent = value; return Y3_OK; }
   if (!strcmp(key, "decode_lanes")) { extern int g_y3_decode_lanes; g_y3_decode_lanes = value; return Y3_OK; }
   if (!strcmp(key, "fuse_dbg")) { extern int g_y3_fuse_dbg; g_y3_fuse_dbg = value; return Y3_OK; }

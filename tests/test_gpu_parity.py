@@ -98,7 +98,7 @@ def test_mini_bf16_uint8_stem_matches_bf16_float_stem():
     assert (a["class_idx"] == b["class_idx"]).float().mean() > 0.97
 
 
-DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 149, "halo_persistent": 0, "fuse_stem": 1, "decode_lanes": 4}
+DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 149, "halo_persistent": 0, "fuse_stem": 1, "decode_lanes": 4, "use_graph": 0}
 
 
 def test_tuning_knobs_do_not_change_results():
@@ -502,6 +502,36 @@ def test_split_class_decode_matches_sequential_decode():
         assert torch.equal(fast["bbox_xywh"], seq["bbox_xywh"])
         torch.testing.assert_close(fast["class_prob"], seq["class_prob"], rtol=2e-6, atol=1e-9)
     finally:
+        lib.y3_set_tuning(b"decode_lanes", 4)
+
+
+def test_graph_replay_equals_eager_launches():
+    """y3_plan_run replays a captured hipGraph on non-default streams (one launch per forward instead of ~80); same
+    bits as launching every kernel, for repeated calls, alternating inputs and after a knob change."""
+    from yolov3 import _hip
+    lib = _hip.lib()
+    net = _net("yolov3", dtype="bf16")
+    dev = net._torch_device()
+    a = torch.from_numpy(synth_frames(1, 2, 416, 416)).to(dev)
+    b = torch.from_numpy(synth_frames(2, 2, 416, 416)).to(dev)
+    try:
+        _hip.check(lib.y3_set_tuning(b"use_graph", 0))
+        ref = [{k: v.clone() for k, v in net.forward_frames(x).items()} for x in (a, b)]
+        _hip.check(lib.y3_set_tuning(b"use_graph", 1))
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            for rep in range(3):                       # eager warm-up, capture, replay -- for both inputs
+                for x, want in ((a, ref[0]), (b, ref[1])):
+                    got = net.forward_frames(x)
+                    stream.synchronize()
+                    for k in want:
+                        assert torch.equal(got[k], want[k]), (rep, k)
+            _hip.check(lib.y3_set_tuning(b"decode_lanes", 1))      # invalidates the captured graphs
+            got = net.forward_frames(a)
+            stream.synchronize()
+            assert torch.equal(got["class_idx"], ref[0]["class_idx"])
+    finally:
+        lib.y3_set_tuning(b"use_graph", 0)
         lib.y3_set_tuning(b"decode_lanes", 4)
 
 
