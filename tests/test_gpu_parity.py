@@ -517,6 +517,7 @@ def test_graph_replay_equals_eager_launches():
     try:
         _hip.check(lib.y3_set_tuning(b"use_graph", 0))
         ref = [{k: v.clone() for k, v in net.forward_frames(x).items()} for x in (a, b)]
+        torch.cuda.synchronize()                       # the side stream below does not wait for the default stream
         _hip.check(lib.y3_set_tuning(b"use_graph", 1))
         stream = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(stream):
