@@ -140,3 +140,30 @@ def test_video_loop_over_a_frame_directory_and_cli(tmp_path):
     assert [im["file_name"] for im in ds["images"]] == names_sorted
     assert len(ds["annotations"]) == sum(len(r[1]) for r in results)
     assert len(os.listdir(out_dir)) == len(names_sorted)
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_json_line():
+    """bench.py's output contract (one JSON line with the driver's keys plus roofline / cpu_baseline objects), on a
+    small workload so the test stays short."""
+    import subprocess
+    import sys
+    from golden_util import ROOT
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "yolov3-tiny", "--dim", "416",
+                           "--batch", "2", "--steps", "3", "--warmup", "1", "--cpu-frames", "1"],
+                          capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["value"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and "traffic" in r
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
