@@ -76,7 +76,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import torch.distributed as dist
-    distributed = world > 1
+    # Y3_BENCH_FORCE_DIST=1 (under torchrun with one process): run the RCCL plumbing -- init, barrier, all-gather,
+    # all-reduce -- with a single rank, so the multi-GPU code path can be exercised on a one-GPU box
+    distributed = world > 1 or os.environ.get("Y3_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -218,7 +220,7 @@ def main():
                                        args.model, dim, dim, b, args.dtype, n_cand_note),
                        "frames_per_gpu": b, "global_batch": b * world, "parallelism": "dp%d" % world,
                        "batches_in_flight_per_gpu": nstream,
-                       "collective": "all_gather(%d x %d x 8 int32 records)" % (b, args.kmax) if world > 1 else "none"},
+                       "collective": "all_gather(%d x %d x 8 int32 records)" % (b, args.kmax) if distributed else "none"},
             "roofline": {"bound": "mfma", "kernel": report["dominant"], "achieved": round(report["achieved"], 2),
                          "peak": report["peak"], "unit": "TFLOP/s", "frac": round(report["achieved"] / report["peak"], 4),
                          "traffic": report["traffic"],

@@ -27,8 +27,8 @@ def shard_range(n_frames, rank, world):
 def all_gather_records(records, counts, world, group=None):
     """records (b, kmax, 8) int32 and counts (b,) int32 of THIS rank -> the same for all ranks,
     concatenated in rank order: (world*b, kmax, 8), (world*b,).  Every rank must pass equal b."""
-    if world == 1:
-        return records, counts
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return records, counts          # plain single-process use: nothing to gather
     out_r = torch.empty((world * records.shape[0],) + tuple(records.shape[1:]), dtype=records.dtype,
                         device=records.device)
     out_c = torch.empty((world * counts.shape[0],), dtype=counts.dtype, device=counts.device)

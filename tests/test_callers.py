@@ -167,3 +167,23 @@ def test_bench_prints_one_contract_json_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_runs_the_rccl_plumbing():
+    """One rank under torchrun with Y3_BENCH_FORCE_DIST=1: process-group init on RCCL, barriers, the per-step
+    all-gather of detection records issued from three streams, the max all-reduce and the teardown all execute on a
+    real GPU (multi-rank correctness of the sharding / gather itself is covered by the gloo test on CPU)."""
+    import subprocess
+    import sys
+    from golden_util import ROOT
+    env = dict(os.environ, Y3_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                           "--gpus", "1", "--model", "yolov3-tiny", "--dim", "416", "--batch", "4", "--steps", "6",
+                           "--warmup", "3", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0, (proc.stdout[-1500:], proc.stderr[-1500:])
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["collective"].startswith("all_gather")
