@@ -221,6 +221,9 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
 #endif
   } else {
     // ---------------- consumer waves ----------------
+    // the younger MFMA wave of each SIMD loses every issue arbitration to its older partner (age order); a static
+    // priority for that half evens the pair out (MI355X_MICROARCH.md, two waves per SIMD, item 4): +1-5 % measured
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     uint32_t tapmask[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -529,6 +532,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_wsp_kernel(HaloArgs p, int n
   }
 
   // ---------------- consumer waves ----------------
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the younger MFMA wave of each SIMD: static priority, +1-5 % measured
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int fr = lane & 15, fq = lane >> 4;
   const int a_lane_row = wm * 64 + fr;
@@ -816,6 +820,7 @@ __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int 
   }
 
   // ---------------- consumer waves ----------------
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the younger MFMA wave of each SIMD: static priority, +1-5 % measured
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int fr = lane & 15, fq = lane >> 4;
   const int a_lane_row = 2 * wm * PC + fr;            // patch row of (tile row 2*wm, column fr) at tap (0, 0)
