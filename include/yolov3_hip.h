@@ -130,10 +130,11 @@ double y3_plan_op_bytes(const y3_plan *plan, int op_index);
 int y3_conv_path(const y3_op *op);
 
 /* process-wide tuning knobs for A/B measurements (tools/conv_bench.py, bench.py --tuning):
- *   "auto_mask"       per-layer kernel choice bits, default 149: halo-reuse kernel for every 3x3 stride-1 conv it
- *                     fits (bit 0: rows > 64 px, bit 4: 33..64, bit 2: <= 32) and the 2-D patch kernel for rows wider
- *                     than 128 px (bit 7); 0 = implicit GEMM everywhere; bits 1 / 5 / 3 / 6 route layers to the
- *                     wave-specialised implicit GEMM instead (api.hip)
+ *   "auto_mask"       per-layer kernel choice bits, default 157: halo-reuse kernel for every 3x3 stride-1 conv it
+ *                     fits (bit 0: rows > 64 px, bit 4: 33..64, bit 2: <= 32), the 2-D patch kernel for rows wider
+ *                     than 128 px (bit 7), the wave-specialised implicit GEMM for 1x1 layers with Cin >= 1024 (bit 3);
+ *                     0 = implicit GEMM v2 everywhere; bits 1 / 5 / 6 route more layers to the wave-specialised
+ *                     implicit GEMM (api.hip)
  *   "halo_persistent" 0 [default] one tile per workgroup, 1 persistent tile loop
  *   "igemm_version"   1 register-staged, 2 LDS-DMA double-buffered [default], 3 wave-specialised
  *   "igemm_ns"        LDS stages of version 3 (2..4);  "igemm_bm" 64 = 64-pixel tiles for version 3 (bf16)

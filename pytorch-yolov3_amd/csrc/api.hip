@@ -20,7 +20,7 @@ thread_local char g_err[512] = "";
 // bit 4: halo kernel for rows of 33..64 instead; bit 5: wave-specialised igemm for rows <= 32 instead;
 // bit 7: 2-D patch kernel (8 x 32 output tiles) for 3x3 stride-1 layers with rows wider than 128 px;
 // bit 6: wave-specialised igemm with 64-pixel tiles (3 stages, two workgroups per CU) for bf16 1x1 layers with Cin >= 256
-int g_y3_auto_mask = 149;  // measured best end to end (profiles/r01_ab_kernel_selection.txt): halo kernel at every row width it fits, 2-D patch kernel for rows wider than 128 px
+int g_y3_auto_mask = 157;  // measured best end to end (profiles/r01_ab_kernel_selection.txt): halo kernel at every row width it fits, 2-D patch kernel for rows wider than 128 px, wave-specialised igemm for the deep-K 1x1 layers
 int g_y3_tuning_epoch = 0;      // bumped by every y3_set_tuning call: captured graphs bake the kernel choice in
 int g_y3_use_graph = 0;         // 1: y3_plan_run replays a captured hipGraph when it can (tuning knob "use_graph");
                                 // measured 1 % SLOWER than 78 individual launches (profiles/r01_ab_kernel_selection.txt)

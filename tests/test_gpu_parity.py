@@ -98,7 +98,7 @@ def test_mini_bf16_uint8_stem_matches_bf16_float_stem():
     assert (a["class_idx"] == b["class_idx"]).float().mean() > 0.97
 
 
-DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 149, "halo_persistent": 0, "fuse_stem": 1, "decode_lanes": 4, "use_graph": 0}
+DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 157, "halo_persistent": 0, "fuse_stem": 1, "decode_lanes": 4, "use_graph": 0}
 
 
 def test_tuning_knobs_do_not_change_results():
