@@ -31,6 +31,9 @@ LAYERS = [
     ("s304_32-64_k3", 304, 32, 64, 3, 1, True, False),
     ("s608_32-64_k3s2", 608, 32, 64, 3, 2, False, False),
     ("s152_128-256_k3s2", 152, 128, 256, 3, 2, False, False),
+    ("s76_256-512_k3s2", 76, 256, 512, 3, 2, False, False),
+    ("s38_512-1024_k3s2", 38, 512, 1024, 3, 2, False, False),
+    ("s304_64-128_k3s2", 304, 64, 128, 3, 2, False, False),
     ("s76_256-128_k1", 76, 256, 128, 1, 1, False, False),
     ("s38_512-256_k1", 38, 512, 256, 1, 1, False, False),
     ("s19_1024-512_k1", 19, 1024, 512, 1, 1, False, False),
@@ -48,6 +51,8 @@ VARIANTS = [
     ("halo_ws", dict(BASE, auto_mask=21)),
     ("halo_wsp", dict(BASE, auto_mask=21, halo_persistent=1)),
     ("patch_8x32", dict(BASE, auto_mask=21 | 128)),
+    ("igemm_v3_ns3", dict(BASE, igemm_version=3, igemm_ns=3)),
+    ("igemm_v3_ns2", dict(BASE, igemm_version=3, igemm_ns=2)),
 ]
 
 
