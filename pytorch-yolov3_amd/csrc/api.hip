@@ -38,8 +38,8 @@ struct y3_plan {
   std::vector<y3_op> ops;
   std::vector<const char *> kernel;
   const void *d_zero;
-  std::vector<char> fuse;   // per op: 0 = launch normally, 1 / 3 = launch fused with the next op (stem pair / residual
-                            // block), 2 = nothing (fused into the previous op)
+  std::vector<char> fuse;   // per op: 0 = launch normally, 1 / 3 / 4 = launch fused with the next op (stem pair / residual
+                            // block / head conv + decode), 2 = nothing (fused into the previous op)
   std::vector<hipEvent_t> events;
   // hipGraph replay (one graph launch per forward instead of ~80 kernel launches): executable graphs keyed by the
   // input pointer they were captured with; the first run of a plan is always eager (one-time function attributes)
@@ -117,6 +117,7 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
 int run_op(y3_plan *plan, size_t i, const void *d_input, hipStream_t s, const char **name) {
   if (plan->fuse[i] == 2) return Y3_OK;
   if (plan->fuse[i] == 3) return y3_launch_conv_fused_resblock(plan->ops[i], plan->ops[i + 1], s, name, false);
+  if (plan->fuse[i] == 4) return y3_launch_conv_head_decode(plan->ops[i], plan->ops[i + 1], plan->d_zero, s, name, false);
   if (plan->fuse[i] == 1) {
     const y3_op &op0 = plan->ops[i];
     const void *in = (op0.flags & Y3_F_PLAN_INPUT) ? d_input : op0.d_in;
@@ -169,6 +170,9 @@ int y3_plan_create(const y3_op *ops, int n_ops, const void *d_zero, y3_plan **ou
     } else if ((p->ops[i].flags & Y3_F_FUSE_NEXT) && y3_conv_fused_resblock_supported(p->ops[i], p->ops[i + 1])) {
       p->fuse[i] = 3;           // whole residual block in one kernel
       p->fuse[i + 1] = 2;
+    } else if (y3_conv_head_decode_supported(p->ops[i], p->ops[i + 1])) {
+      p->fuse[i] = 4;           // head conv + YOLO decode (the float32 logits never leave the CU)
+      p->fuse[i + 1] = 2;
     }
   for (int i = 0; i < n_ops; ++i) {
     if (p->fuse[i] == 2) { p->kernel[i] = "(fused into the previous op)"; continue; }
@@ -178,6 +182,10 @@ int y3_plan_create(const y3_op *ops, int n_ops, const void *d_zero, y3_plan **ou
     }
     if (p->fuse[i] == 3) {
       (void)y3_launch_conv_fused_resblock(p->ops[i], p->ops[i + 1], nullptr, &p->kernel[i], true);
+      continue;
+    }
+    if (p->fuse[i] == 4) {
+      (void)y3_launch_conv_head_decode(p->ops[i], p->ops[i + 1], d_zero, nullptr, &p->kernel[i], true);
       continue;
     }
     const int rc = dispatch(p->ops[i], nullptr, d_zero, nullptr, &p->kernel[i], true);
@@ -283,7 +291,7 @@ double y3_plan_op_flops(const y3_plan *plan, int op_index) {
     return o.kind != Y3_OP_CONV ? 0.0 : 2.0 * o.ksize * o.ksize * o.in_c * (double)o.out_c * o.out_h * o.out_w * o.batch;
   };
   double f = conv_flops(plan->ops[op_index]);
-  if (plan->fuse[op_index] == 1 || plan->fuse[op_index] == 3) f += conv_flops(plan->ops[op_index + 1]);
+  if (plan->fuse[op_index] == 1 || plan->fuse[op_index] == 3) f += conv_flops(plan->ops[op_index + 1]);   // (4: the decode has no conv FLOPs)
   return f;
 }
 
@@ -294,6 +302,11 @@ double y3_plan_op_bytes(const y3_plan *plan, int op_index) {
     const y3_op &a = plan->ops[op_index], &b = plan->ops[op_index + 1];
     return (double)a.batch * a.in_h * a.in_w * a.in_c + (double)b.batch * b.out_h * b.out_w * b.out_c * 2.0 +
            27.0 * a.out_c * 2.0 + 9.0 * b.in_c * b.out_c * 2.0;
+  }
+  if (plan->fuse[op_index] == 4) {   // activations + weights in, 28 bytes per box out
+    const y3_op &a = plan->ops[op_index], &b = plan->ops[op_index + 1];
+    return ((double)a.batch * a.in_h * a.in_w * a.in_c + (double)a.in_c * a.out_c) * 2.0 +
+           (double)b.batch * b.in_h * b.in_w * b.n_anchor * 28.0;
   }
   if (plan->fuse[op_index] == 3) {   // x in (once), z out, both weight sets
     const y3_op &a = plan->ops[op_index], &b = plan->ops[op_index + 1];

@@ -146,6 +146,10 @@ int y3_launch_conv_fused_stem_s2(const y3_op &op0, const y3_op &op1, const void 
 bool y3_conv_fused_resblock_supported(const y3_op &op0, const y3_op &op1);
 int y3_launch_conv_fused_resblock(const y3_op &op0, const y3_op &op1, hipStream_t s, const char **kernel_name,
                                   bool dry_run);
+// detection head: 1x1 conv + YOLO decode in one launch (conv_igemm.hip)
+bool y3_conv_head_decode_supported(const y3_op &op0, const y3_op &op1);
+int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d_zero, hipStream_t s,
+                               const char **kernel_name, bool dry_run);
 extern int g_y3_fuse_stem;
 // halo-reuse 3x3 kernel (conv_halo.hip): whether it can take this conv, and its launcher
 bool y3_conv_halo_ws_fits(const y3_op &op);

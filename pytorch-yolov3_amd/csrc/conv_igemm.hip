@@ -40,6 +40,12 @@ struct IgemmArgs {
   int m_tiles, n_tiles;
   uint32_t mul_hw, sh_hw, mul_w, sh_w;   // n / d == (umulhi(n, mul) + n) >> sh  for n < 2^31 (d = HoWo, Wo)
   uint32_t flags;
+  // detection-head fusion (conv_igemm2_kernel<..., DECODE = true>): the YOLO decode of yolo_decode.hip runs on the
+  // parked fp32 tile instead of a second kernel reading it back from HBM
+  float *y_bbox, *y_prob;
+  long long *y_cls;
+  int y_anchors, y_attr, y_row_offset, y_rows_total;
+  float y_net_w, y_net_h, y_aw[8], y_ah[8];
 };
 
 template <typename T>
@@ -261,6 +267,66 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
 }
 
 
+// YOLO decode of `rows` pixels whose float32 logits (conv sums with scale / bias already applied) are parked in LDS with
+// a row stride of LD floats (LD odd in units of banks: the per-box reads of adjacent lanes spread over the banks): the
+// arithmetic of yolo_decode_kernel<4> (four lanes per box).  Each operation rounds separately, like in
+// yolo_decode.hip (built with -ffp-contract=off).
+template <int NT, int LD>
+__device__ __forceinline__ void head_decode_rows(const IgemmArgs &p, const float *sL, int mbase, int rows, int tid) {
+#pragma clang fp contract(off)
+  const int nbox = rows * p.y_anchors;
+  for (int t = tid; t < nbox * 4; t += NT) {
+    const int box = t >> 2, sub = t & 3;
+    const int pl = box / p.y_anchors, a = box - pl * p.y_anchors;
+    const long long m = (long long)mbase + pl;
+    const bool live = m < p.M;
+    const uint32_t um = (uint32_t)(live ? m : p.M - 1);
+    const uint32_t b = (__umulhi(um, p.mul_hw) + um) >> p.sh_hw;
+    const uint32_t rem = um - b * (uint32_t)p.HoWo;
+    const uint32_t y = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
+    const uint32_t x = rem - y * (uint32_t)p.Wo;
+    const float *t_ = sL + pl * LD + a * p.y_attr;
+    const int ncls = p.y_attr - 5;
+    const int per = (ncls + 3) >> 2;
+    const int c_lo = sub * per, c_hi = c_lo + per < ncls ? c_lo + per : ncls;
+    float mx = -INFINITY;
+    for (int c = c_lo; c < c_hi; ++c) mx = fmaxf(mx, t_[5 + c]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float sum = 0.f, best = -1.f;
+    int best_c = 0;
+    for (int c = c_lo; c < c_hi; ++c) {
+      const float e = expf(t_[5 + c] - mx);
+      sum += e;
+      if (e > best) {
+        best = e;
+        best_c = c;
+      }
+    }
+#pragma unroll
+    for (int d = 1; d <= 2; d <<= 1) {
+      const float os = __shfl_xor(sum, d, 64), ob = __shfl_xor(best, d, 64);
+      const int oc = __shfl_xor(best_c, d, 64);
+      sum += os;
+      if (ob > best || (ob == best && oc < best_c)) {
+        best = ob;
+        best_c = oc;
+      }
+    }
+    if (!live || sub != 0) continue;
+    const float bx = (1.0f / (1.0f + expf(-t_[0])) + (float)x) / (float)p.Wo;
+    const float by = (1.0f / (1.0f + expf(-t_[1])) + (float)y) / (float)p.Ho;
+    const float bw = (expf(t_[2]) * p.y_aw[a]) / p.y_net_w;
+    const float bh = (expf(t_[3]) * p.y_ah[a]) / p.y_net_h;
+    const float obj = 1.0f / (1.0f + expf(-t_[4]));
+    const float score = (best / sum) * obj;
+    const long long row = (long long)b * p.y_rows_total + p.y_row_offset + (long long)a * p.HoWo + (long long)y * p.Wo + x;
+    *reinterpret_cast<f32x4 *>(p.y_bbox + row * 4) = f32x4{bx, by, bw, bh};
+    p.y_prob[row] = score;
+    p.y_cls[row] = best_c;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // v2: LDS-DMA pipeline.  Same tile geometry and LDS image as above, but
 //   * operands go global -> LDS directly (global_load_lds_dwordx4, 16 B per lane, 1 KiB per wave
@@ -273,7 +339,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
 //       2: BKE % Cin == 0, Cin < BKE (several whole taps per K-tile, e.g. Cin = 32 with bf16)
 // (Measured and removed: a register-staged single-stage form, 64-byte K rows for three workgroups per CU, and a
 // 256x128 eight-wave tile -- all within +-8 % of this one, none better: profiles/r01_convbench_variants.txt.)
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KMODE>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, bool DECODE = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(IgemmArgs p) {
   constexpr int RB = 128;                            // bytes of K per tile row
   constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -491,11 +557,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
         const int prow = wm * TM + mi * 16;       // first pixel row of this 16-row fragment (compile-time per wm)
         if (prow / RP == h) {
           const int pl = prow + fr - h * RP;
-          *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
+          if constexpr (DECODE) {
+            // logits = sum * scale + bias (the conv epilogue's single fused rounding), row stride BN + 1 floats
+            const f32x4 hs = *reinterpret_cast<const f32x4 *>(p.scale + n0 + cl);
+            const f32x4 hb = *reinterpret_cast<const f32x4 *>(p.bias + n0 + cl);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sC[pl * (BN + 1) + cl + r] = __builtin_fmaf(acc[mi][ni][r], hs[r], hb[r]);
+          } else {
+            *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
+          }
         }
       }
     }
     __syncthreads();
+    if constexpr (DECODE) {
+      static_assert(RP * (BN + 1) * 4 <= LDS_BYTES, "padded logit tile must fit in the operand stages");
+      head_decode_rows<NT, BN + 1>(p, sC, m0 + h * RP, RP, tid);
+      continue;
+    }
     if (nvalid <= 0) continue;
 #pragma unroll
     for (int j = 0; j < WR; ++j) {
@@ -940,6 +1019,7 @@ extern "C" int y3_set_tuning(const char *key, int value) {
   if (!strcmp(key, "igemm_bm")) { g_igemm_bm = value; return Y3_OK; }
   if (!strcmp(key, "igemm_ns")) { g_igemm_ns = value; return Y3_OK; }
   if (!strcmp(key, "auto_mask")) { g_y3_auto_mask = value; return Y3_OK; }
+  if (!strcmp(key, "fuse_head")) { extern int g_y3_fuse_head; g_y3_fuse_head = value; return Y3_OK; }
   if (!strcmp(key, "use_graph")) { g_y3_use_graph = value; return Y3_OK; }
   if (!strcmp(key, "halo_persistent")) { g_y3_halo_persistent = value; return Y3_OK; }
   if (!strcmp(key, "decode_lanes")) { extern int g_y3_decode_lanes; g_y3_decode_lanes = value; return Y3_OK; }
@@ -1033,3 +1113,56 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
 }
 
 Y3_STAMP_READER(y3_debug_stamps_igemm)
+
+// ---- detection head: 1x1 conv (bias, no activation, float32 logits) + YOLO decode in one launch -------------------
+// op0: the head conv as the plan holds it (Y3_F_OUT_F32, Cout = anchors * attributes <= 256); op1: the Y3_OP_YOLO op
+// reading it.  bf16 networks only: the float32 parity path keeps the two kernels (sequential class loop).
+int g_y3_fuse_head = 1;   // tuning knob "fuse_head" (takes effect at y3_plan_create)
+
+bool y3_conv_head_decode_supported(const y3_op &op0, const y3_op &op1) {
+  if (!g_y3_fuse_head) return false;
+  if (op0.kind != Y3_OP_CONV || op1.kind != Y3_OP_YOLO || op0.dtype != Y3_BF16) return false;
+  if (op0.ksize != 1 || op0.stride != 1 || !(op0.flags & Y3_F_OUT_F32)) return false;
+  if (op0.flags & (Y3_F_LEAKY | Y3_F_RESIDUAL | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT)) return false;
+  if (!y3_conv_igemm_supported(op0) || op0.in_c % 64 != 0 || op0.out_c > 256 || op0.cout_pad < 256) return false;
+  if (op1.d_in != op0.d_out || op1.in_ld != op0.out_ld || op1.in_h != op0.out_h || op1.in_w != op0.out_w) return false;
+  if (op1.batch != op0.batch || op1.n_anchor < 1 || op1.n_anchor > 8 || op1.n_attr <= 5) return false;
+  if (op1.n_anchor * op1.n_attr != op0.out_c) return false;
+  return op1.d_bbox && op1.d_prob && op1.d_cls;
+}
+
+int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d_zero, hipStream_t s,
+                               const char **kernel_name, bool dry_run) {
+  *kernel_name = "conv_head_decode_bf16_128x256";
+  if (dry_run) return Y3_OK;
+  IgemmArgs a;
+  a.in = static_cast<const char *>(op0.d_in);
+  a.wgt = static_cast<const char *>(op0.d_weight);
+  a.scale = op0.d_scale;
+  a.bias = op0.d_bias;
+  a.res = nullptr;
+  a.out = nullptr;
+  a.zero = static_cast<const char *>(d_zero);
+  a.H = op0.in_h; a.W = op0.in_w; a.Cin = op0.in_c; a.in_ld = op0.in_ld;
+  a.Ho = op0.out_h; a.Wo = op0.out_w; a.Cout = op0.out_c; a.out_ld = op0.out_ld; a.res_ld = 0;
+  a.ks = 1; a.stride = 1; a.pad = 0;
+  a.HoWo = op0.out_h * op0.out_w;
+  a.M = op0.batch * a.HoWo;
+  a.k_ld = op0.k_ld;
+  a.K = op0.in_c;
+  a.ktiles_per_tap = op0.in_c / 64;
+  a.n_ktiles = a.ktiles_per_tap;
+  a.flags = op0.flags;
+  igemm_fast_div((uint32_t)a.HoWo, a.mul_hw, a.sh_hw);
+  igemm_fast_div((uint32_t)a.Wo, a.mul_w, a.sh_w);
+  a.y_bbox = op1.d_bbox; a.y_prob = op1.d_prob; a.y_cls = reinterpret_cast<long long *>(op1.d_cls);
+  a.y_anchors = op1.n_anchor; a.y_attr = op1.n_attr;
+  a.y_row_offset = op1.row_offset; a.y_rows_total = op1.rows_total;
+  a.y_net_w = op1.net_w; a.y_net_h = op1.net_h;
+  for (int i = 0; i < 8; ++i) { a.y_aw[i] = op1.anchor_w[i]; a.y_ah[i] = op1.anchor_h[i]; }
+  a.m_tiles = y3_ceil_div(a.M, 128);
+  a.n_tiles = 1;
+  hipLaunchKernelGGL((conv_igemm2_kernel<bf16_t, 128, 256, 2, 4, 0, true>), dim3(a.m_tiles), dim3(512), 0, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}

@@ -98,7 +98,7 @@ def test_mini_bf16_uint8_stem_matches_bf16_float_stem():
     assert (a["class_idx"] == b["class_idx"]).float().mean() > 0.97
 
 
-DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 157, "halo_persistent": 0, "fuse_stem": 1, "decode_lanes": 4, "use_graph": 0}
+DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 157, "halo_persistent": 0, "fuse_stem": 1, "decode_lanes": 4, "use_graph": 0, "fuse_head": 1}
 
 
 def test_tuning_knobs_do_not_change_results():
@@ -483,6 +483,30 @@ def test_fused_stem_and_stride2_conv_matches_unfused(dim, batch):
         torch.testing.assert_close(fused["bbox_xywh"], plain["bbox_xywh"], rtol=5e-2, atol=5e-3)
     finally:
         lib.y3_set_tuning(b"fuse_stem", 1)
+
+
+@pytest.mark.parametrize("model,dim,batch", [("yolov3", 608, 2), ("yolov3", 320, 3), ("yolov3-tiny", 416, 2), ("yolov3-spp", 416, 1)])
+def test_fused_head_conv_and_decode_matches_separate_kernels(model, dim, batch):
+    """Detection heads in bf16 networks: 1x1 conv + YOLO decode in one launch (float32 logits stay in LDS) against the
+    head conv kernel followed by the decode kernel."""
+    from yolov3 import _hip
+    lib = _hip.lib()
+    frames = synth_frames(17 + dim, batch, dim, dim)
+    try:
+        _hip.check(lib.y3_set_tuning(b"fuse_head", 1))
+        net = _net(model, dtype="bf16")
+        fused = {k: v.clone() for k, v in net.forward_frames(frames).items()}
+        names = [r["kernel"] for r in net.plan_report()]
+        assert sum(k == "conv_head_decode_bf16_128x256" for k in names) == (2 if model == "yolov3-tiny" else 3)
+        _hip.check(lib.y3_set_tuning(b"fuse_head", 0))
+        net2 = _net(model, dtype="bf16")
+        plain = net2.forward_frames(frames)
+        assert not any("head_decode" in r["kernel"] for r in net2.plan_report())
+        assert torch.equal(fused["class_idx"], plain["class_idx"])
+        torch.testing.assert_close(fused["class_prob"], plain["class_prob"], rtol=2e-6, atol=1e-9)
+        torch.testing.assert_close(fused["bbox_xywh"], plain["bbox_xywh"], rtol=2e-6, atol=1e-9)
+    finally:
+        lib.y3_set_tuning(b"fuse_head", 1)
 
 
 def test_split_class_decode_matches_sequential_decode():
