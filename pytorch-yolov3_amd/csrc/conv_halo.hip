@@ -43,6 +43,7 @@ struct HaloArgs {
   int k_ld;
   int nchunks;         // Cin / BKE
   int n_tiles;
+  int hr;              // halo rows that hold pixels (256 + 2W + 2); strip kernel: row `hr` of each buffer is all zero
   int hr_pad;          // halo rows, padded to a multiple of the loader's rows-per-pass
   int na;              // loader passes per halo (= glds per thread per halo)
   int a_bytes;         // hr_pad * 128
@@ -147,8 +148,9 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     const int kc = slot ^ (row0 & 7);
     const long long q0 = (long long)m0 - p.W - 1;     // flattened input pixel of halo row 0
     auto issue_halo_pass = [&](int chunk, int pass, bool live) {
-      const long long q = q0 + row0 + pass * RPL;
-      const bool ok = live && q >= 0 && q < p.M;
+      const int row = row0 + pass * RPL;
+      const long long q = q0 + row;
+      const bool ok = live && row < p.hr && q >= 0 && q < p.M;   // rows >= hr stay zero: row hr is the consumers' zero row
       const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
       char *dst = sA + (chunk & 1) * p.a_bytes + pass * (NL * 16) + lwave * 1024;
       __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       const long long m = (long long)m0 + px;
       const bool ok = px < BM && m < p.M;
       const char *src = ok ? p.res + (m * p.res_ld + n0) * ES + cb : p.zero;
-      const int pass = sl < p.na ? sl : p.na - 1;      // any slice position inside the idle halo buffer
+      const int pass = sl < p.na - 1 ? sl : p.na - 2;  // any slice of the idle halo buffer but the last (zero row)
       char *dst = sA + (chunk & 1) * p.a_bytes + pass * (NL * 16) + lwave * 1024;
       __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
     };
@@ -243,19 +245,46 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     const int b_lane_row = wn * 64 + fr;
     const int b_off0 = b_lane_row * 128 + (((0 + fq) ^ (b_lane_row & 7)) << 4);
     const int b_off1 = b_lane_row * 128 + (((4 + fq) ^ (b_lane_row & 7)) << 4);
-    auto read_frags = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], const char *aBuf, const char *bBuf, int a_shift, int g) {
-      const int r0 = a_lane_row + a_shift;
-      const char *ap = aBuf + r0 * 128 + (((g * 4 + fq) ^ (r0 & 7)) << 4);
-      const char *bp = bBuf + (g ? b_off1 : b_off0);
+    // Border taps (zero padding, row wrap of the raster strip) are not cleared in registers: the fragment's LDS address
+    // is redirected to the all-zero row `hr` of halo buffer 0 instead -- one select per fragment of K-half 0; K-half 1
+    // of the same tap is the same address with bit 6 flipped (the XOR swizzle), for the zero row as well.  (The K loop
+    // is VALU-issue bound: PMC)
+    // (absolute LDS byte addresses, so that nothing but the immediate is added per read; the workgroup's LDS block and
+    // the halo buffers are 128-byte aligned, which the bit-6 flip relies on)
+    typedef const __attribute__((address_space(3))) u32x4 lds_u32x4;
+    const int sA_lds = (int)(size_t)(lds_void *)sA;
+    int zalt[MI], sel[MI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const u32x4 *>(ap + mi * 2048);
+    for (int mi = 0; mi < MI; ++mi) {
+      zalt[mi] = sA_lds + p.hr * 128 - mi * 2048;
+      asm volatile("" : "+v"(zalt[mi]));               // lives in a VGPR: v_cndmask takes one scalar operand, the condition
+    }
+    auto read_frags0 = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], int a_off, const char *bBuf, int a_shift, int tap) {
+      const int r0 = a_lane_row + a_shift;
+      const int ap = ((r0 << 7) + (a_off + sA_lds)) + ((fq ^ (r0 & 7)) << 4);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        int off = ((tapmask[mi] >> tap) & 1u) ? ap : zalt[mi];
+        asm volatile("" : "+v"(off));                  // keeps `+ mi * 2048` in the ds_read's immediate offset
+        sel[mi] = off;
+        xf[mi] = *reinterpret_cast<lds_u32x4 *>(off + mi * 2048);
+      }
+      const char *bp = bBuf + b_off0;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
     };
-    auto mma_all = [&](u32x4 (&xf)[MI], const u32x4 (&wf)[NI], int tap) {
+    auto read_frags1 = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], const char *bBuf) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        if (!((tapmask[mi] >> tap) & 1u)) xf[mi] = u32x4{0u, 0u, 0u, 0u};
+      for (int mi = 0; mi < MI; ++mi) {
+        int off = sel[mi] ^ 64;
+        asm volatile("" : "+v"(off));
+        xf[mi] = *reinterpret_cast<lds_u32x4 *>(off + mi * 2048);
+      }
+      const char *bp = bBuf + b_off1;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
+    };
+    auto mma_all = [&](const u32x4 (&xf)[MI], const u32x4 (&wf)[NI]) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -272,7 +301,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     __builtin_amdgcn_s_barrier();                     // B(0): halo(0), weights(0), weights(1) are in LDS
     Y3_STAMP(0);
     u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
-    read_frags(xf0, wf0, sA, sB, 0, 0);
+    read_frags0(xf0, wf0, 0, sB, 0, 0);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     int tap = 0, chunk = 0, ring = 0;
 #pragma unroll 1
@@ -287,11 +316,9 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
 #else
 #define Y3_W0(slot) do {} while (0)
 #endif
-      const char *aBuf = sA + (chunk & 1) * p.a_bytes;
-      const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
       __builtin_amdgcn_sched_barrier(0);
-      read_frags(xf1, wf1, aBuf, sB + ring * B_BYTES, ky * p.W + kx, 1);
-      mma_all(xf0, wf0, tap);
+      read_frags1(xf1, wf1, sB + ring * B_BYTES);
+      mma_all(xf0, wf0);
       interleave();
       __builtin_amdgcn_sched_barrier(0);
       Y3_W0(2);
@@ -302,9 +329,9 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       const int ring_n = ring + 1 == NSB ? 0 : ring + 1;
       {
         const int ky_n = (tap_n * 11) >> 5, kx_n = tap_n - ky_n * 3;
-        read_frags(xf0, wf0, sA + (chunk_n & 1) * p.a_bytes, sB + ring_n * B_BYTES, ky_n * p.W + kx_n, 0);
+        read_frags0(xf0, wf0, (chunk_n & 1) * p.a_bytes, sB + ring_n * B_BYTES, ky_n * p.W + kx_n, tap_n);
       }
-      mma_all(xf1, wf1, tap);
+      mma_all(xf1, wf1);
       interleave();
       __builtin_amdgcn_sched_barrier(0);
       Y3_W0(4);
@@ -992,7 +1019,8 @@ template <typename T>
 int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
   HaloArgs a = a0;
   const int hr = 256 + 2 * a.W + 2;
-  a.na = y3_ceil_div(hr, 32);
+  a.hr = hr;
+  a.na = y3_ceil_div(hr + 1, 32);                     // + the zero row
   a.hr_pad = a.na * 32;
   a.a_bytes = a.hr_pad * 128;
   // the next chunk's halo goes out two passes per K-step and must be older than the last loads allowed in flight
@@ -1100,7 +1128,7 @@ bool y3_conv_halo_eligible(const y3_op &op) {
 // real halo slices must be out by tap 6 of the previous chunk (<= 14 passes of 32 rows)
 bool y3_conv_halo_ws_fits(const y3_op &op) {
   if (!y3_conv_halo_eligible(op)) return false;
-  const int na = y3_ceil_div(256 + 2 * op.in_w + 2, 32);
+  const int na = y3_ceil_div(256 + 2 * op.in_w + 3, 32);
   return na <= 14 && (size_t)3 * 128 * 128 + (size_t)2 * na * 32 * 128 <= 160 * 1024;
 }
 
