@@ -65,6 +65,34 @@ __device__ __forceinline__ float y3_from_float<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ bf16_t y3_from_float<bf16_t>(float v) { return (bf16_t)v; }
 
+// Conv epilogue arithmetic for eight consecutive output channels: acc * scale + bias, then LeakyReLU(0.1).  Written
+// on 2-wide vectors so that hipcc emits v_pk_fma_f32 / v_pk_mul_f32, and with v_max_f32 spelled out: max(v, 0.1 v) is
+// v > 0 ? v : 0.1 v bit for bit (both operands carry v's sign), one instruction instead of compare + select, and fmaxf
+// would add a canonicalising v_max per value.  The epilogues are VALU-bound (MI355X: 4 cycles per instruction and
+// wave, 64 values per lane and tile).
+__device__ __forceinline__ float y3_vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// `leaky` is a run-time flag of the layer: a slope of 1 makes max(v, slope * v) the identity without a branch (phi
+// copies of all eight values otherwise)
+__device__ __forceinline__ void y3_bn_leaky8(float (&v)[8], const f32x4 &lo, const f32x4 &hi, const f32x4 &sc_lo,
+                                             const f32x4 &sc_hi, const f32x4 &bi_lo, const f32x4 &bi_hi, bool leaky) {
+  const float slope = leaky ? Y3_LEAKY_SLOPE : 1.0f;
+  f32x2 t[4];
+  t[0] = f32x2{lo[0], lo[1]} * f32x2{sc_lo[0], sc_lo[1]} + f32x2{bi_lo[0], bi_lo[1]};
+  t[1] = f32x2{lo[2], lo[3]} * f32x2{sc_lo[2], sc_lo[3]} + f32x2{bi_lo[2], bi_lo[3]};
+  t[2] = f32x2{hi[0], hi[1]} * f32x2{sc_hi[0], sc_hi[1]} + f32x2{bi_hi[0], bi_hi[1]};
+  t[3] = f32x2{hi[2], hi[3]} * f32x2{sc_hi[2], sc_hi[3]} + f32x2{bi_hi[2], bi_hi[3]};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 s = t[i] * slope;
+    v[2 * i] = y3_vmax(t[i][0], s[0]);
+    v[2 * i + 1] = y3_vmax(t[i][1], s[1]);
+  }
+}
+
 // Diagnostic build only (-DY3_STAMPS, `make stamps`): per-workgroup phase timing with s_memtime.
 // Lane 0 of wave 0 adds the cycle count of each phase into g_y3_stamps[phase]; slot 7 counts
 // workgroups.  Never compiled into the shipped library.
@@ -108,8 +136,32 @@ __device__ __forceinline__ unsigned long long y3_now() {
 #define Y3_STAMP_COUNT() do {} while (0)
 #endif
 
+// Y3_STAMPS_CLOCK (diagnostic, `make stamps STAMP_FLAGS=-DY3_STAMPS_CLOCK`): no stamp inside the K loop; thread 0
+// stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around it: slot 0 = loop cycles, slot 1 = loop time in
+// 10 ns ticks (in-kernel clock = slot0 / slot1 * 100 MHz: MI355X_MICROARCH.md, DVFS give-back item 6), slot 2 =
+// cycles before the loop, slot 3 = cycles after it
+#if defined(Y3_STAMPS) && defined(Y3_STAMPS_CLOCK)
+#undef Y3_STAMP
+#define Y3_STAMP(slot) do {} while (0)
+__device__ __forceinline__ unsigned long long y3_now_real() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define Y3_CLK_BEGIN() unsigned long long _clk_r0 = 0; do { const unsigned long long _n = y3_now(); _st_acc[2] = _n - _st_prev; _st_prev = _n; _clk_r0 = y3_now_real(); } while (0)
+#define Y3_CLK_END() do { const unsigned long long _n = y3_now(); _st_acc[0] = _n - _st_prev; _st_prev = _n; _st_acc[1] = y3_now_real() - _clk_r0; } while (0)
+#define Y3_CLK_TAIL() do { if (threadIdx.x == 0) { _st_acc[3] = y3_now() - _st_prev; for (int _i = 0; _i < 4; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]); atomicAdd(&g_y3_stamps[7], 1ull); } } while (0)
+#else
+#define Y3_CLK_BEGIN() do {} while (0)
+#define Y3_CLK_END() do {} while (0)
+#define Y3_CLK_TAIL() do {} while (0)
+#endif
+
 // Y3_STAMPS_FINE (diagnostic): the ping-pong kernel stamps the pieces of its K-step instead of its phases
-#if defined(Y3_STAMPS) && defined(Y3_STAMPS_FINE)
+#if defined(Y3_STAMPS) && defined(Y3_STAMPS_CLOCK)
+#define Y3_FINE(slot) do {} while (0)
+#define Y3_COARSE(slot) do {} while (0)
+#elif defined(Y3_STAMPS) && defined(Y3_STAMPS_FINE)
 #define Y3_FINE(slot) Y3_STAMP(slot)
 #define Y3_COARSE(slot) do { _st_prev = y3_now(); } while (0)
 #else

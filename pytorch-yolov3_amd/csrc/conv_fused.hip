@@ -64,8 +64,8 @@ __device__ __forceinline__ u32x2 bn_leaky_bf16x4(const f32x4 &a, const f32x4 &sc
   const f32x2 lo = f32x2{a[0], a[1]} * f32x2{sc[0], sc[1]} + f32x2{bi[0], bi[1]};
   const f32x2 hi = f32x2{a[2], a[3]} * f32x2{sc[2], sc[3]} + f32x2{bi[2], bi[3]};
   const f32x2 tl = lo * Y3_LEAKY_SLOPE, th = hi * Y3_LEAKY_SLOPE;
-  const bf16x4 o = {(bf16_t)fmaxf(lo[0], tl[0]), (bf16_t)fmaxf(lo[1], tl[1]), (bf16_t)fmaxf(hi[0], th[0]),
-                    (bf16_t)fmaxf(hi[1], th[1])};
+  const bf16x4 o = {(bf16_t)y3_vmax(lo[0], tl[0]), (bf16_t)y3_vmax(lo[1], tl[1]), (bf16_t)y3_vmax(hi[0], th[0]),
+                    (bf16_t)y3_vmax(hi[1], th[1])};
   return __builtin_bit_cast(u32x2, o);
 }
 

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       Y3_COARSE(5);
     }
     wait_vmcnt<0>();                                  // the tail's dummy loads must not land on the output tile
-#if defined(Y3_STAMPS) && !defined(Y3_STAMPS_FINE)
+#if defined(Y3_STAMPS) && !defined(Y3_STAMPS_FINE) && !defined(Y3_STAMPS_CLOCK)
     if (tid == NC) for (int _i = 3; _i < 7; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]);
 #endif
   } else {
@@ -300,6 +300,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     Y3_STAMP(2);
     __builtin_amdgcn_s_barrier();                     // B(0): halo(0), weights(0), weights(1) are in LDS
     Y3_STAMP(0);
+    Y3_CLK_BEGIN();
     u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
     read_frags0(xf0, wf0, 0, sB, 0, 0);
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -345,7 +346,9 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       chunk = chunk_n;
       ring = ring_n;
     }
-#if defined(Y3_STAMPS_FINE)
+    Y3_CLK_END();
+#if defined(Y3_STAMPS_CLOCK)
+#elif defined(Y3_STAMPS_FINE)
     if (tid == 0) {
       for (int _i = 0; _i < 6; ++_i) if (_i != 1) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]);
       atomicAdd(&g_y3_stamps[7], 1ull);
@@ -413,15 +416,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
     const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
     float v[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[r] = lo[r] * sc_lo[r] + bi_lo[r];
-      v[4 + r] = hi[r] * sc_hi[r] + bi_hi[r];
-    }
-    if (leaky) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : Y3_LEAKY_SLOPE * v[r];
-    }
+    y3_bn_leaky8(v, lo, hi, sc_lo, sc_hi, bi_lo, bi_hi, leaky);
     if (has_res) {
       if constexpr (sizeof(T) == 2) {
         const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[j]);
@@ -445,6 +440,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
     }
   }
+  Y3_CLK_TAIL();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -686,15 +682,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_wsp_kernel(HaloArgs p, int n
         const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * 64 + (((2 * oc) ^ pl) << 2));
         const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * 64 + (((2 * oc + 1) ^ pl) << 2));
         float v[8];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          v[q] = lo[q] * sc_lo[q] + bi_lo[q];
-          v[4 + q] = hi[q] * sc_hi[q] + bi_hi[q];
-        }
-        if (leaky) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = v[q] > 0.f ? v[q] : Y3_LEAKY_SLOPE * v[q];
-        }
+        y3_bn_leaky8(v, lo, hi, sc_lo, sc_hi, bi_lo, bi_hi, leaky);
         if (m < p.M) {
           if (has_res) {
             if constexpr (sizeof(T) == 2) {
@@ -970,15 +958,7 @@ __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int 
         const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * 64 + (((2 * oc) ^ pl) << 2));
         const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * 64 + (((2 * oc + 1) ^ pl) << 2));
         float v[8];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          v[q] = lo[q] * sc_lo[q] + bi_lo[q];
-          v[4 + q] = hi[q] * sc_hi[q] + bi_hi[q];
-        }
-        if (leaky) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = v[q] > 0.f ? v[q] : Y3_LEAKY_SLOPE * v[q];
-        }
+        y3_bn_leaky8(v, lo, hi, sc_lo, sc_hi, bi_lo, bi_hi, leaky);
         if (oy < p.H && ox < p.W) {
           if (has_res) {
             if constexpr (sizeof(T) == 2) {

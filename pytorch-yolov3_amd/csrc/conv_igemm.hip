@@ -584,15 +584,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
       const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
       const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
       float v[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = lo[r] * sc_lo[r] + bi_lo[r];
-        v[4 + r] = hi[r] * sc_hi[r] + bi_hi[r];
-      }
-      if (leaky) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : Y3_LEAKY_SLOPE * v[r];
-      }
+      y3_bn_leaky8(v, lo, hi, sc_lo, sc_hi, bi_lo, bi_hi, leaky);
       if (has_res) {
         if (res_fast) {
           if constexpr (sizeof(T) == 2) {
@@ -890,15 +882,7 @@ void conv_igemm3_kernel(IgemmArgs p) {
     const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
     const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
     float v[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[r] = lo[r] * sc_lo[r] + bi_lo[r];
-      v[4 + r] = hi[r] * sc_hi[r] + bi_hi[r];
-    }
-    if (leaky) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : Y3_LEAKY_SLOPE * v[r];
-    }
+    y3_bn_leaky8(v, lo, hi, sc_lo, sc_hi, bi_lo, bi_hi, leaky);
     if (has_res) {
       if (res_fast) {
         if constexpr (sizeof(T) == 2) {
