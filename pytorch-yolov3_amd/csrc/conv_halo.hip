@@ -12,8 +12,9 @@
 // order (b, y, x flattened) x 128 output channels and stages, per 128-byte channel chunk, the
 // 256 + 2W + 2 input pixels that ALL nine taps of those outputs touch -- once.  Tap (ky,kx) of
 // output pixel p is halo row  p + ky*W + kx, so the nine K-steps of a chunk read the same LDS
-// image at nine row offsets.  Row-wrap / image-border taps (the zero padding) are cleared in
-// registers with a per-pixel 9-bit mask after the fragment read.  Only the weight tile (128 rows x
+// image at nine row offsets.  Row-wrap / image-border taps (the zero padding): conv_halo_ws_kernel
+// redirects the lane's fragment address to an all-zero row of the halo image; the persistent variant
+// still clears the fragment in registers with a per-pixel 9-bit mask.  Only the weight tile (128 rows x
 // 128 B) changes per K-step; it streams through a 3- or 4-slot LDS ring.  Bytes through the LDS-DMA
 // path per FLOP drop ~3x versus the 128x128 implicit GEMM.
 //
@@ -716,7 +717,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_wsp_kernel(HaloArgs p, int n
 // where the raster strip's halo of 2W + 2 rows no longer fits in LDS): a workgroup owns an 8 x 32 output tile and
 // stages the 10 x 34 input patch per channel chunk (one LDS row per patch pixel, out-of-frame pixels as zeros).  Tap
 // (ky, kx) of output (y, x) is patch row (y + ky) * 34 + x + kx: rows never wrap, so the fragment masking of the strip
-// kernels (56 of ~125 VALU instructions per wave and K-step) disappears.  Loaders, weight ring, barriers and the
+// kernels disappears.  Loaders, weight ring, barriers and the
 // per-wave epilogue are those of conv_halo_wsp_kernel.  Cost: tiles that hang over the right / bottom edge compute
 // pixels nobody stores (152 = 4.75 x 32: 5 %), which is why narrow maps stay on the strip kernels.
 template <typename T, int NSB>
