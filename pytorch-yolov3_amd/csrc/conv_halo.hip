@@ -365,54 +365,6 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     }
 #endif
   }
-  // ---- bf16 epilogue, straight from the accumulators: a lane holds four consecutive output channels of one pixel per
-  // (mi, ni), i.e. 8 bytes of NHWC output; the four ni stores of a pixel fill one 128-byte line.  No LDS round trip
-  // and no workgroup barrier: a wave that leaves the K loop early writes out under the other waves' MFMAs.
-  if constexpr (sizeof(T) == 2) {
-    if (loader) return;
-    const float slope = (p.flags & Y3_F_LEAKY) ? Y3_LEAKY_SLOPE : 1.0f;   // max(v, 1 * v) == v
-    const bool has_res = p.flags & Y3_F_RESIDUAL;
-    const int cbase = n0 + wn * 64 + fq * 4;
-    f32x4 sc[NI], bi[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      sc[ni] = *reinterpret_cast<const f32x4 *>(p.scale + cbase + ni * 16);
-      bi[ni] = *reinterpret_cast<const f32x4 *>(p.bias + cbase + ni * 16);
-    }
-    u32x2 rv[MI][NI];
-    if (has_res) {
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + fr;
-        const char *rp = p.res + ((long long)m * p.res_ld + cbase) * 2;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          rv[mi][ni] = m < p.M ? *reinterpret_cast<const u32x2 *>(rp + ni * 32) : u32x2{0u, 0u};
-      }
-    }
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m = m0 + wm * 64 + mi * 16 + fr;
-      char *op = p.out + ((long long)m * p.out_ld + cbase) * 2;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const f32x4 a = acc[mi][ni];
-        f32x2 lo = f32x2{a[0], a[1]} * f32x2{sc[ni][0], sc[ni][1]} + f32x2{bi[ni][0], bi[ni][1]};
-        f32x2 hi = f32x2{a[2], a[3]} * f32x2{sc[ni][2], sc[ni][3]} + f32x2{bi[ni][2], bi[ni][3]};
-        const f32x2 tl = lo * slope, th = hi * slope;
-        lo = f32x2{y3_vmax(lo[0], tl[0]), y3_vmax(lo[1], tl[1])};
-        hi = f32x2{y3_vmax(hi[0], th[0]), y3_vmax(hi[1], th[1])};
-        if (has_res) {
-          const u32x2 r = rv[mi][ni];
-          lo += f32x2{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xffff0000u)};
-          hi += f32x2{__builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xffff0000u)};
-        }
-        const bf16x4 o = {(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)hi[0], (bf16_t)hi[1]};
-        if (m < p.M) *reinterpret_cast<u32x2 *>(op + ni * 32) = __builtin_bit_cast(u32x2, o);
-      }
-    }
-    return;
-  }
   // ---- epilogue (the 512 consumer threads write out; the loaders only keep the barrier count) ----
   constexpr int SWZ = 15;
   constexpr int OCT_PER_ROW = BN / 8;
