@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: step i runs on HIP stream i %% streams with its own arena, so "
                          "one batch's kernel tails overlap the next batch's ramp-up (1 = strictly serial steps)")
+    ap.add_argument("--h2d", action="store_true",
+                    help="PCIe-inclusive variant (never the headline value): frames start in pinned host memory and are "
+                         "copied to the GPU inside every step, the packed detection records are copied back")
     ap.add_argument("--tuning", default="", help="A/B runs: comma-separated y3_set_tuning knobs, e.g. auto_mask=15")
     return ap.parse_args()
 
@@ -115,12 +118,40 @@ def main():
     det = dets[0]
     lib = _hip.lib()
 
+    host_frames = dev_frames = host_rec = copy_stream = free_ev = ready_ev = None
+    h2d_parts = int(os.environ.get("Y3_BENCH_H2D_PARTS", "3"))   # diagnostic: 1 = frames in only, 2 = records out only
+    if args.h2d:
+        host_frames = torch.from_numpy(synth_frames(123 + rank, b, dim, dim)).pin_memory()
+        dev_frames = [torch.empty_like(frames) for _ in range(nstream)]
+        copy_stream = torch.cuda.Stream(device=dev)
+        free_ev = [torch.cuda.Event() for _ in range(nstream)]
+        ready_ev = [torch.cuda.Event() for _ in range(nstream)]
+        for e in free_ev:
+            e.record()
+
     def step(fr, i=0):
+        nonlocal host_rec
         k = i % nstream
         with torch.cuda.stream(streams[k]):
+            if args.h2d and (h2d_parts & 1):
+                # the copy runs on its own stream (one step ahead of the compute stream that consumes it)
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(free_ev[k])
+                    dev_frames[k].copy_(host_frames, non_blocking=True)
+                    ready_ev[k].record(copy_stream)
+                streams[k].wait_event(ready_ev[k])
+                fr = dev_frames[k]
             o = net.forward_frames(fr, fresh=False, slot=k)
+            if args.h2d and (h2d_parts & 1):
+                free_ev[k].record(streams[k])
             dets[k].run(o, orig_hw, 0.05, 0.3)
-            return gathers[k].run(dets[k])
+            rec = gathers[k].run(dets[k])
+            if args.h2d and (h2d_parts & 2):
+                if host_rec is None:
+                    host_rec = [[torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in rec] for _ in range(nstream)]
+                for h, t in zip(host_rec[k], rec):
+                    h.copy_(t, non_blocking=True)
+            return rec
 
     for i in range(max(args.warmup, nstream)):
         step(warm_frames, i)
@@ -215,9 +246,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%s %dx%d batch=%d/GPU %s, procedural weights, uint8 frames resident in HBM -> "
+            "config": {"workload": "%s %dx%d batch=%d/GPU %s, procedural weights, uint8 frames %s -> "
                                    "detections (thr 0.05, NMS IoU 0.3), ~%d kept/frame" % (
-                                       args.model, dim, dim, b, args.dtype, n_cand_note),
+                                       args.model, dim, dim, b, args.dtype,
+                                       "in pinned host memory, H2D + records D2H inside the step (PCIe-inclusive, not "
+                                       "the headline)" if args.h2d else "resident in HBM", n_cand_note),
                        "frames_per_gpu": b, "global_batch": b * world, "parallelism": "dp%d" % world,
                        "batches_in_flight_per_gpu": nstream,
                        "collective": "all_gather(%d x %d x 8 int32 records)" % (b, args.kmax) if distributed else "none"},

@@ -170,6 +170,21 @@ def test_bench_prints_one_contract_json_line():
 
 
 @pytest.mark.gpu
+def test_bench_pcie_inclusive_variant_runs():
+    """`bench.py --h2d` (frames start in pinned host memory, records come back to the host inside every step): runs,
+    says so in config.workload; it is a side figure, never the headline value."""
+    import subprocess
+    import sys
+    from golden_util import ROOT
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "yolov3-tiny", "--dim", "416",
+                           "--batch", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--h2d"],
+                          capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    d = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][0])
+    assert d["value"] > 0 and "PCIe-inclusive" in d["config"]["workload"]
+
+
+@pytest.mark.gpu
 def test_bench_under_torchrun_runs_the_rccl_plumbing():
     """One rank under torchrun with Y3_BENCH_FORCE_DIST=1: process-group init on RCCL, barriers, the per-step
     all-gather of detection records issued from three streams, the max all-reduce and the teardown all execute on a
