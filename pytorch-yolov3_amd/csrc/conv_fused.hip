@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs p
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = a[r] * s3[r] + b3[r];
-          v = fmaxf(v, Y3_LEAKY_SLOPE * v);
+          v = y3_vmax(v, Y3_LEAKY_SLOPE * v);
           o[r] = (bf16_t)(v + (float)xv[r]);
         }
         const int px = oyl * kRT + fr;
