@@ -13,8 +13,8 @@
 // 256 + 2W + 2 input pixels that ALL nine taps of those outputs touch -- once.  Tap (ky,kx) of
 // output pixel p is halo row  p + ky*W + kx, so the nine K-steps of a chunk read the same LDS
 // image at nine row offsets.  Row-wrap / image-border taps (the zero padding): conv_halo_ws_kernel
-// redirects the lane's fragment address to an all-zero row of the halo image; the persistent variant
-// still clears the fragment in registers with a per-pixel 9-bit mask.  Only the weight tile (128 rows x
+// and its persistent variant redirect the lane's fragment address to an all-zero row of the halo
+// image (no data instructions).  Only the weight tile (128 rows x
 // 128 B) changes per K-step; it streams through a 3- or 4-slot LDS ring.  Bytes through the LDS-DMA
 // path per FLOP drop ~3x versus the 128x128 implicit GEMM.
 //
@@ -491,8 +491,9 @@ __global__ __launch_bounds__(768, 3) void conv_halo_wsp_kernel(HaloArgs p, int n
     const int kc = slot ^ (row0 & 7);
     // halo slice `pass` of chunk `chunk` of the tile whose first halo pixel is q0, into halo buffer `buf`
     auto issue_halo_pass = [&](long long q0, int chunk, int pass, int buf, bool live) {
-      const long long q = q0 + row0 + pass * RPL;
-      const bool ok = live && q >= 0 && q < p.M;
+      const int row = row0 + pass * RPL;
+      const long long q = q0 + row;
+      const bool ok = live && row < p.hr && q >= 0 && q < p.M;   // rows >= hr stay zero (the consumers' zero row)
       const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
       char *dst = sA + buf * p.a_bytes + pass * (NL * 16) + lwave * 1024;
       __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
@@ -589,19 +590,42 @@ __global__ __launch_bounds__(768, 3) void conv_halo_wsp_kernel(HaloArgs p, int n
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto read_frags = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], const char *aBuf, const char *bBuf, int a_shift, int g) {
-      const int r0 = a_lane_row + a_shift;
-      const char *ap = aBuf + r0 * 128 + (((g * 4 + fq) ^ (r0 & 7)) << 4);
-      const char *bp = bBuf + (g ? b_off1 : b_off0);
+    // border taps read the all-zero row `hr` of halo buffer 0 instead of their (wrapped) neighbour: see
+    // conv_halo_ws_kernel
+    typedef const __attribute__((address_space(3))) u32x4 lds_u32x4;
+    const int sA_lds = (int)(size_t)(lds_void *)sA;
+    int zalt[MI], sel[MI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const u32x4 *>(ap + mi * 2048);
+    for (int mi = 0; mi < MI; ++mi) {
+      zalt[mi] = sA_lds + p.hr * 128 - mi * 2048;
+      asm volatile("" : "+v"(zalt[mi]));
+    }
+    auto read_frags0 = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], int a_off, const char *bBuf, int a_shift, int tap) {
+      const int r0 = a_lane_row + a_shift;
+      const int ap = ((r0 << 7) + (a_off + sA_lds)) + ((fq ^ (r0 & 7)) << 4);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        int off = ((tapmask[mi] >> tap) & 1u) ? ap : zalt[mi];
+        asm volatile("" : "+v"(off));
+        sel[mi] = off;
+        xf[mi] = *reinterpret_cast<lds_u32x4 *>(off + mi * 2048);
+      }
+      const char *bp = bBuf + b_off0;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
     };
-    auto mma_all = [&](u32x4 (&xf)[MI], const u32x4 (&wf)[NI], int tap) {
+    auto read_frags1 = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], const char *bBuf) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        if (!((tapmask[mi] >> tap) & 1u)) xf[mi] = u32x4{0u, 0u, 0u, 0u};
+      for (int mi = 0; mi < MI; ++mi) {
+        int off = sel[mi] ^ 64;
+        asm volatile("" : "+v"(off));
+        xf[mi] = *reinterpret_cast<lds_u32x4 *>(off + mi * 2048);
+      }
+      const char *bp = bBuf + b_off1;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
+    };
+    auto mma_all = [&](const u32x4 (&xf)[MI], const u32x4 (&wf)[NI]) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -616,17 +640,15 @@ __global__ __launch_bounds__(768, 3) void conv_halo_wsp_kernel(HaloArgs p, int n
     };
     __builtin_amdgcn_s_barrier();                      // B(0) of this tile
     u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
-    read_frags(xf0, wf0, sA + (gchunk & 1) * p.a_bytes, sB + ring * B_BYTES, 0, 0);
+    read_frags0(xf0, wf0, (gchunk & 1) * p.a_bytes, sB + ring * B_BYTES, 0, 0);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     int tap = 0;
 #pragma unroll 1
     for (int it = 0; it < nit; ++it) {
       if (it) __builtin_amdgcn_s_barrier();
-      const char *aBuf = sA + (gchunk & 1) * p.a_bytes;
-      const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
       __builtin_amdgcn_sched_barrier(0);
-      read_frags(xf1, wf1, aBuf, sB + ring * B_BYTES, ky * p.W + kx, 1);
-      mma_all(xf0, wf0, tap);
+      read_frags1(xf1, wf1, sB + ring * B_BYTES);
+      mma_all(xf0, wf0);
       interleave();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -635,9 +657,9 @@ __global__ __launch_bounds__(768, 3) void conv_halo_wsp_kernel(HaloArgs p, int n
       const int ring_n = ring + 1 == NSB ? 0 : ring + 1;
       {
         const int ky_n = (tap_n * 11) >> 5, kx_n = tap_n - ky_n * 3;
-        read_frags(xf0, wf0, sA + (gchunk_n & 1) * p.a_bytes, sB + ring_n * B_BYTES, ky_n * p.W + kx_n, 0);
+        read_frags0(xf0, wf0, (gchunk_n & 1) * p.a_bytes, sB + ring_n * B_BYTES, ky_n * p.W + kx_n, tap_n);
       }
-      mma_all(xf1, wf1, tap);
+      mma_all(xf1, wf1);
       interleave();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -1033,7 +1055,8 @@ template <typename T>
 int launch_halo_wsp(const HaloArgs &a0, hipStream_t s) {
   HaloArgs a = a0;
   const int hr = 256 + 2 * a.W + 2;
-  a.na = y3_ceil_div(hr, 32);
+  a.hr = hr;
+  a.na = y3_ceil_div(hr + 1, 32);                     // + the zero row
   a.hr_pad = a.na * 32;
   a.a_bytes = a.hr_pad * 128;
   int nsb = 0;
