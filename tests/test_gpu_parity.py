@@ -209,6 +209,46 @@ def test_gpu_matches_oracle_on_fresh_input():
         assert abs(len(a[1]) - len(b[1])) <= 2
 
 
+@pytest.mark.parametrize("h,w", [(352, 480), (512, 320)])
+def test_yolov3_float32_matches_oracle_at_other_input_sizes(h, w):
+    """Darknet-53 at input sizes other than the cfg's: feature-map rows of 60 / 30 / 15, 44 / 22 / 11, 64 / 32 / 16 and
+    40 / 20 / 10 pixels (halo rows that are an exact multiple of the loader pass at 15, different weight-ring depths,
+    strips that span several frames at the coarse scales), non-square.  float32 HIP path against the CPU oracle."""
+    net = _net("yolov3")
+    ref = orc.OracleDarknet(MODELS["yolov3"]).load_weights(golden_weights_path("yolov3"))
+    frames = synth_frames(h + w, 2, h, w)
+    x = torch.from_numpy(orc.frames_to_input(list(frames)))
+    want = ref.forward(x)
+    got = net.forward(x)
+    np.testing.assert_allclose(got["bbox_xywh"].cpu().numpy(), want["bbox_xywh"].numpy(), rtol=1e-4, atol=BOX_ATOL)
+    np.testing.assert_allclose(got["class_prob"].cpu().numpy(), want["class_prob"].numpy(), atol=SCORE_ATOL)
+    assert (got["class_idx"].cpu().numpy() == want["class_idx"].numpy()).mean() > 0.999
+
+
+@pytest.mark.parametrize("h,w", [(352, 480), (512, 320), (480, 480)])
+def test_yolov3_bf16_kernel_choices_agree_at_other_input_sizes(h, w):
+    """Same sizes in bf16: the default kernel selection (halo / patch / fused kernels) against the plain implicit GEMM
+    everywhere (`auto_mask` 0, no fusion) on the same frames -- different summation orders of the same bf16 products."""
+    from yolov3 import _hip
+    lib = _hip.lib()
+    frames = synth_frames(h * 3 + w, 2, h, w)
+    try:
+        net = _net("yolov3", dtype="bf16")
+        fast = {k: v.clone() for k, v in net.forward_frames(frames).items()}
+        for key, val in (("auto_mask", 0), ("fuse_stem", 0), ("fuse_head", 0)):
+            _hip.check(lib.y3_set_tuning(key.encode(), val))
+        net2 = _net("yolov3", dtype="bf16")
+        plain = net2.forward_frames(frames)
+        assert not any("halo" in r["kernel"] or "patch" in r["kernel"] or "fused" in r["kernel"] for r in net2.plan_report())
+        d = (fast["class_prob"] - plain["class_prob"]).abs()
+        assert float(d.max()) < 0.1 and float(d.median()) < 2e-3, (float(d.max()), float(d.median()))
+        assert float((fast["class_idx"] == plain["class_idx"]).float().mean()) > 0.97
+        torch.testing.assert_close(fast["bbox_xywh"], plain["bbox_xywh"], rtol=5e-2, atol=5e-3)
+    finally:
+        for key, val in DEFAULT_KNOBS.items():
+            lib.y3_set_tuning(key.encode(), val)
+
+
 def test_nms_cases_match_reference():
     with open(os.path.join(GOLDEN, "nms_cases.json")) as fh:
         cases = json.load(fh)
