@@ -594,30 +594,29 @@ __global__ __launch_bounds__(768, 3) void conv_halo_wsp_kernel(HaloArgs p, int n
     // conv_halo_ws_kernel
     typedef const __attribute__((address_space(3))) u32x4 lds_u32x4;
     const int sA_lds = (int)(size_t)(lds_void *)sA;
-    int zalt[MI], sel[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      zalt[mi] = sA_lds + p.hr * 128 - mi * 2048;
-      asm volatile("" : "+v"(zalt[mi]));
-    }
+    // (this kernel carries a tile loop's worth of extra state: the zero-row addresses are rebuilt per use and the
+    // K-half-1 addresses recomputed instead of carried, to stay inside 168 VGPRs)
+    int zrow = sA_lds + p.hr * 128;
+    asm volatile("" : "+v"(zrow));
     auto read_frags0 = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], int a_off, const char *bBuf, int a_shift, int tap) {
       const int r0 = a_lane_row + a_shift;
       const int ap = ((r0 << 7) + (a_off + sA_lds)) + ((fq ^ (r0 & 7)) << 4);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        int off = ((tapmask[mi] >> tap) & 1u) ? ap : zalt[mi];
+        int off = ((tapmask[mi] >> tap) & 1u) ? ap : zrow - mi * 2048;
         asm volatile("" : "+v"(off));
-        sel[mi] = off;
         xf[mi] = *reinterpret_cast<lds_u32x4 *>(off + mi * 2048);
       }
       const char *bp = bBuf + b_off0;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
     };
-    auto read_frags1 = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], const char *bBuf) {
+    auto read_frags1 = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], int a_off, const char *bBuf, int a_shift, int tap) {
+      const int r0 = a_lane_row + a_shift;
+      const int ap = ((r0 << 7) + (a_off + sA_lds)) + (((4 + fq) ^ (r0 & 7)) << 4);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        int off = sel[mi] ^ 64;
+        int off = ((tapmask[mi] >> tap) & 1u) ? ap : zrow - mi * 2048;
         asm volatile("" : "+v"(off));
         xf[mi] = *reinterpret_cast<lds_u32x4 *>(off + mi * 2048);
       }
@@ -646,8 +645,9 @@ __global__ __launch_bounds__(768, 3) void conv_halo_wsp_kernel(HaloArgs p, int n
 #pragma unroll 1
     for (int it = 0; it < nit; ++it) {
       if (it) __builtin_amdgcn_s_barrier();
+      const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
       __builtin_amdgcn_sched_barrier(0);
-      read_frags1(xf1, wf1, sB + ring * B_BYTES);
+      read_frags1(xf1, wf1, (gchunk & 1) * p.a_bytes, sB + ring * B_BYTES, ky * p.W + kx, tap);
       mma_all(xf0, wf0);
       interleave();
       __builtin_amdgcn_sched_barrier(0);
@@ -1179,7 +1179,8 @@ int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, h
   const int es = y3_elem_size(op.dtype);
   const bool bf = op.dtype == Y3_BF16;
   Y3_REQUIRE(y3_conv_halo_ws_fits(op), "conv block %d: shape not supported by the halo kernel", op.block_idx);
-  if (persistent) *kernel_name = bf ? "conv_halo_wsp_bf16_256x128" : "conv_halo_wsp_f32_256x128";
+  persistent = persistent && bf;   // the persistent variant is a bf16 throughput kernel (float32: > 168 VGPRs of state)
+  if (persistent) *kernel_name = "conv_halo_wsp_bf16_256x128";
   else *kernel_name = bf ? "conv_halo_ws_bf16_256x128" : "conv_halo_ws_f32_256x128";
   if (dry_run) return Y3_OK;
   HaloArgs a;
@@ -1201,7 +1202,7 @@ int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, h
   fast_div((uint32_t)a.W, a.mul_w, a.sh_w);
   a.flags = op.flags;
   Y3_REQUIRE((long long)op.batch * a.HW < (1ll << 31), "conv block %d: too many pixels for the 32-bit tile index", op.block_idx);
-  if (persistent) return bf ? launch_halo_wsp<bf16_t>(a, s) : launch_halo_wsp<float>(a, s);
+  if (persistent) return launch_halo_wsp<bf16_t>(a, s);
   return bf ? launch_halo_ws<bf16_t>(a, s) : launch_halo_ws<float>(a, s);
 }
 
