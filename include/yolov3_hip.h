@@ -137,7 +137,7 @@ int y3_conv_path(const y3_op *op);
  *                     implicit GEMM (api.hip)
  *   "halo_persistent" 0 [default] one tile per workgroup, 1 persistent tile loop
  *   "igemm_version"   1 register-staged, 2 LDS-DMA double-buffered [default], 3 wave-specialised
- *   "igemm_ns"        LDS stages of version 3 (2..4);  "igemm_bm" 64 = 64-pixel tiles for version 3 (bf16)
+ *   "igemm_ns"        LDS stages of version 3 (3 or 4; less means 3);  "igemm_bm" 64 = 64-pixel tiles for version 3 (bf16)
  *   "use_graph"       1: y3_plan_run replays a captured hipGraph (one launch per forward) on non-default streams;
  *                     0 [default]: every kernel is launched individually (measured 1 % faster at batch 16)
  * Results do not depend on the knobs beyond floating-point summation order.                          */

@@ -52,7 +52,6 @@ VARIANTS = [
     ("halo_wsp", dict(BASE, auto_mask=21, halo_persistent=1)),
     ("patch_8x32", dict(BASE, auto_mask=21 | 128)),
     ("igemm_v3_ns3", dict(BASE, igemm_version=3, igemm_ns=3)),
-    ("igemm_v3_ns2", dict(BASE, igemm_version=3, igemm_ns=2)),
     ("igemm_v3_ns4", dict(BASE, igemm_version=3, igemm_ns=4)),
     ("igemm_v3_bm64_ns4", dict(BASE, igemm_version=3, igemm_ns=4, igemm_bm=64)),
     ("igemm_v3_bm64_ns3", dict(BASE, igemm_version=3, igemm_ns=3, igemm_bm=64)),
