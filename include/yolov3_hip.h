@@ -135,7 +135,7 @@ int y3_conv_path(const y3_op *op);
  *                     than 128 px (bit 7), the wave-specialised implicit GEMM for 1x1 layers with Cin >= 1024 (bit 3);
  *                     0 = implicit GEMM v2 everywhere; bits 1 / 5 / 6 route more layers to the wave-specialised
  *                     implicit GEMM (api.hip)
- *   "halo_persistent" 0 [default] one tile per workgroup, 1 persistent tile loop
+ *   "halo_persistent" 0 [default] one tile per workgroup, 1 persistent tile loop (bf16 networks; float32 keeps 0)
  *   "igemm_version"   1 register-staged, 2 LDS-DMA double-buffered [default], 3 wave-specialised
  *   "igemm_ns"        LDS stages of version 3 (3 or 4; less means 3);  "igemm_bm" 64 = 64-pixel tiles for version 3 (bf16)
  *   "use_graph"       1: y3_plan_run replays a captured hipGraph (one launch per forward) on non-default streams;
