@@ -2,7 +2,7 @@
 """Benchmark of the MI355X YOLOv3 hot path (BASELINE.json metric: frames/sec at 608x608).
 
 One "step" = one pass of the whole path over one batch of synthetic frames that are already
-resident in HBM: uint8 BGR frames -> fused preprocess + Darknet-53 convs (HIP implicit GEMM)
+resident in HBM: uint8 BGR frames -> fused preprocess + Darknet-53 convs (HIP MFMA kernels)
 -> 3 YOLO heads decode -> threshold/scale/int/tlbr + per-class NMS on device -> padded
 detection records (and, for N > 1 ranks, an RCCL all-gather of those records).
 
@@ -19,6 +19,10 @@ import json
 import os
 import sys
 import time
+
+# RCCL between processes on this driver stack needs dmabuf IPC (already exported on the pool's boxes; kept here so a
+# bare environment behaves the same)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pytorch-yolov3_amd"))
