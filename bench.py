@@ -4,19 +4,28 @@
 One "step" = one pass of the whole path over one batch of synthetic frames that are already
 resident in HBM: uint8 BGR frames -> fused preprocess + Darknet-53 convs (HIP MFMA kernels)
 -> 3 YOLO heads decode -> threshold/scale/int/tlbr + per-class NMS on device -> padded
-detection records (and, for N > 1 ranks, an RCCL all-gather of those records).
+detection records (and, for N > 1 ranks, ONE RCCL all-gather of those records per step, on a side stream).
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `value` = frames of all ranks / max-over-ranks wall time.
-`roofline` is measured live with HIP events around every kernel of the plan (same stream);
-`cpu_baseline` times the CPU oracle (the "-d cpu" restatement) on a bounded sample.
+With N > 1 and no torchrun environment the process starts its N ranks itself (``python -m torch.distributed.run``,
+one process per GPU, rendezvous on 127.0.0.1) before anything touches a GPU, relays rank 0's JSON line and exits
+non-zero if a rank fails or fewer than N GPUs are visible.  Launched under torchrun it is one rank of the job.
+
+Rank 0 prints ONE JSON line.  `value` = frames of all ranks / max-over-ranks wall time of exactly K steps.
+At N = 1 the same run also measures and reports, in that line:
+  roofline        dominant kernel, HIP events around every launch on the launch stream (serial passes)
+  cpu_baseline    the CPU oracle (the reference's "-d cpu" op sequence) on the host cores, SURVEY.md 8(d) protocol
+  pcie_inclusive  the same workload with frames starting in pinned host memory and records copied back every step
+  other_configs   BASELINE.json's other single-GPU configurations (parity cases, each with its own roofline)
+  bf16_agreement  bf16 detections against the reference's float32 detections on the golden frames (tests/golden)
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,9 +42,10 @@ import torch  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "float32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA)
 MODEL_FLOPS_PER_FRAME = {("yolov3", 608): 140.692e9, ("yolov3-tiny", 416): 5.565e9, ("yolov3-spp", 608): 141.449e9}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -48,17 +58,20 @@ def parse_args():
                     help="objectness bias of the procedural weights (sets candidates/frame)")
     ap.add_argument("--kmax", type=int, default=512, help="detection records per frame in the gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip pcie_inclusive / other_configs / bf16_agreement (A/B runs, profiling)")
+    ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU-baseline work (bounded sample)")
     ap.add_argument("--profile-passes", type=int, default=3)
     ap.add_argument("--dump-ops", default=None, help="write the per-op timing table (text) to this file")
     ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: step i runs on HIP stream i %% streams with its own arena, so "
                          "one batch's kernel tails overlap the next batch's ramp-up (1 = strictly serial steps)")
     ap.add_argument("--h2d", action="store_true",
-                    help="PCIe-inclusive variant (never the headline value): frames start in pinned host memory and are "
-                         "copied to the GPU inside every step, the packed detection records are copied back")
+                    help="make the PCIe-inclusive variant the timed region (never the headline value): frames start in "
+                         "pinned host memory and are copied to the GPU inside every step, the packed detection records "
+                         "are copied back")
     ap.add_argument("--tuning", default="", help="A/B runs: comma-separated y3_set_tuning knobs, e.g. auto_mask=15")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def usable_cpus():
@@ -75,117 +88,183 @@ def usable_cpus():
     return max(1, n)
 
 
-def main():
-    args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torchrun
+# ------------------------------------------------------------------------------------------------
+
+def self_launch(args, argv):
+    """Start N ranks as a child torch.distributed.run job.  Runs BEFORE this process has made any GPU call (a
+    process that has initialised the GPU must not exec / is not what gets replaced here: the job is a child)."""
+    plumbing = os.environ.get("Y3_BENCH_PLUMBING")
+    if not plumbing:
+        visible = torch.cuda.device_count()        # counts devices without initialising the GPU runtime
+        if visible < args.gpus:
+            sys.stderr.write("bench.py: %d GPUs requested, %d visible -- refusing to run fewer ranks than asked for\n" % (
+                args.gpus, visible))
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // args.gpus)))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, universal_newlines=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(proc.stdout[-4000:])
+        sys.stderr.write("\nbench.py: the %d-rank job failed (exit code %d, %d JSON lines)\n" % (
+            args.gpus, proc.returncode, len(lines)))
+        return proc.returncode or 1
+    print(lines[0], flush=True)
+    return 0
+
+
+def plumbing_main(args, backend):
+    """Y3_BENCH_PLUMBING=gloo: no GPU work.  The same rank / shard / barrier / one-all-gather-per-step / max-over-ranks
+    skeleton as the real run, over gloo on CPU tensors: what tests/test_dist_gloo.py uses to check the launcher."""
     import torch.distributed as dist
-    # Y3_BENCH_FORCE_DIST=1 (under torchrun with one process): run the RCCL plumbing -- init, barrier, all-gather,
-    # all-reduce -- with a single rank, so the multi-GPU code path can be exercised on a one-GPU box
-    distributed = world > 1 or os.environ.get("Y3_BENCH_FORCE_DIST") == "1"
-    torch.cuda.set_device(local_rank)
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from yolov3.dist import all_gather_records, counts_of, pack_records_host
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("Y3_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend=backend)
+    b = args.batch
+    rs = np.random.RandomState(rank)
+    dets = []
+    for _ in range(b):
+        k = int(rs.randint(0, 9))
+        dets.append([rs.randint(0, 600, size=(k, 4)), rs.rand(k).astype(np.float32), rs.randint(0, 80, size=k),
+                     rs.randint(0, 22743, size=k)])
+    rec = torch.from_numpy(pack_records_host(dets, args.kmax))
+    for _ in range(args.warmup):
+        all_gather_records(rec, world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = all_gather_records(rec, world)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec (608x608)", "value": None, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "plumbing_only": True, "ranks_seen_by_collective": dist.get_world_size(),
+                          "frames_gathered_per_step": int(counts_of(out).shape[0]),
+                          "config": {"global_batch": b * world, "parallelism": "dp%d" % world}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
 
-    import yolov3
-    from yolov3 import _hip, weights as W
-    from yolov3.inference import Detector
-    from yolov3.synthdata import synth_frames
-    from yolov3.dist import DetectionGather
 
-    dev = torch.device("cuda", local_rank)
-    for kv in filter(None, args.tuning.split(",")):
-        key, val = kv.split("=")
-        _hip.check(_hip.lib().y3_set_tuning(key.encode(), int(val)))
-    cfg = os.path.join(ROOT, "pytorch-yolov3_amd", "models", args.model + ".cfg")
-    net = yolov3.Darknet(cfg, device="cuda:%d" % local_rank, dtype=args.dtype).eval()
-    params = W.synth_params(net.blocks, net.net_info, seed=0, obj_bias=args.obj_bias,
-                            calib=W.load_calibration(args.model))
-    net.set_params(params)
+# ------------------------------------------------------------------------------------------------
+# one workload on this rank's GPU
+# ------------------------------------------------------------------------------------------------
 
-    b, dim = args.batch, args.dim
-    # distinct frames per rank (data-parallel shards), resident in HBM before timing starts
-    frames = torch.from_numpy(synth_frames(123 + rank, b, dim, dim)).to(dev)
-    warm_frames = torch.from_numpy(synth_frames(1000 + rank, b, dim, dim)).to(dev)
-    orig_hw = torch.tensor([[dim, dim]] * b, dtype=torch.int32, device=dev)
+class Workload(object):
+    """model x input size x batch x dtype on one GPU: net, resident frames, per-stream detector / gather buffers."""
 
-    out = net.forward_frames(warm_frames, fresh=False)
-    rows = out["class_prob"].shape[1]
-    nstream = max(1, args.streams)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
-    dets = [Detector(b, rows, dev) for _ in range(nstream)]
-    gathers = [DetectionGather(b, rows, args.kmax, dev, world) for _ in range(nstream)]
-    det = dets[0]
-    lib = _hip.lib()
+    def __init__(self, model, dim, batch, dtype, params, dev, rank, world, kmax, nstream):
+        import yolov3
+        from yolov3.inference import Detector
+        from yolov3.synthdata import synth_frames
+        from yolov3.dist import DetectionGather
+        self.model, self.dim, self.batch, self.dtype, self.dev, self.nstream = model, dim, batch, dtype, dev, nstream
+        cfg = os.path.join(ROOT, "pytorch-yolov3_amd", "models", model + ".cfg")
+        self.cfg = cfg
+        self.net = yolov3.Darknet(cfg, device=str(dev), dtype=dtype).eval()
+        self.net.set_params(params)
+        self.frames_np = synth_frames(123 + rank, batch, dim, dim)
+        # distinct frames per rank (data-parallel shards), resident in HBM before timing starts
+        self.frames = torch.from_numpy(self.frames_np).to(dev)
+        self.warm_frames = torch.from_numpy(synth_frames(1000 + rank, batch, dim, dim)).to(dev)
+        self.orig_hw = torch.tensor([[dim, dim]] * batch, dtype=torch.int32, device=dev)
+        out = self.net.forward_frames(self.warm_frames, fresh=False)
+        self.rows = out["class_prob"].shape[1]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
+        self.dets = [Detector(batch, self.rows, dev) for _ in range(nstream)]
+        self.gathers = [DetectionGather(batch, self.rows, kmax, dev, world) for _ in range(nstream)]
+        self.h2d = None
 
-    host_frames = dev_frames = host_rec = copy_stream = free_ev = ready_ev = None
-    h2d_parts = int(os.environ.get("Y3_BENCH_H2D_PARTS", "3"))   # diagnostic: 1 = frames in only, 2 = records out only
-    if args.h2d:
-        host_frames = torch.from_numpy(synth_frames(123 + rank, b, dim, dim)).pin_memory()
-        dev_frames = [torch.empty_like(frames) for _ in range(nstream)]
-        copy_stream = torch.cuda.Stream(device=dev)
-        free_ev = [torch.cuda.Event() for _ in range(nstream)]
-        ready_ev = [torch.cuda.Event() for _ in range(nstream)]
-        for e in free_ev:
+    def enable_h2d(self, parts=3):
+        self.h2d = dict(parts=parts, host_frames=torch.from_numpy(self.frames_np).pin_memory(),
+                        dev_frames=[torch.empty_like(self.frames) for _ in range(self.nstream)],
+                        copy_stream=torch.cuda.Stream(device=self.dev), host_rec=None,
+                        free_ev=[torch.cuda.Event() for _ in range(self.nstream)],
+                        ready_ev=[torch.cuda.Event() for _ in range(self.nstream)])
+        for e in self.h2d["free_ev"]:
             e.record()
 
-    def step(fr, i=0):
-        nonlocal host_rec
-        k = i % nstream
-        with torch.cuda.stream(streams[k]):
-            if args.h2d and (h2d_parts & 1):
+    def step(self, fr, i=0, h2d=False):
+        k = i % self.nstream
+        h = self.h2d if h2d else None
+        with torch.cuda.stream(self.streams[k]):
+            if h and (h["parts"] & 1):
                 # the copy runs on its own stream (one step ahead of the compute stream that consumes it)
-                with torch.cuda.stream(copy_stream):
-                    copy_stream.wait_event(free_ev[k])
-                    dev_frames[k].copy_(host_frames, non_blocking=True)
-                    ready_ev[k].record(copy_stream)
-                streams[k].wait_event(ready_ev[k])
-                fr = dev_frames[k]
-            o = net.forward_frames(fr, fresh=False, slot=k)
-            if args.h2d and (h2d_parts & 1):
-                free_ev[k].record(streams[k])
-            dets[k].run(o, orig_hw, 0.05, 0.3)
-            rec = gathers[k].run(dets[k])
-            if args.h2d and (h2d_parts & 2):
-                if host_rec is None:
-                    host_rec = [[torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in rec] for _ in range(nstream)]
-                for h, t in zip(host_rec[k], rec):
-                    h.copy_(t, non_blocking=True)
+                with torch.cuda.stream(h["copy_stream"]):
+                    h["copy_stream"].wait_event(h["free_ev"][k])
+                    h["dev_frames"][k].copy_(h["host_frames"], non_blocking=True)
+                    h["ready_ev"][k].record(h["copy_stream"])
+                self.streams[k].wait_event(h["ready_ev"][k])
+                fr = h["dev_frames"][k]
+            o = self.net.forward_frames(fr, fresh=False, slot=k)
+            if h and (h["parts"] & 1):
+                h["free_ev"][k].record(self.streams[k])
+            self.dets[k].run(o, self.orig_hw, 0.05, 0.3)
+            rec = self.gathers[k].run(self.dets[k])
+            if h and (h["parts"] & 2):
+                g = self.gathers[k]
+                if g.done is not None:
+                    self.streams[k].wait_event(g.done)
+                if h["host_rec"] is None:
+                    h["host_rec"] = [torch.empty(rec.shape, dtype=rec.dtype).pin_memory() for _ in range(self.nstream)]
+                h["host_rec"][k].copy_(rec, non_blocking=True)
             return rec
 
-    for i in range(max(args.warmup, nstream)):
-        step(warm_frames, i)
-    torch.cuda.synchronize()
+    def timed(self, steps, warmup, distributed=False, h2d=False):
+        """`warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize; max over ranks."""
+        import torch.distributed as dist
+        for i in range(max(warmup, self.nstream)):
+            self.step(self.warm_frames, i, h2d)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            self.step(self.frames, i, h2d)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
 
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        rec = step(frames, i)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def kept_per_frame(self):
+        return int(self.dets[0].count.cpu().numpy().mean())
 
-    counts = det.count.cpu().numpy()
-    n_cand_note = int(counts.mean())
-
-    # ---- per-kernel timing with HIP events on the launch stream (separate passes) -------------
-    report = None
-    if rank == 0:
+    def kernel_report(self, passes, dump_ops=None):
+        """Per-kernel device time with HIP events around every launch, serial passes on the launch stream (inside the
+        timed region several batches overlap and a launch's duration would include its neighbours')."""
+        net = self.net
         per_op = None
-        for _ in range(args.profile_passes):
-            net._run(frames, "u8", timed=True, fresh=False)
+        for _ in range(passes):
+            net._run(self.frames, "u8", timed=True, fresh=False)
             ms = np.array(net.last_op_ms)
             per_op = ms if per_op is None else np.minimum(per_op, ms)
         plan = net.plan_report()
@@ -196,9 +275,10 @@ def main():
             k["flops"] += op["flops"]
             k["bytes"] += op["bytes"]
             k["launches"] += 1
-        if args.dump_ops:
+        by_kernel.pop("(fused into the previous op)", None)
+        if dump_ops:
             desc = net._last_plan.desc["ops"]
-            with open(args.dump_ops, "w") as fh:
+            with open(dump_ops, "w") as fh:
                 fh.write("%4s %5s %-28s %-34s %9s %9s %9s\n" % ("op", "block", "kernel", "shape", "ms", "TFLOP/s", "GB/s"))
                 for i, (op, ms, od) in enumerate(zip(plan, per_op, desc)):
                     ti, to = od["inp"], od.get("out")
@@ -206,44 +286,188 @@ def main():
                     fh.write("%4d %5d %-28s %-34s %9.4f %9.1f %9.1f\n" % (
                         i, op["block"], op["kernel"], shape, ms, op["flops"] / max(ms, 1e-9) / 1e9, op["bytes"] / max(ms, 1e-9) / 1e6))
         dominant = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
-        dk = by_kernel[dominant]
+        return dict(by_kernel=by_kernel, dominant=dominant, plan_ms=float(per_op.sum()))
+
+    def roofline(self, report, traffic_table=None):
+        dk = report["by_kernel"][report["dominant"]]
         achieved = dk["flops"] / (dk["ms"] * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[args.dtype]
-        # HBM-side traffic of the dominant kernel comes from a separate rocprofv3 PMC run (FETCH_SIZE / WRITE_SIZE
-        # cannot share a pass, and counters cannot be read from inside this process); the committed summary of
-        # that run is looked up here, null if it does not cover this kernel
+        peak = PEAK_TFLOPS[self.dtype]
         traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-                traffic = json.load(fh).get(dominant, {}).get("traffic_bytes_per_launch")
-        except (OSError, ValueError):
-            pass
-        report = dict(by_kernel=by_kernel, dominant=dominant, achieved=achieved, peak=peak,
-                      plan_ms=float(per_op.sum()), traffic=traffic)
+        if traffic_table:
+            traffic = traffic_table.get("kernels", {}).get(report["dominant"], {}).get("traffic_bytes_per_launch")
+        return {"bound": "mfma", "kernel": report["dominant"], "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(dk["bytes"] / dk["launches"]),
+                "algorithmic_flops_per_launch": round(dk["flops"] / dk["launches"]),
+                "timing": "HIP events around every launch, serial passes on the launch stream",
+                "launches_per_step": dk["launches"], "kernel_ms_per_step": round(dk["ms"], 4),
+                "all_kernels_ms_per_step": round(report["plan_ms"], 4)}
 
-    # ---- CPU baseline: the oracle (reference "-d cpu" op sequence) on a bounded sample ----------
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import darknet_oracle as orc
-        torch.set_num_threads(usable_cpus())
-        onet = orc.OracleDarknet(cfg).set_params(params)
-        cpu_frames = [f for f in synth_frames(123, args.cpu_frames, dim, dim)]
-        orc.inference(onet, cpu_frames[:1], 0.05, 0.3)           # warm-up
-        reps, t_cpu = 0, 0.0
-        while reps < 2 or (t_cpu < 12.0 and reps < 200):     # ~12 s of CPU work on the bounded sample
+
+def lib_sha256():
+    from yolov3 import _hip
+    with open(os.path.abspath(_hip.LIB_PATH), "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
+def load_traffic_table():
+    """HBM-side traffic per launch comes from separate rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a
+    pass and counters cannot be read from inside this process): tools/traffic_pmc.sh -> profiles/r02_traffic.json,
+    which records the sha256 of the library it measured.  A table measured on another binary is not used."""
+    try:
+        with open(TRAFFIC_FILE) as fh:
+            table = json.load(fh)
+    except (OSError, ValueError):
+        return None, "no traffic table"
+    if table.get("lib_sha256") != lib_sha256():
+        return None, "traffic table is from another build of libyolov3_hip.so (stale): null"
+    return table, "HBM bytes per launch, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE in separate passes (%s, same binary)" % (
+        os.path.relpath(TRAFFIC_FILE, ROOT))
+
+
+def cpu_baseline(cfg, params, model, dim, budget_s):
+    """the reference's "-d cpu" op sequence (oracle/: torch-CPU Conv2d -> BN -> LeakyReLU as separate
+    float32 ops, NCHW, numpy greedy NMS) on the host cores, batch 1 and batch 16, 3 warm-up + 10 timed iterations,
+    median -- bounded by `budget_s` seconds of CPU work (fewer iterations if the budget runs out; said in `sample`)."""
+    from oracle import darknet_oracle as orc
+    from yolov3.synthdata import synth_frames
+    cores = usable_cpus()
+    torch.set_num_threads(cores)
+    onet = orc.OracleDarknet(cfg).set_params(params)
+    frames = [f for f in synth_frames(123, 16, dim, dim)]
+    out = {}
+    spent = 0.0
+    for batch, share in ((1, 0.2), (16, 0.8)):
+        times = []
+        warm = 0
+        limit = spent + budget_s * share if batch == 1 else budget_s
+        while len(times) < 10:
             c0 = time.perf_counter()
-            orc.inference(onet, cpu_frames, 0.05, 0.3)
-            t_cpu += time.perf_counter() - c0
-            reps += 1
-        cpu = dict(value=round(reps * len(cpu_frames) / t_cpu, 3), unit="frames/s",
-                   cores=torch.get_num_threads(), kind="port",
-                   sample="%d passes of %d frames %s %dx%d fp32, torch-CPU conv/BN/leaky + numpy NMS (oracle/)" % (
-                       reps, len(cpu_frames), args.model, dim, dim))
+            orc.inference(onet, frames[:batch], 0.05, 0.3)
+            dt = time.perf_counter() - c0
+            spent += dt
+            if warm < 3 and (batch == 1 or spent + 2 * dt < limit):
+                warm += 1
+                continue
+            times.append(dt)
+            if spent + dt > limit and len(times) >= 2:
+                break
+        med = float(np.median(times))
+        out[batch] = dict(fps=round(batch / med, 3), median_s=round(med, 4), warmup=warm, timed=len(times))
+    return dict(value=out[16]["fps"], unit="frames/s", cores=cores, cpu_model=cpu_model(), kind="port",
+                batch1=out[1], batch16=out[16],
+                sample="%s %dx%d float32, torch-CPU conv/BN/leaky + numpy NMS (oracle/), %d threads; batch 1: %d warm-up + %d "
+                       "timed, batch 16: %d warm-up + %d timed iterations, median (%.0f s of CPU work)" % (
+                           model, dim, dim, cores, out[1]["warmup"], out[1]["timed"], out[16]["warmup"], out[16]["timed"], spent))
 
+
+def bf16_agreement(dev):
+    """bf16 HIP detections against the reference's float32 ``inference()`` lists on the golden frames
+    (tests/golden/inference_yolov3.npz, produced by the reference; floors from the bf16-emulating oracle in
+    tests/golden/bf16_agreement.json).  Keep-set Jaccard by prediction row and score differences on common rows."""
+    import yolov3
+    from yolov3 import weights as W
+    from yolov3.synthdata import synth_frames
+    from PIL import Image
+    gdir = os.path.join(ROOT, "tests", "golden")
+    g = np.load(os.path.join(gdir, "inference_yolov3.npz"))
+    with open(os.path.join(gdir, "bf16_agreement.json")) as fh:
+        floors = json.load(fh)["yolov3"]
+
+    def jpeg(name):
+        return np.ascontiguousarray(np.asarray(Image.open(os.path.join(gdir, "images", name)).convert("RGB"))[:, :, ::-1])
+
+    frames = [jpeg("000000229358.jpg"), synth_frames(9, 1, 608, 608)[0], jpeg("000000393569.jpg")]
+    cfg = os.path.join(ROOT, "pytorch-yolov3_amd", "models", "yolov3.cfg")
+    net = yolov3.Darknet(cfg, device=str(dev), dtype="bf16").eval()
+    net.set_params(W.synth_params(net.blocks, net.net_info, seed=0, obj_bias=-5.0, calib=W.load_calibration("yolov3")))
+    out = {}
+    for tag in ("a", "b"):
+        pth, ith = g[tag + "_thresholds"]
+        res = yolov3.inference(net, frames, device=str(dev), prob_thresh=float(pth), nms_iou_thresh=float(ith), return_rows=True)
+        jac, ideal, dps, kept, ref_kept = [], [], [], 0, 0
+        for f in range(len(frames)):
+            key = "%s_f%d_" % (tag, f)
+            rows = set(int(r) for r in res[f][3])
+            want = set(g[key + "rows"].tolist())
+            gp = dict(zip(g[key + "rows"].tolist(), g[key + "prob"].tolist()))
+            mine = {int(r): k for k, r in enumerate(res[f][3])}
+            jac.append(len(rows & want) / len(rows | want) if rows | want else 1.0)
+            ideal.append(floors["%s_f%d" % (tag, f)]["jaccard"])
+            dps += [abs(float(res[f][1][mine[r]]) - gp[r]) for r in rows & want]
+            kept += len(rows)
+            ref_kept += len(want)
+        dps = np.array(dps) if dps else np.zeros(1)
+        out["thr_%.2f_iou_%.1f" % (pth, ith)] = dict(
+            keep_set_jaccard=[round(j, 4) for j in jac], ideal_bf16_jaccard=ideal, kept=kept, reference_kept=ref_kept,
+            score_abs_diff=dict(median=float(np.median(dps)), p90=float(np.percentile(dps, 90)),
+                                p99=float(np.percentile(dps, 99)), max=float(dps.max())))
+    out["note"] = ("yolov3 608 bf16 HIP path vs the reference's float32 inference() on 3 golden frames, procedural weights "
+                   "(thousands of overlapping near-threshold boxes per frame); ideal_bf16_jaccard = the bf16-emulating "
+                   "oracle on the same frames (tests/golden/bf16_agreement.json)")
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, argv)
+    plumbing = os.environ.get("Y3_BENCH_PLUMBING")
+    if plumbing and "WORLD_SIZE" in os.environ:
+        return plumbing_main(args, plumbing)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        return 2
+    import torch.distributed as dist
+    # Y3_BENCH_FORCE_DIST=1 (under torchrun with one process): run the RCCL plumbing -- init, barrier, all-gather,
+    # all-reduce -- with a single rank, so the multi-GPU code path can be exercised on a one-GPU box
+    distributed = world > 1 or os.environ.get("Y3_BENCH_FORCE_DIST") == "1"
+    if torch.cuda.device_count() <= local_rank:
+        sys.stderr.write("bench.py: rank %d needs GPU %d, %d visible\n" % (rank, local_rank, torch.cuda.device_count()))
+        return 2
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from yolov3 import _hip, weights as W
+    from yolov3.cfgparse import parse_config
+
+    for kv in filter(None, args.tuning.split(",")):
+        key, val = kv.split("=")
+        _hip.check(_hip.lib().y3_set_tuning(key.encode(), int(val)))
+
+    def params_for(model, obj_bias):
+        blocks, net_info = parse_config(os.path.join(ROOT, "pytorch-yolov3_amd", "models", model + ".cfg"))
+        return W.synth_params(blocks, net_info, seed=0, obj_bias=obj_bias, calib=W.load_calibration(model))
+
+    nstream = max(1, args.streams)
+    params = params_for(args.model, args.obj_bias)
+    wl = Workload(args.model, args.dim, args.batch, args.dtype, params, dev, rank, world, args.kmax, nstream)
+    if args.h2d:
+        wl.enable_h2d(int(os.environ.get("Y3_BENCH_H2D_PARTS", "3")))
+    elapsed = wl.timed(args.steps, args.warmup, distributed, h2d=args.h2d)
+    kept = wl.kept_per_frame()
+    ranks_seen = dist.get_world_size() if distributed else 1
+
+    extras = rank == 0 and world == 1 and not args.no_extras and not args.h2d
+    line = None
     if rank == 0:
-        total_frames = world * b * args.steps
-        fps = total_frames / elapsed
+        traffic_table, traffic_note = load_traffic_table()
+        report = wl.kernel_report(args.profile_passes, args.dump_ops)
+        b, dim = args.batch, args.dim
+        fps = world * b * args.steps / elapsed
         flops_frame = MODEL_FLOPS_PER_FRAME.get((args.model, dim))
+        roof = wl.roofline(report, traffic_table)
+        roof["traffic_unit"] = traffic_note
         line = {
             "metric": "frames/sec (608x608)" if dim == 608 else "frames/sec (%dx%d)" % (dim, dim),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -254,21 +478,14 @@ def main():
                                    "detections (thr 0.05, NMS IoU 0.3), ~%d kept/frame" % (
                                        args.model, dim, dim, b, args.dtype,
                                        "in pinned host memory, H2D + records D2H inside the step (PCIe-inclusive, not "
-                                       "the headline)" if args.h2d else "resident in HBM", n_cand_note),
+                                       "the headline)" if args.h2d else "resident in HBM", kept),
                        "frames_per_gpu": b, "global_batch": b * world, "parallelism": "dp%d" % world,
-                       "batches_in_flight_per_gpu": nstream,
-                       "collective": "all_gather(%d x %d x 8 int32 records)" % (b, args.kmax) if distributed else "none"},
-            "roofline": {"bound": "mfma", "kernel": report["dominant"], "achieved": round(report["achieved"], 2),
-                         "peak": report["peak"], "unit": "TFLOP/s", "frac": round(report["achieved"] / report["peak"], 4),
-                         "traffic": report["traffic"],
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_traffic.json)",
-                         "algorithmic_bytes_per_launch": round(report["by_kernel"][report["dominant"]]["bytes"] /
-                                                               report["by_kernel"][report["dominant"]]["launches"]),
-                         "timing": "HIP events around every launch, serial passes on the launch stream",
-                         "launches_per_step": report["by_kernel"][report["dominant"]]["launches"],
-                         "kernel_ms_per_step": round(report["by_kernel"][report["dominant"]]["ms"], 4),
-                         "all_kernels_ms_per_step": round(report["plan_ms"], 4)},
-            "cpu_baseline": cpu,
+                       "batches_in_flight_per_gpu": nstream, "ranks_seen_by_collective": ranks_seen,
+                       "collective": ("1 x all_gather_into_tensor(%d x %d x 8 int32 records) per step, side stream" % (
+                           b, args.kmax)) if distributed else "none"},
+            "roofline": roof,
+            "cpu_baseline": None,
+            "lib_sha256": lib_sha256()[:16],
         }
         if flops_frame:
             line["end_to_end_tflops"] = round(fps * flops_frame / 1e12, 2)
@@ -277,11 +494,52 @@ def main():
                                "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2),
                                "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
                            for k, v in report["by_kernel"].items()}
+
+    if extras:
+        # ---- PCIe-inclusive rate of the same workload (never `value`) ---------------------------------------
+        wl.enable_h2d(3)
+        e2 = wl.timed(args.steps, min(args.warmup, 5), False, h2d=True)
+        line["pcie_inclusive"] = {
+            "value": round(args.batch * args.steps / e2, 2), "unit": "frames/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
+            "what": "same workload, frames start in pinned host memory: H2D copy of the uint8 batch (copy stream, one step "
+                    "ahead) and D2H of the packed detection records inside every step"}
+        # ---- the other single-GPU configurations of BASELINE.json (parity cases; each with its own roofline) -----
+        others = []
+        for model, dim, batch, dtype in (("yolov3-tiny", 416, 8, "float32"), ("yolov3-spp", 608, 16, "bf16"),
+                                         ("yolov3", 608, 16, "float32")):
+            if (model, dim, batch, dtype) == (args.model, args.dim, args.batch, args.dtype):
+                continue
+            p = params if model == args.model else params_for(model, args.obj_bias)
+            w2 = Workload(model, dim, batch, dtype, p, dev, 0, 1, args.kmax, nstream)
+            steps = max(6, min(args.steps, 20 if dtype == "float32" else args.steps))
+            e = w2.timed(steps, 3, False)
+            rep = w2.kernel_report(2)
+            f = batch * steps / e
+            ff = MODEL_FLOPS_PER_FRAME.get((model, dim))
+            others.append({"workload": "%s %dx%d batch=%d %s" % (model, dim, dim, batch, dtype), "value": round(f, 2),
+                           "unit": "frames/s", "steps": steps, "ms_per_step": round(e / steps * 1e3, 4),
+                           "kept_per_frame": w2.kept_per_frame(),
+                           "end_to_end_frac_of_peak": round(f * ff / 1e12 / PEAK_TFLOPS[dtype], 4) if ff else None,
+                           "roofline": w2.roofline(rep, traffic_table)})
+            del w2
+            torch.cuda.empty_cache()
+        line["other_configs"] = others
+        try:
+            line["bf16_agreement"] = bf16_agreement(dev)
+        except Exception as exc:        # the golden files are test data: their absence must not void the bench line
+            line["bf16_agreement"] = {"error": repr(exc)}
+
+    # ---- CPU baseline: the oracle (reference "-d cpu" op sequence) timed on the host cores ----------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(wl.cfg, params, args.model, args.dim, args.cpu_budget)
+
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()          # ranks > 0 wait for rank 0's profiling passes before the group goes away
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -182,8 +182,10 @@ int y3_resize_bilinear_u8(const uint8_t *d_src, int src_h, int src_w, uint8_t *d
                           const int32_t *d_ytab, const int32_t *d_xtab, void *stream);
 
 /* padded fixed-size detection records for the multi-GPU all-gather (no reference counterpart:
- * the reference is single device).  Record = 8 x int32: x1,y1,x2,y2, score bits, class, row, valid.
- * d_records (batch, kmax, 8) int32, d_counts passthrough of min(count,kmax) in slot [b][0][7]... */
+ * the reference is single device).  Record = 8 x int32: x1,y1,x2,y2, score bits, class, row, and the
+ * frame's TRUE detection count (0 in padding records: the field doubles as the valid flag; a count
+ * above kmax means the frame was truncated to its kmax best-ordered detections).
+ * d_records (batch, kmax, 8) int32; d_rec_count (batch) int32 also receives the true counts, may be NULL. */
 int y3_pack_records(const int32_t *d_det_count, const int64_t *d_det_tlbr, const float *d_det_prob,
                     const int64_t *d_det_cls, const int32_t *d_det_row, int batch, int rows, int kmax,
                     int32_t *d_records, int32_t *d_rec_count, void *stream);

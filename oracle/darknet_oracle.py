@@ -19,6 +19,21 @@ numpy: argsort and int64/float64 array arithmetic; both unpinned in
 /root/reference/requirements.txt).  This restatement calls the same public
 torch/numpy primitives, op by op and in the reference's order, so it is the
 "-d cpu" path with the nn.Module plumbing removed.
+
+bf16 EMULATION (``OracleDarknet.forward(..., emulate_bf16=True)``): the reference
+is float32 only, so the bf16 throughput mode of the product has no reference
+counterpart.  Its checker is THIS pinned float32 restatement with bf16 storage
+rounding (round-to-nearest-even, ``torch.bfloat16``) inserted exactly where the
+bf16 plan keeps a tensor in HBM: the normalised input, every conv weight, every
+conv / shortcut output that is materialised.  Everything between two rounding
+points is the reference's float32 op sequence (conv accumulate, BatchNorm,
+LeakyReLU, the shortcut add: /root/reference/yolov3/darknet.py:244-257,376-379);
+detection-head convs stay float32 (their logits are decoded in float32).  The
+rounding points are listed in ``bf16_rounding_points``.  ``accumulate="f64"``
+sums every conv in float64 (bf16 x bf16 products are exact there): the distance
+between the f32- and f64-accumulating runs is the summation-order noise two
+correct bf16 implementations may differ by, which is what the GPU tests derive
+their tolerances from (tests/test_oracle_golden.py::test_bf16_emulation_noise_floor).
 """
 import os
 import sys
@@ -42,19 +57,37 @@ LEAKY_SLOPE = 0.1      # reference darknet.py:256
 # per-op restatements
 # --------------------------------------------------------------------------
 
-def conv_block(x, p, stride, pad, leaky):
+def bf16_round(t):
+    """float32 tensor -> nearest bfloat16 (ties to even) -> float32: the storage rounding of the bf16 mode."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _conv2d(x, w, stride, pad, accumulate):
+    if accumulate == "f64":
+        return F.conv2d(x.double(), w.double(), None, stride=stride, padding=pad).float()
+    return F.conv2d(x, w, None, stride=stride, padding=pad)
+
+
+def conv_block(x, p, stride, pad, leaky, bf16_weights=False, accumulate="f32"):
     """conv -> [BN eval] -> [LeakyReLU 0.1]  (reference darknet.py:236-264, run :367-368).
 
     x: (B,Cin,H,W) f32.  p: dict with ``weight`` and either BN tensors or
     ``bias`` (numpy).  ``activation=linear`` means identity (darknet.py:258-261).
+    ``bf16_weights``: kernel weights rounded to bf16 first (bf16 emulation; BN tensors and biases
+    stay float32).  The result is float32 and NOT rounded here.
     """
     w = torch.from_numpy(np.ascontiguousarray(p["weight"]))
+    if bf16_weights:
+        w = bf16_round(w)
     if "bn_gamma" in p:
-        y = F.conv2d(x, w, None, stride=stride, padding=pad)
+        y = _conv2d(x, w, stride, pad, accumulate)
         y = F.batch_norm(
             y, torch.from_numpy(p["bn_mean"].copy()), torch.from_numpy(p["bn_var"].copy()),
             torch.from_numpy(p["bn_gamma"].copy()), torch.from_numpy(p["bn_beta"].copy()),
             training=False, eps=BN_EPS)
+    elif accumulate == "f64":
+        y = (F.conv2d(x.double(), w.double(), torch.from_numpy(p["bias"].copy()).double(), stride=stride,
+                      padding=pad)).float()
     else:
         y = F.conv2d(x, w, torch.from_numpy(p["bias"].copy()), stride=stride, padding=pad)
     if leaky:
@@ -133,22 +166,54 @@ class OracleDarknet:
         self.params = params
         return self
 
-    def forward(self, x, collect=None):
+    def bf16_rounding_points(self):
+        """Which block outputs the bf16 mode stores in bf16 (True), keeps in float32 (False: detection-head convs,
+        whose logits go to the decode in float32, and convs whose ONLY reader is the shortcut right after them:
+        the product's conv epilogue adds the shortcut operand in float32 and stores the sum once)."""
+        n = len(self.blocks)
+        readers = [0] * n
+        for i, blk in enumerate(self.blocks):
+            if blk["type"] in ("convolutional", "maxpool", "upsample", "yolo") and i > 0:
+                readers[i - 1] += 1
+            elif blk["type"] == "route":
+                for j in blk["layers"]:
+                    readers[j] += 1
+            elif blk["type"] == "shortcut":
+                readers[i - 1] += 1
+                readers[i + blk["from"]] += 1
+        rounds = [True] * n
+        for i, blk in enumerate(self.blocks):
+            if blk["type"] != "convolutional":
+                continue
+            nxt = self.blocks[i + 1]["type"] if i + 1 < n else None
+            if nxt == "yolo":
+                rounds[i] = False
+            elif nxt == "shortcut" and readers[i] == 1 and i + 1 + self.blocks[i + 1]["from"] != i:
+                rounds[i] = False
+        return rounds
+
+    def forward(self, x, collect=None, emulate_bf16=False, accumulate="f32"):
         """x: torch (B,3,H,W) f32.  Returns dict like the reference (darknet.py:401-405).
 
         ``collect``: optional dict filled with {block_idx: tensor} of every
         block output (used by per-layer parity tests).
+        ``emulate_bf16`` / ``accumulate``: see the module docstring (checker of the bf16 mode).
         """
         outs = []
         heads = []
+        rounds = self.bf16_rounding_points() if emulate_bf16 else None
         with torch.no_grad():
+            if emulate_bf16:
+                x = bf16_round(x)
             for i, blk in enumerate(self.blocks):
                 kind = blk["type"]
                 if kind == "convolutional":
                     k = blk["size"]
                     pad = (k - 1) // 2 if "pad" in blk else 0      # darknet.py:240
                     x = conv_block(x, self.params[self._conv_slot[i]], blk["stride"], pad,
-                                   blk["activation"] == "leaky")
+                                   blk["activation"] == "leaky", bf16_weights=emulate_bf16, accumulate=accumulate)
+                    if emulate_bf16 and rounds[i]:
+                        x = bf16_round(x)
                 elif kind == "maxpool":
                     x = maxpool(x, blk["size"], blk["stride"])
                 elif kind == "upsample":
@@ -157,6 +222,8 @@ class OracleDarknet:
                     x = torch.cat([outs[j] for j in blk["layers"]], dim=1)   # darknet.py:372-375
                 elif kind == "shortcut":
                     x = outs[i - 1] + outs[i + blk["from"]]                  # darknet.py:379
+                    if emulate_bf16:
+                        x = bf16_round(x)
                 elif kind == "yolo":
                     anchors = [blk["anchors"][m] for m in blk["mask"]]       # darknet.py:44
                     heads.append(yolo_decode(x, anchors))
@@ -237,11 +304,17 @@ def non_max_suppression(tlbr, class_prob, class_idx=None, iou_thresh=0.3):
 
 
 def postprocess(bbox_xywh, class_prob, class_idx, orig_shapes, prob_thresh=0.05,
-                nms_iou_thresh=0.3):
+                nms_iou_thresh=0.3, audit=False):
     """Tail of reference ``inference()`` (inference.py:338-366) on numpy arrays.
 
     orig_shapes: per-frame (H, W[, C]).  Returns per frame
     [tlbr int64 (K,4), prob f32 (K,), cls int64 (K,)].
+
+    ``audit=True`` appends, per frame, the prediction row of every kept detection, the rows of all
+    candidates (score >= threshold) and which candidates are FRAGILE: a scaled coordinate within 2e-3 px
+    of an integer or a score within 1e-5 of the threshold, i.e. where a float difference of a few ulp
+    between two correct implementations legitimately flips ``astype(int)`` / the threshold test (same
+    audit as tools/make_goldens.py stores with the G7 goldens).
     """
     results = []
     mask = class_prob >= prob_thresh
@@ -254,8 +327,40 @@ def postprocess(bbox_xywh, class_prob, class_idx, orig_shapes, prob_thresh=0.05,
         with np.errstate(invalid="ignore"):
             tlbr = cxywh_to_tlbr(box.astype(np.int64))
         keep = non_max_suppression(tlbr, prob, class_idx=cls, iou_thresh=nms_iou_thresh)
-        results.append([tlbr[keep, :], prob[keep], cls[keep]])
+        item = [tlbr[keep, :], prob[keep], cls[keep]]
+        if audit:
+            cand = np.where(mask[i])[0]
+            with np.errstate(invalid="ignore"):
+                dist = np.abs(box - np.rint(box)).min(axis=1) if len(cand) else np.zeros(0)
+            fragile = (dist < 2e-3) | (np.abs(prob - np.float32(prob_thresh)) < 1e-5)
+            item += [cand[keep].astype(np.int64), cand.astype(np.int64), fragile]
+        results.append(item)
     return results
+
+
+def compare_detections(got, want):
+    """One frame of the product's detections, ``got`` = [tlbr, prob, cls, rows], against an audited oracle
+    frame (``postprocess(..., audit=True)``): the kept prediction rows must be the same set, classes equal,
+    boxes equal, except at FRAGILE candidates (see ``postprocess``), where the truncated pixel may differ by
+    one.  Returns (rows that differ in the keep set, fragile boxes that differ); raises AssertionError on
+    any difference outside the fragile rows."""
+    tlbr, prob, cls, rows = got[0], got[1], got[2], got[3]
+    w_tlbr, w_prob, w_cls, w_rows, w_cand, w_frag = want
+    fragile_rows = set(w_cand[w_frag].tolist())
+    g = {int(r): k for k, r in enumerate(rows)}
+    w = {int(r): k for k, r in enumerate(w_rows)}
+    assert len(g) == len(rows), "duplicate rows in detections"
+    diff = set(g) ^ set(w)
+    assert diff <= fragile_rows, "keep sets differ at non-fragile rows %s" % sorted(diff - fragile_rows)[:8]
+    bad = 0
+    for r in set(g) & set(w):
+        a, b = g[r], w[r]
+        assert cls[a] == w_cls[b], "class differs at row %d" % r
+        if not (tlbr[a] == w_tlbr[b]).all():
+            assert r in fragile_rows and np.abs(tlbr[a] - w_tlbr[b]).max() <= 1, \
+                "box differs at non-fragile row %d: %s vs %s" % (r, tlbr[a], w_tlbr[b])
+            bad += 1
+    return len(diff), bad
 
 
 def inference(net, frames, prob_thresh=0.05, nms_iou_thresh=0.3):

@@ -471,8 +471,9 @@ __global__ void pack_records_kernel(const int *cnt, const long long *tlbr, const
                                     const long long *cls, const int *row, int rows, int kmax,
                                     int *rec, int *rec_count) {
   const int b = blockIdx.x;
-  const int n = cnt[b] < kmax ? cnt[b] : kmax;
-  if (threadIdx.x == 0) rec_count[b] = cnt[b];
+  const int total = cnt[b];
+  const int n = total < kmax ? total : kmax;
+  if (threadIdx.x == 0 && rec_count) rec_count[b] = total;
   for (int k = threadIdx.x; k < kmax; k += blockDim.x) {
     int *o = rec + ((long long)b * kmax + k) * 8;
     if (k < n) {
@@ -481,7 +482,7 @@ __global__ void pack_records_kernel(const int *cnt, const long long *tlbr, const
       o[4] = __float_as_int(prob[(long long)b * rows + k]);
       o[5] = (int)cls[(long long)b * rows + k];
       o[6] = row[(long long)b * rows + k];
-      o[7] = 1;
+      o[7] = total;   // the frame's true count rides in every valid record (0 = padding): one collective carries both
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = 0;
@@ -601,7 +602,7 @@ extern "C" int y3_pack_records(const int32_t *d_det_count, const int64_t *d_det_
                                const int64_t *d_det_cls, const int32_t *d_det_row, int batch, int rows, int kmax,
                                int32_t *d_records, int32_t *d_rec_count, void *stream) {
   Y3_REQUIRE(batch > 0 && rows > 0 && kmax > 0, "y3_pack_records: sizes must be positive");
-  Y3_REQUIRE(d_det_count && d_det_tlbr && d_det_prob && d_det_cls && d_det_row && d_records && d_rec_count,
+  Y3_REQUIRE(d_det_count && d_det_tlbr && d_det_prob && d_det_cls && d_det_row && d_records,
              "y3_pack_records: null pointer argument");
   hipLaunchKernelGGL(pack_records_kernel, dim3(batch), dim3(256), 0, static_cast<hipStream_t>(stream), d_det_count,
                      reinterpret_cast<const long long *>(d_det_tlbr), d_det_prob,

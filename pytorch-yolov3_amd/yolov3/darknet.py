@@ -71,7 +71,7 @@ class _CompiledPlan(object):
 
 
 class Darknet(object):
-    def __init__(self, config_fpath, device="cuda", dtype="float32", keep_all=False):
+    def __init__(self, config_fpath, device="cuda", dtype="float32", keep_all=False, fuse=None):
         """
         Args:
             config_fpath (str): Darknet .cfg file.
@@ -85,6 +85,9 @@ class Darknet(object):
             raise ValueError("cfg {!r} has no [net] section".format(config_fpath))
         self.config_fpath = config_fpath
         self.keep_all = bool(keep_all)   # debugging: no arena reuse, so block_output() works
+        # conv-pair fusion (stem + stride-2 conv, residual blocks): default on, off with keep_all unless asked for
+        # (then the tensor between a fused pair is never written and block_output() of it is meaningless)
+        self.fuse = (not self.keep_all) if fuse is None else bool(fuse)
         self.device = device
         self.header = None
         self.training = False
@@ -119,14 +122,24 @@ class Darknet(object):
             raise NotImplementedError("inference-only implementation (BatchNorm uses running statistics)")
         return self.eval()
 
+    def _move(self, device):
+        """Device weights and compiled plans hold addresses on the old device: drop them when the device changes
+        (they are rebuilt lazily by the next forward)."""
+        if str(device) != str(self.device):
+            self._dev_weights = {}
+            for plan in self._plans.values():
+                plan.destroy()
+            self._plans = {}
+            self._zero = None
+        self.device = device
+        return self
+
     def cuda(self, device=None):
         if device is None:
-            self.device = "cuda"
-        elif isinstance(device, int):
-            self.device = "cuda:%d" % device
-        else:
-            self.device = str(device)
-        return self
+            return self._move("cuda")
+        if isinstance(device, int):
+            return self._move("cuda:%d" % device)
+        return self._move(str(device))
 
     def to(self, device):
         return self.cuda(device) if str(device).startswith("cuda") else self._set_cpu()
@@ -135,8 +148,7 @@ class Darknet(object):
         return self._set_cpu()
 
     def _set_cpu(self):
-        self.device = "cpu"
-        return self
+        return self._move("cpu")
 
     def __call__(self, x):
         return self.forward(x)
@@ -173,7 +185,7 @@ class Darknet(object):
         return scale, bias
 
     def _device_weights(self, slot, path, elem_bf16, dev):
-        key = (slot, path, elem_bf16)
+        key = (slot, path, elem_bf16, str(dev))
         if key in self._dev_weights:
             return self._dev_weights[key]
         c = self._convs[slot]
@@ -230,7 +242,7 @@ class Darknet(object):
         lib = _hip.lib()
         bf16 = self.dtype == "bf16"
         es = 2 if bf16 else 4
-        desc = build_plan(self.blocks, self.net_info, batch, height, width, es, reuse=not self.keep_all)
+        desc = build_plan(self.blocks, self.net_info, batch, height, width, es, reuse=not self.keep_all, fuse=self.fuse)
         cp = _CompiledPlan()
         cp.batch = batch
         cp.rows_total = desc["rows_total"]

@@ -5,8 +5,11 @@ on GPUs, gloo in the CPU tests) of fixed-size padded detection records.
 The reference is single-device; frames are independent (BN uses running
 statistics, NMS is per frame: /root/reference/yolov3/inference.py:346), so the only exchange
 is the result gather.  Record = 8 x int32: x1, y1, x2, y2, float32 score bits, class,
-prediction row, valid flag; ``kmax`` records per frame (payload = frames * kmax * 32 B per
-rank: latency-bound, KBs), plus the true per-frame count so truncation is detectable.
+prediction row, and the frame's TRUE detection count (0 in padding records, so it doubles as
+the valid flag, and a count above ``kmax`` says the frame was truncated); ``kmax`` records
+per frame (payload = frames * kmax * 32 B per rank: latency-bound, KBs).  The count rides in
+the records, so a batch costs exactly one ``all_gather_into_tensor``; on GPUs it is issued on
+a side stream behind an event, so the compute stream goes straight on to the next batch.
 """
 import numpy as np
 import torch
@@ -24,17 +27,20 @@ def shard_range(n_frames, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_records(records, counts, world, group=None):
-    """records (b, kmax, 8) int32 and counts (b,) int32 of THIS rank -> the same for all ranks,
-    concatenated in rank order: (world*b, kmax, 8), (world*b,).  Every rank must pass equal b."""
+def counts_of(records):
+    """Per-frame true detection counts carried in field 7 of each frame's first record."""
+    return records[:, 0, 7]
+
+
+def all_gather_records(records, world, group=None):
+    """records (b, kmax, 8) int32 of THIS rank -> the records of all ranks concatenated in rank order,
+    (world*b, kmax, 8), with ONE collective.  Every rank must pass equal b."""
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
-        return records, counts          # plain single-process use: nothing to gather
-    out_r = torch.empty((world * records.shape[0],) + tuple(records.shape[1:]), dtype=records.dtype,
-                        device=records.device)
-    out_c = torch.empty((world * counts.shape[0],), dtype=counts.dtype, device=counts.device)
-    dist.all_gather_into_tensor(out_r, records.contiguous(), group=group)
-    dist.all_gather_into_tensor(out_c, counts.contiguous(), group=group)
-    return out_r, out_c
+        return records                  # plain single-process use: nothing to gather
+    out = torch.empty((world * records.shape[0],) + tuple(records.shape[1:]), dtype=records.dtype,
+                      device=records.device)
+    dist.all_gather_into_tensor(out, records.contiguous(), group=group)
+    return out
 
 
 def pack_records_host(dets, kmax):
@@ -43,23 +49,21 @@ def pack_records_host(dets, kmax):
     dets: list of [tlbr (K,4), prob (K,), cls (K,), rows (K,)]."""
     b = len(dets)
     rec = np.zeros((b, kmax, RECORD_INTS), dtype=np.int32)
-    cnt = np.zeros(b, dtype=np.int32)
     for i, d in enumerate(dets):
         k = min(len(d[1]), kmax)
-        cnt[i] = len(d[1])
         rec[i, :k, 0:4] = d[0][:k]
         rec[i, :k, 4] = np.asarray(d[1][:k], dtype=np.float32).view(np.int32)
         rec[i, :k, 5] = d[2][:k]
         rec[i, :k, 6] = d[3][:k] if len(d) > 3 else 0
-        rec[i, :k, 7] = 1
-    return rec, cnt
+        rec[i, :k, 7] = len(d[1])
+    return rec
 
 
-def unpack_records(records, counts):
+def unpack_records(records):
     """Inverse of the packers: -> per frame [tlbr int64 (K,4), prob f32 (K,), cls int64 (K,),
     rows int64 (K,), truncated bool]."""
     rec = records.cpu().numpy() if isinstance(records, torch.Tensor) else np.asarray(records)
-    cnt = counts.cpu().numpy() if isinstance(counts, torch.Tensor) else np.asarray(counts)
+    cnt = rec[:, 0, 7]
     out = []
     for i in range(rec.shape[0]):
         k = int(min(cnt[i], rec.shape[1]))
@@ -70,17 +74,43 @@ def unpack_records(records, counts):
 
 
 class DetectionGather(object):
-    """Device buffers + the per-batch gather of one rank."""
+    """Device buffers + the per-batch gather of one rank.
+
+    ``run`` packs on the CURRENT (compute) stream, then issues the all-gather on this object's side stream
+    behind an event, and returns the gathered tensor; ``done`` is recorded on the side stream when the
+    gather has finished: consumers on other streams ``wait_event(done)`` (or synchronise the device) before
+    reading it.  Re-running the same object first waits for its previous gather, so the record buffer is
+    never overwritten while RCCL still reads it."""
 
     def __init__(self, batch, rows, kmax, device, world, group=None):
         self.batch, self.rows, self.kmax, self.world, self.group = batch, rows, kmax, world, group
         self.records = torch.zeros((batch, kmax, RECORD_INTS), dtype=torch.int32, device=device)
-        self.counts = torch.zeros(batch, dtype=torch.int32, device=device)
+        self.gathered = self.records
+        self.collective = world > 1 or (dist.is_available() and dist.is_initialized())
+        self.side = self.packed = self.done = None
+        if self.collective and torch.device(device).type == "cuda":
+            self.gathered = torch.empty((world * batch, kmax, RECORD_INTS), dtype=torch.int32, device=device)
+            self.side = torch.cuda.Stream(device=device)
+            self.packed = torch.cuda.Event()
+            self.done = torch.cuda.Event()
+            self.done.record(self.side)
 
     def run(self, det):
-        """det: yolov3.inference.Detector after ``run``.  Returns (records, counts) of all ranks."""
+        """det: yolov3.inference.Detector after ``run``.  Returns the records of all ranks, (world*batch, kmax, 8)."""
         from . import _hip
+        cur = torch.cuda.current_stream()
+        if self.side is not None:
+            cur.wait_event(self.done)           # the previous gather of this buffer has been read by RCCL
         _hip.check(_hip.lib().y3_pack_records(
             det.count.data_ptr(), det.tlbr.data_ptr(), det.prob.data_ptr(), det.cls.data_ptr(), det.row.data_ptr(),
-            self.batch, self.rows, self.kmax, self.records.data_ptr(), self.counts.data_ptr(), _hip.stream_ptr()))
-        return all_gather_records(self.records, self.counts, self.world, self.group)
+            self.batch, self.rows, self.kmax, self.records.data_ptr(), None, _hip.stream_ptr()))
+        if not self.collective:
+            return self.records
+        if self.side is None:
+            return all_gather_records(self.records, self.world, self.group)
+        self.packed.record(cur)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.packed)
+            dist.all_gather_into_tensor(self.gathered, self.records, group=self.group)
+            self.done.record(self.side)
+        return self.gathered

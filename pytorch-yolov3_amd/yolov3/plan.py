@@ -78,12 +78,17 @@ def infer_shapes(blocks, net_info, height, width):
     return shapes
 
 
-def build_plan(blocks, net_info, batch, height, width, elem_size, reuse=True):
+def build_plan(blocks, net_info, batch, height, width, elem_size, reuse=True, fuse=None):
     """Resolve the graph.  ``blocks`` must already carry absolute route indices.
 
     Returns dict(ops=[...], buffers={id: nbytes}, offsets={id: arena offset}, arena_bytes,
     rows_total, shapes).  Each op is a dict; tensors are :class:`Tensor`.
+    ``fuse`` (default: same as ``reuse``): mark conv pairs the executor may run as one kernel; with
+    ``reuse=False, fuse=True`` (per-block parity tests) the intermediate tensor of a fused pair keeps
+    its arena slot but is never written.
     """
+    if fuse is None:
+        fuse = reuse
     n = len(blocks)
     shapes = infer_shapes(blocks, net_info, height, width)
     kinds = [b["type"] for b in blocks]
@@ -190,7 +195,7 @@ def build_plan(blocks, net_info, batch, height, width, elem_size, reuse=True):
                             # output, so the pair may run as one kernel that never writes this tensor (stem + stride-2
                             # conv, 1x1 + 3x3 of a residual block); needs arena reuse semantics, i.e. not the
                             # keep-every-tensor debugging mode.  Whether a fused kernel exists is the executor's call.
-                            fuse_next=bool(reuse and i not in conv_fused and i + 1 < n and
+                            fuse_next=bool(fuse and i not in conv_fused and i + 1 < n and
                                            kinds[i + 1] == "convolutional" and readers[i] == [(i + 1, "in")])))
             conv_slot += 1
             if i in conv_fused:

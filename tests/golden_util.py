@@ -61,7 +61,6 @@ def compare_detections(g, prefix, det, rows=None, prob_tol=1e-5):
     tlbr, prob, cls = det[0], det[1], det[2]
     g_tlbr, g_prob, g_cls, g_rows = g[prefix + "tlbr"], g[prefix + "prob"], g[prefix + "cls"], g[prefix + "rows"]
     fragile_rows = set(g[prefix + "cand_rows"][g[prefix + "cand_fragile"]].tolist())
-    budget = 3 * len(fragile_rows)
     assert tlbr.dtype == np.int64 and cls.dtype == np.int64 and prob.dtype == np.float32
     assert tlbr.shape == (len(prob), 4) and cls.shape == prob.shape
     if rows is not None:
@@ -69,7 +68,10 @@ def compare_detections(g, prefix, det, rows=None, prob_tol=1e-5):
         want = {int(r): k for k, r in enumerate(g_rows)}
         assert len(got) == len(rows), "duplicate rows in detections"
         diff = set(got) ^ set(want)
-        assert len(diff) <= budget, "keep sets differ by %d rows (budget %d)" % (len(diff), budget)
+        # identical indices after NMS (BASELINE.json north_star): the only rows allowed to differ are the fragile
+        # candidates themselves (measured on MI355X: none differ, profiles/r01_gpu_tests_v1.log)
+        assert diff <= fragile_rows, "keep sets differ at %d non-fragile rows, e.g. %s" % (
+            len(diff - fragile_rows), sorted(diff - fragile_rows)[:8])
         bad = 0
         for r in set(got) & set(want):
             a, b = got[r], want[r]
@@ -83,5 +85,13 @@ def compare_detections(g, prefix, det, rows=None, prob_tol=1e-5):
     got = Counter((int(c),) + tuple(int(v) for v in t) for c, t in zip(cls, tlbr))
     want = Counter((int(c),) + tuple(int(v) for v in t) for c, t in zip(g_cls, g_tlbr))
     diff = sum(((got - want) + (want - got)).values())
-    assert diff <= 2 * budget, "detections differ in %d rows (budget %d)" % (diff, 2 * budget)
+    assert diff <= 2 * len(fragile_rows), "detections differ in %d rows (%d fragile candidates)" % (diff, len(fragile_rows))
     return diff, 0
+
+
+def bf16_agreement():
+    """tests/golden/bf16_agreement.json (tools/make_bf16_fixture.py): what the bf16-emulating oracle reaches against
+    the reference's float32 detections on the G7 frames -- the floor for the HIP bf16 path."""
+    import json
+    with open(os.path.join(GOLDEN, "bf16_agreement.json")) as fh:
+        return json.load(fh)

@@ -150,8 +150,8 @@ def test_bench_prints_one_contract_json_line():
     import sys
     from golden_util import ROOT
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "yolov3-tiny", "--dim", "416",
-                           "--batch", "2", "--steps", "3", "--warmup", "1", "--cpu-frames", "1"],
-                          capture_output=True, text=True, timeout=600)
+                           "--batch", "2", "--steps", "3", "--warmup", "1", "--cpu-budget", "4"],
+                          capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -167,6 +167,16 @@ def test_bench_prints_one_contract_json_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert c["cpu_model"] and c["batch1"]["fps"] > 0 and c["batch16"]["fps"] > 0
+    # measured in the same run: PCIe-inclusive rate, the other BASELINE configurations, bf16 detection agreement
+    assert d["pcie_inclusive"]["value"] > 0
+    assert {o["workload"] for o in d["other_configs"]} == {"yolov3-tiny 416x416 batch=8 float32", "yolov3-spp 608x608 batch=16 bf16",
+                                                           "yolov3 608x608 batch=16 float32"}
+    for o in d["other_configs"]:
+        assert o["value"] > 0 and abs(o["roofline"]["frac"] - o["roofline"]["achieved"] / o["roofline"]["peak"]) < 1e-3
+    agree = d["bf16_agreement"]["thr_0.05_iou_0.3"]
+    assert len(agree["keep_set_jaccard"]) == 3 and min(agree["keep_set_jaccard"]) > 0.4
+    assert agree["score_abs_diff"]["median"] < 0.01
 
 
 @pytest.mark.gpu
@@ -201,4 +211,22 @@ def test_bench_under_torchrun_runs_the_rccl_plumbing():
     lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["collective"].startswith("all_gather")
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "all_gather_into_tensor" in d["config"]["collective"]
+    assert d["config"]["collective"].startswith("1 x ") and d["config"]["ranks_seen_by_collective"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_gpus_than_visible_on_the_gpu_box():
+    """`python bench.py --gpus N` (no torchrun) with fewer than N GPUs: non-zero exit and a clear message, never a
+    silent one-rank run."""
+    import subprocess
+    import sys
+    import torch
+    from golden_util import ROOT
+    want = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "1", "--warmup", "0"],
+                          capture_output=True, text=True, timeout=300, env=env)
+    assert proc.returncode != 0
+    assert "%d GPUs requested, %d visible" % (want, want - 1) in proc.stderr
+    assert not [l for l in proc.stdout.splitlines() if l.startswith("{")]

@@ -1,14 +1,21 @@
-"""world_size-2 CPU test (gloo) of the multi-GPU plumbing: contiguous frame sharding and the
-single all-gather of padded detection records (RCCL on the GPUs, gloo here)."""
+"""CPU tests (gloo, world sizes 2 and 8) of the multi-GPU plumbing: contiguous frame sharding, the single
+all-gather of padded detection records per batch (RCCL on the GPUs, gloo here) and bench.py's own launcher
+(`python bench.py --gpus N` starts its N ranks itself)."""
+import json
+import subprocess
+import sys
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from yolov3.dist import all_gather_records, pack_records_host, shard_range, unpack_records
+from yolov3.dist import all_gather_records, counts_of, pack_records_host, shard_range, unpack_records
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 def _fake_dets(frame_id):
@@ -26,9 +33,10 @@ def _worker(rank, world, port, n_frames, kmax, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_range(n_frames, rank, world)
     dets = [_fake_dets(f) for f in range(lo, hi)]
-    rec, cnt = pack_records_host(dets, kmax)
-    all_rec, all_cnt = all_gather_records(torch.from_numpy(rec), torch.from_numpy(cnt), world)
-    out = unpack_records(all_rec, all_cnt)
+    rec = pack_records_host(dets, kmax)
+    all_rec = all_gather_records(torch.from_numpy(rec), world)          # ONE collective per batch
+    assert counts_of(all_rec).shape == (n_frames,)
+    out = unpack_records(all_rec)
     q.put((rank, [(d[0].tolist(), d[1].tolist(), d[2].tolist(), d[3].tolist(), d[4]) for d in out]))
     dist.barrier()
     dist.destroy_process_group()
@@ -53,16 +61,19 @@ def test_shard_range_partitions_exactly():
 
 def test_pack_unpack_roundtrip_and_truncation():
     dets = [_fake_dets(f) for f in range(5)]
-    rec, cnt = pack_records_host(dets, 4)
-    back = unpack_records(rec, cnt)
+    rec = pack_records_host(dets, 4)
+    assert counts_of(rec).tolist() == [len(d[1]) for d in dets]      # the true count rides in the records
+    back = unpack_records(rec)
     for d, b in zip(dets, back):
         k = min(len(d[1]), 4)
         assert (b[0] == d[0][:k]).all() and (b[1] == d[1][:k]).all() and (b[2] == d[2][:k]).all()
         assert b[4] == (len(d[1]) > 4)
 
 
-def test_all_gather_two_ranks_gloo():
-    world, n_frames, kmax = 2, 8, 16
+@pytest.mark.parametrize("world,n_frames", [(2, 8), (8, 128)])
+def test_all_gather_gloo(world, n_frames):
+    """(8, 128) is BASELINE.json configs[4]: 128 frames over 8 ranks, 16 each."""
+    kmax = 16
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -80,3 +91,43 @@ def test_all_gather_two_ranks_gloo():
             tl, pr, cl, rw, trunc = got[rank][f]
             assert tl == want[f][0].tolist() and cl == want[f][2].tolist() and rw == want[f][3].tolist()
             assert np.allclose(pr, want[f][1]) and not trunc
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, timeout=timeout,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` with fewer than N GPUs visible must fail loudly, never run fewer ranks."""
+    n_visible = torch.cuda.device_count()
+    want = n_visible + 2
+    r = _run_bench(["--gpus", str(want), "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert "%d GPUs requested, %d visible" % (want, n_visible) in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_self_launch_starts_n_ranks(world):
+    """The driver runs `python bench.py --gpus N ...` without torchrun: the parent process must start N ranks itself
+    (torch.distributed.run), relay rank 0's one JSON line and propagate failures.  Exercised here with the
+    plumbing-only mode (Y3_BENCH_PLUMBING=gloo: no GPU work, the same shard / gather / timing skeleton over gloo)."""
+    r = _run_bench(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "16", "--no-cpu-baseline"],
+                   {"Y3_BENCH_PLUMBING": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["config"]["global_batch"] == 16 * world
+    assert line["plumbing_only"] is True and line["ranks_seen_by_collective"] == world
+    assert line["frames_gathered_per_step"] == 16 * world
+
+
+def test_bench_self_launch_propagates_rank_failure():
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"Y3_BENCH_PLUMBING": "gloo", "Y3_BENCH_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

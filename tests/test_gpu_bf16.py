@@ -1,0 +1,280 @@
+"""bf16 parity gates (-m gpu): the benchmarked dtype against the bf16-emulating oracle.
+
+Three levels, from tight to loose:
+
+1. ``test_bf16_every_block_teacher_forced``: every block of a network, each fed with the PRODUCT's own input
+   tensor for that block, against the oracle's bf16 emulation of that one block (``oracle/darknet_oracle.py``:
+   bf16 weights and inputs, float32 accumulate / BatchNorm / LeakyReLU / shortcut add, one rounding where the
+   tensor is stored).  With identical inputs the only legitimate difference is float32 summation order, i.e. at
+   most ONE bf16 ulp on the few values that sit on a rounding boundary -- a wrong border column, tap, K tile or
+   channel slice is O(1).  Covers every conv kernel family the plans select (MFMA stem, fused first two convs,
+   fused residual block, halo / patch / implicit-GEMM kernels, fused head conv + decode), pools, upsample, routes.
+2. ``test_bf16_whole_net_vs_bf16_oracle``: end-to-end outputs against the emulating oracle, with tolerances
+   derived in the test from the summation-order noise floor (oracle accumulating in float32 vs float64: through
+   75 layers of procedural weights one-ulp flips amplify, so two CORRECT bf16 implementations differ by this much).
+3. ``test_bf16_post_nms_agreement_vs_reference``: detections of the bf16 path against the reference's own
+   ``inference()`` lists (G7): keep-set Jaccard and score differences, asserted against the floor an ideal bf16
+   implementation reaches (tests/golden/bf16_agreement.json, tools/make_bf16_fixture.py).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import yolov3
+from oracle import darknet_oracle as orc
+from yolov3.preprocess import resize_bilinear_u8
+from yolov3.synthdata import synth_frames
+
+from golden_util import (GOLDEN, MODELS, MODEL_DIMS, bf16_agreement, golden_params, golden_weights_path, load_jpeg_bgr)
+
+pytestmark = pytest.mark.gpu
+
+BF16_ULP_REL = 2.0 ** -7        # spacing of bf16 values relative to their magnitude is in (2^-8, 2^-7]
+MISMATCH_MAX = 0.02             # share of values allowed to land on the other side of a rounding boundary
+
+
+def _net(model, **kw):
+    net = yolov3.Darknet(MODELS[model], device="cuda", dtype="bf16", **kw)
+    if model == "mini":
+        net.set_params(golden_params("mini"))
+    else:
+        net.load_weights(golden_weights_path(model))
+    return net.eval()
+
+
+def _bf16_ulp(r):
+    """Spacing of bf16 values at the (bf16-valued) tensor r: 2^(exponent - 7)."""
+    _, e = torch.frexp(r)                      # r = m * 2^e, m in [0.5, 1)
+    return torch.where(r == 0, torch.zeros_like(r), torch.ldexp(torch.ones_like(r), e - 8))
+
+
+def _flip_slack(mid, w2, alpha2, stride, pad):
+    """A fused conv pair keeps its intermediate tensor on chip, rounded to bf16: where the oracle's unrounded value
+    ``mid`` sits on a bf16 rounding boundary (within float32 summation noise), the kernel may legitimately hold the
+    neighbouring bf16 value.  Returns, per OUTPUT element of the second conv, how far such flips in its receptive
+    field can move it: sum over taps of |w2| * |BN scale| * ulp(mid) over the boundary candidates (LeakyReLU's
+    slope is <= 1).  Zero for outputs that see no candidate."""
+    r = orc.bf16_round(mid)
+    ulp = _bf16_ulp(r)
+    rms = float(mid.pow(2).mean().sqrt())
+    dist = 0.5 * ulp - (mid - r).abs()         # distance of mid to the nearer rounding boundary
+    cand = (dist <= 1e-5 * (mid.abs() + rms)).float()
+    moved = torch.nn.functional.conv2d(cand * 2.0 * ulp, w2.abs(), None, stride=stride, padding=pad)
+    return moved * alpha2.abs().reshape(1, -1, 1, 1)
+
+
+def _close_bf16(got, want, what, slack=None):
+    """``got``/``want``: float32 tensors holding bf16 values.  One bf16 ulp + a floor for values near zero
+    (+ ``slack``, see ``_flip_slack``)."""
+    got, want = got.float(), want.float()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    rms = float(want.pow(2).mean().sqrt())
+    d = (got - want).abs()
+    tol = BF16_ULP_REL * want.abs() + 1e-4 * rms + 1e-30
+    if slack is not None:
+        tol = tol + slack
+        d = torch.where(slack > 0, torch.minimum(d, tol), d)      # counted as explained below, still bounded above
+    worst = float((d / tol).max())
+    frac = float(((d > 0) & ((slack == 0) if slack is not None else True)).float().mean())
+    assert worst <= 1.0, "%s: |d| up to %.2f x (one bf16 ulp), max |d| %.3g, rms %.3g" % (what, worst, float(d.max()), rms)
+    assert frac <= MISMATCH_MAX, "%s: %.2f %% of the values differ (summation order explains < %.0f %%)" % (
+        what, 100 * frac, 100 * MISMATCH_MAX)
+    return frac
+
+
+def _teacher_forced(model, frames, expect_kernels=()):
+    net = _net(model, keep_all=True, fuse=True)
+    out = net.forward_frames(frames)
+    torch.cuda.synchronize()
+    report = net.plan_report()
+    kernel_of = {}
+    for r in report:
+        kernel_of.setdefault(r["block"], []).append(r["kernel"])
+    names = [r["kernel"] for r in report]
+    for frag in expect_kernels:
+        assert any(frag in k for k in names), "no %s kernel in the plan: %s" % (frag, sorted(set(names)))
+
+    ref = orc.OracleDarknet(MODELS[model]).set_params(net._params)
+    blocks = ref.blocks
+    rounds = ref.bf16_rounding_points()
+    x_net = orc.bf16_round(torch.from_numpy(orc.frames_to_input(list(frames))))
+
+    def hip(i):
+        return x_net if i < 0 else net.block_output(i).cpu()
+
+    def conv(i, x):
+        blk = blocks[i]
+        k = blk["size"]
+        pad = (k - 1) // 2 if "pad" in blk else 0
+        return orc.conv_block(x, ref.params[ref._conv_slot[i]], blk["stride"], pad, blk["activation"] == "leaky",
+                              bf16_weights=True)
+
+    def fused_away(i):
+        return kernel_of.get(i, [""])[0].startswith("(fused")
+
+    checked, worst_frac = 0, 0.0
+    heads = []
+    for i, blk in enumerate(blocks):
+        kind = blk["type"]
+        what = "%s block %d (%s, %s)" % (model, i, kind, ",".join(kernel_of.get(i, ["-"])))
+        if kind == "convolutional":
+            if i + 1 < len(blocks) and fused_away(i + 1) and blocks[i + 1]["type"] == "convolutional":
+                continue                                   # first half of a fused pair: checked with its second half
+            slack = None
+            if fused_away(i) and blocks[i - 1]["type"] == "convolutional":
+                mid = conv(i - 1, hip(i - 2))              # the pair's intermediate tensor lives in LDS as bf16
+                x = orc.bf16_round(mid)
+                p2 = ref.params[ref._conv_slot[i]]
+                alpha2 = torch.from_numpy(p2["bn_gamma"] / np.sqrt(p2["bn_var"] + orc.BN_EPS))
+                k = blk["size"]
+                slack = _flip_slack(mid, orc.bf16_round(torch.from_numpy(p2["weight"])), alpha2, blk["stride"],
+                                    (k - 1) // 2 if "pad" in blk else 0)
+            else:
+                x = hip(i - 1)
+            y = conv(i, x)
+            nxt = blocks[i + 1]["type"] if i + 1 < len(blocks) else None
+            if nxt == "yolo":
+                heads.append((i + 1, y))                   # float32 logits: checked through the decode below
+                continue
+            if not rounds[i]:                              # conv + shortcut in one epilogue, one rounding of the sum
+                sc = i + 1
+                y = y + hip(sc + blocks[sc]["from"])
+                worst_frac = max(worst_frac, _close_bf16(hip(sc), orc.bf16_round(y), what + " + shortcut", slack))
+            else:
+                worst_frac = max(worst_frac, _close_bf16(hip(i), orc.bf16_round(y), what, slack))
+            checked += 1
+        elif kind == "shortcut":
+            if not rounds[i - 1]:
+                continue                                   # checked with its conv
+            want = orc.bf16_round(hip(i - 1) + hip(i + blk["from"]))
+            _close_bf16(hip(i), want, what)
+            checked += 1
+        elif kind == "maxpool":
+            assert torch.equal(hip(i), orc.maxpool(hip(i - 1), blk["size"], blk["stride"])), what
+            checked += 1
+        elif kind == "upsample":
+            assert torch.equal(hip(i), orc.upsample(hip(i - 1), blk["stride"])), what
+            checked += 1
+        elif kind == "route":
+            assert torch.equal(hip(i), torch.cat([hip(j) for j in blk["layers"]], dim=1)), what
+            checked += 1
+    # detection heads: decode of the oracle's float32 logits (from the product's head-conv input) against the
+    # rows this head wrote into the final outputs
+    bb = out["bbox_xywh"].cpu()
+    pr = out["class_prob"].cpu()
+    ci = out["class_idx"].cpu()
+    row = 0
+    for yi, logits in heads:
+        blk = blocks[yi]
+        mask = blk["mask"] if isinstance(blk["mask"], list) else [blk["mask"]]
+        box, prob, idx = orc.yolo_decode(logits, [blk["anchors"][m] for m in mask])
+        box[:, :, 2] /= ref.net_info["width"]
+        box[:, :, 3] /= ref.net_info["height"]
+        n = prob.shape[1]
+        what = "%s head at block %d (%s)" % (model, yi, ",".join(kernel_of.get(yi - 1, ["-"])))
+        torch.testing.assert_close(bb[:, row:row + n], box, rtol=2e-4, atol=2e-5, msg=lambda m: what + " boxes: " + m)
+        torch.testing.assert_close(pr[:, row:row + n], prob, rtol=5e-4, atol=2e-5, msg=lambda m: what + " scores: " + m)
+        top2 = torch.softmax(logits.reshape(logits.shape[0], len(mask), -1, logits.shape[2], logits.shape[3])[:, :, 5:], dim=2)
+        top2 = torch.topk(top2, 2, dim=2).values
+        margin = (top2[:, :, 0] - top2[:, :, 1]).reshape(logits.shape[0], -1)
+        flips = (ci[:, row:row + n] != idx) & (margin > 1e-3)
+        assert int(flips.sum()) == 0, what + ": arg-max flips on clear margins"
+        row += n
+        checked += 1
+    assert row == pr.shape[1]
+    return checked, worst_frac, names
+
+
+def test_bf16_every_block_teacher_forced_mini():
+    g = np.load(os.path.join(GOLDEN, "mini_blocks.npz"))
+    checked, frac, names = _teacher_forced("mini", g["frames"])
+    print("mini: %d blocks checked, worst mismatch share %.4f; kernels %s" % (checked, frac, sorted(set(names))))
+    assert checked >= 20
+
+
+@pytest.mark.parametrize("model,h,w,batch,kernels", [
+    ("yolov3-tiny", 416, 416, 2, ("conv_stem_mfma", "conv_igemm", "head_decode", "maxpool")),
+    ("yolov3", 608, 608, 1, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_halo_ws", "conv_patch", "conv_igemm2",
+                             "conv_igemm3", "head_decode")),
+    ("yolov3", 352, 480, 2, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_halo_ws", "head_decode")),
+    ("yolov3", 320, 320, 3, ("conv_halo_ws", "head_decode")),
+    ("yolov3-spp", 608, 608, 1, ("conv_halo_ws", "maxpool", "head_decode")),
+    ("yolov3-spp", 416, 416, 2, ("conv_halo_ws", "maxpool", "head_decode")),
+])
+def test_bf16_every_block_teacher_forced(model, h, w, batch, kernels):
+    frames = synth_frames(1000 + h + w + batch, batch, h, w)
+    if (h, w) == (608, 608):
+        frames[0] = resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), h, w)
+    checked, frac, names = _teacher_forced(model, frames, kernels)
+    print("%s %dx%d b%d: %d blocks checked, worst mismatch share %.4f" % (model, h, w, batch, checked, frac))
+    assert checked >= (20 if model == "yolov3-tiny" else 100)
+
+
+def _stats(a, b):
+    d = np.abs(a["class_prob"] - b["class_prob"])
+    rel = np.abs(a["bbox_xywh"] - b["bbox_xywh"]) / (np.abs(b["bbox_xywh"]) + 1e-6)
+    return dict(score_med=float(np.median(d)), score_p99=float(np.percentile(d, 99)), score_max=float(d.max()),
+                box_rel_p99=float(np.percentile(rel, 99)), argmax_disagree=float((a["class_idx"] != b["class_idx"]).mean()))
+
+
+@pytest.mark.parametrize("model", ["yolov3-tiny", "yolov3", "yolov3-spp"])
+def test_bf16_whole_net_vs_bf16_oracle(model):
+    dim = MODEL_DIMS[model]
+    frames = np.stack([resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), dim, dim), synth_frames(5, 1, dim, dim)[0]])
+    out = _net(model).forward_frames(frames)
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    ref = orc.OracleDarknet(MODELS[model]).set_params(golden_params(model))
+    x = torch.from_numpy(orc.frames_to_input(list(frames)))
+    o32 = {k: v.numpy() for k, v in ref.forward(x, emulate_bf16=True).items()}
+    o64 = {k: v.numpy() for k, v in ref.forward(x, emulate_bf16=True, accumulate="f64").items()}
+    floor = _stats(o32, o64)          # what summation order alone does to a correct bf16 implementation
+    ours = _stats(got, o32)
+    print(model, "noise floor", floor)
+    print(model, "HIP vs oracle", ours)
+    assert np.isfinite(got["bbox_xywh"]).all() and np.isfinite(got["class_prob"]).all()
+    for key in ("score_med", "score_p99", "score_max", "box_rel_p99", "argmax_disagree"):
+        assert ours[key] <= 3.0 * floor[key] + 1e-6, "%s: %s %.3g vs noise floor %.3g" % (model, key, ours[key], floor[key])
+
+
+def _keep_agreement(det, g, prefix):
+    rows = set(int(r) for r in det[3])
+    want = set(g[prefix + "rows"].tolist())
+    gp = dict(zip(g[prefix + "rows"].tolist(), g[prefix + "prob"].tolist()))
+    gc = dict(zip(g[prefix + "rows"].tolist(), g[prefix + "cls"].tolist()))
+    mine = {int(r): k for k, r in enumerate(det[3])}
+    common = sorted(rows & want)
+    dp = np.array([abs(float(det[1][mine[r]]) - gp[r]) for r in common]) if common else np.zeros(1)
+    cls_same = float(np.mean([int(det[2][mine[r]]) == gc[r] for r in common])) if common else 1.0
+    return (len(rows & want) / len(rows | want) if rows | want else 1.0), dp, cls_same, len(rows ^ want)
+
+
+@pytest.mark.parametrize("model", ["yolov3-tiny", "yolov3", "yolov3-spp"])
+def test_bf16_post_nms_agreement_vs_reference(model):
+    """bf16 detections against the reference's float32 ``inference()`` lists (G7).  With procedural weights and
+    thousands of overlapping near-threshold boxes per frame the keep set is sensitive to bf16 rounding as such:
+    the floor is what the emulating oracle (an ideal bf16 implementation) reaches on the same frames."""
+    g = np.load(os.path.join(GOLDEN, "inference_%s.npz" % model))
+    fixture = bf16_agreement()[model]
+    dim = MODEL_DIMS[model]
+    frames = [load_jpeg_bgr("000000229358.jpg"), synth_frames(9, 1, dim, dim)[0], load_jpeg_bgr("000000393569.jpg")]
+    net = _net(model)
+    for tag in ("a", "b"):
+        pth, ith = g[tag + "_thresholds"]
+        res = yolov3.inference(net, frames, device="cuda", prob_thresh=float(pth), nms_iou_thresh=float(ith),
+                               return_rows=True)
+        for f in range(len(frames)):
+            jac, dp, cls_same, nxor = _keep_agreement(res[f], g, "%s_f%d_" % (tag, f))
+            fl = fixture["%s_f%d" % (tag, f)]
+            print("%s %s frame %d: keep-set Jaccard %.3f (ideal bf16: %.3f), score |d| median %.1e p99 %.1e (ideal %.1e / %.1e), "
+                  "class agreement on common rows %.4f" % (model, tag, f, jac, fl["jaccard"], np.median(dp),
+                                                          np.percentile(dp, 99), fl["score_med"], fl["score_p99"], cls_same))
+            if fl["ref_kept"] >= 100:
+                assert jac >= fl["jaccard"] - 0.08
+            else:           # a handful of detections: count rows instead of a ratio
+                ideal_xor = round((1.0 - fl["jaccard"]) * max(fl["kept"], fl["ref_kept"]) * 2)
+                assert nxor <= ideal_xor + 3
+            assert np.median(dp) <= 2.0 * fl["score_med"] + 1e-3 and np.percentile(dp, 99) <= 2.0 * fl["score_p99"] + 5e-3
+            assert cls_same >= 0.99

@@ -13,7 +13,7 @@ from yolov3 import weights as W
 from yolov3.preprocess import resize_bilinear_u8
 from yolov3.synthdata import synth_frames
 
-from golden_util import (GOLDEN, MODELS, MODEL_DIMS, golden_weights_path, load_jpeg_bgr, sha,
+from golden_util import (GOLDEN, MODELS, MODEL_DIMS, ROOT, golden_params, golden_weights_path, load_jpeg_bgr, sha,
                          compare_detections)
 
 
@@ -117,6 +117,77 @@ def test_inference_golden_tiny(tmp_path):
     for tag in ("a", "b"):
         pth, ith = g[tag + "_thresholds"]
         res = orc.postprocess(out["bbox_xywh"].numpy(), out["class_prob"].numpy(), out["class_idx"].numpy(),
-                              [f.shape for f in frames], float(pth), float(ith))
+                              [f.shape for f in frames], float(pth), float(ith), audit=True)
         for f in range(len(frames)):
-            compare_detections(g, "%s_f%d_" % (tag, f), res[f], rows=None)
+            ndiff, nbad = compare_detections(g, "%s_f%d_" % (tag, f), res[f][:3], rows=res[f][3])
+            assert ndiff == 0 and nbad == 0        # same machine, same libraries as the golden run: exact
+            # the audit the oracle computes is the one stored with the goldens
+            assert np.array_equal(res[f][4], g["%s_f%d_cand_rows" % (tag, f)])
+            assert np.array_equal(res[f][5], g["%s_f%d_cand_fragile" % (tag, f)])
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16 emulation mode of the oracle (checker of the product's bf16 path, tests/test_gpu_bf16.py)
+# ---------------------------------------------------------------------------------------------------
+
+def test_bf16_rounding_points():
+    net = orc.OracleDarknet(MODELS["yolov3"])
+    rounds = net.bf16_rounding_points()
+    kinds = [b["type"] for b in net.blocks]
+    kept_f32 = [i for i, r in enumerate(rounds) if not r]
+    # 23 convs whose only reader is the shortcut behind them + 3 detection-head convs stay float32
+    assert len(kept_f32) == 26 and all(kinds[i] == "convolutional" for i in kept_f32)
+    assert sum(kinds[i + 1] == "yolo" for i in kept_f32) == 3 and sum(kinds[i + 1] == "shortcut" for i in kept_f32) == 23
+
+
+def test_bf16_emulation_noise_floor():
+    """The emulation stores bf16 values where it says it does; accumulating in float32 or float64 changes single
+    blocks by at most one bf16 ulp on a small share of the values (teacher-forced), and the end-to-end outputs of
+    yolov3-tiny by ~1e-3 -- the yardsticks the GPU tests use."""
+    model = "yolov3-tiny"
+    dim = MODEL_DIMS[model]
+    frames = [synth_frames(5, 1, dim, dim)[0]]
+    x = torch.from_numpy(orc.frames_to_input(frames))
+    net = orc.OracleDarknet(MODELS[model]).set_params(golden_params(model))
+    c32, c64 = {}, {}
+    o32 = net.forward(x, emulate_bf16=True, collect=c32)
+    o64 = net.forward(x, emulate_bf16=True, accumulate="f64", collect=c64)
+    rounds = net.bf16_rounding_points()
+    for i, blk in enumerate(net.blocks):
+        if blk["type"] != "yolo" and rounds[i]:
+            assert torch.equal(c32[i], orc.bf16_round(c32[i])), "block %d is not stored in bf16" % i
+    # teacher-forced: block 2 (conv 16 -> 32) from the SAME input, float32 vs float64 accumulation
+    blk = net.blocks[2]
+    a = orc.bf16_round(orc.conv_block(c32[1], net.params[1], blk["stride"], 1, True, bf16_weights=True))
+    b = orc.bf16_round(orc.conv_block(c32[1], net.params[1], blk["stride"], 1, True, bf16_weights=True, accumulate="f64"))
+    d = (a - b).abs()
+    assert float((d > 0).float().mean()) < 0.01
+    assert bool((d <= 2.0 ** -7 * b.abs() + 1e-4 * float(b.pow(2).mean().sqrt())).all())
+    dp = (o32["class_prob"] - o64["class_prob"]).abs().numpy()
+    assert np.median(dp) < 1e-3 and dp.max() < 0.05
+    # and bf16 as such stays near the float32 reference golden on this small network
+    g = np.load(os.path.join(GOLDEN, "forward_%s.npz" % model))
+    assert np.median(np.abs(o32["class_prob"].numpy()[0] - g["class_prob"][1])) < 1e-3
+
+
+def test_bf16_agreement_fixture_is_what_the_oracle_produces():
+    """tests/golden/bf16_agreement.json (floors for the GPU bf16 tests and bench.py) regenerates from the oracle
+    and the G7 goldens (tools/make_bf16_fixture.py); checked here for yolov3-tiny."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_bf16_fixture", os.path.join(ROOT, "tools", "make_bf16_fixture.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from golden_util import bf16_agreement
+    model = "yolov3-tiny"
+    g = np.load(os.path.join(GOLDEN, "inference_%s.npz" % model))
+    dim = MODEL_DIMS[model]
+    frames = [load_jpeg_bgr("000000229358.jpg"), synth_frames(9, 1, dim, dim)[0], load_jpeg_bgr("000000393569.jpg")]
+    x = torch.from_numpy(orc.frames_to_input([resize_bilinear_u8(f, dim, dim) for f in frames]))
+    o = orc.OracleDarknet(MODELS[model]).set_params(golden_params(model)).forward(x, emulate_bf16=True)
+    pth, ith = g["a_thresholds"]
+    dets = orc.postprocess(o["bbox_xywh"].numpy(), o["class_prob"].numpy(), o["class_idx"].numpy(),
+                           [f.shape for f in frames], float(pth), float(ith), audit=True)
+    fixture = bf16_agreement()[model]
+    for f in range(3):
+        a = mod.agreement(dets[f], g, "a_f%d_" % f)
+        assert a["jaccard"] == fixture["a_f%d" % f]["jaccard"] and a["kept"] == fixture["a_f%d" % f]["kept"]

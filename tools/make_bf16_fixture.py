@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""tests/golden/bf16_agreement.json: what an IDEAL bf16 implementation reaches against the reference's float32
+``inference()`` lists (G7, tests/golden/inference_*.npz, produced by the reference itself).
+
+The reference has no bf16 mode; the bf16-emulating oracle (oracle/darknet_oracle.py, ``emulate_bf16=True``) stands for
+"a correct bf16 implementation".  For every G7 frame and threshold pair this stores the keep-set Jaccard (by prediction
+row) and the score differences on the common rows, for the oracle accumulating in float32 and in float64 (the spread
+between the two is the summation-order noise).  tests/test_gpu_bf16.py and bench.py (``bf16_agreement``) compare the HIP
+bf16 path with these floors.  Runs on CPU, needs nothing outside the repository:  python tools/make_bf16_fixture.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+for p in (os.path.join(ROOT, "pytorch-yolov3_amd"), ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+from oracle import darknet_oracle as orc  # noqa: E402
+from golden_util import GOLDEN, MODELS, MODEL_DIMS, golden_params, load_jpeg_bgr  # noqa: E402
+from yolov3.preprocess import resize_bilinear_u8  # noqa: E402
+from yolov3.synthdata import synth_frames  # noqa: E402
+
+
+def agreement(det, g, prefix):
+    rows = set(int(r) for r in det[3])
+    want = set(g[prefix + "rows"].tolist())
+    gp = dict(zip(g[prefix + "rows"].tolist(), g[prefix + "prob"].tolist()))
+    mine = {int(r): k for k, r in enumerate(det[3])}
+    common = sorted(rows & want)
+    dp = np.array([abs(float(det[1][mine[r]]) - gp[r]) for r in common]) if common else np.zeros(1)
+    return dict(jaccard=round(len(rows & want) / len(rows | want), 4) if rows | want else 1.0, kept=len(rows), ref_kept=len(want),
+                score_med=float(np.median(dp)), score_p99=float(np.percentile(dp, 99)), score_max=float(dp.max()))
+
+
+def main():
+    table = {}
+    for model in ("yolov3-tiny", "yolov3", "yolov3-spp"):
+        g = np.load(os.path.join(GOLDEN, "inference_%s.npz" % model))
+        dim = MODEL_DIMS[model]
+        frames = [load_jpeg_bgr("000000229358.jpg"), synth_frames(9, 1, dim, dim)[0], load_jpeg_bgr("000000393569.jpg")]
+        x = torch.from_numpy(orc.frames_to_input([resize_bilinear_u8(f, dim, dim) for f in frames]))
+        net = orc.OracleDarknet(MODELS[model]).set_params(golden_params(model))
+        entry = {}
+        for acc in ("f32", "f64"):
+            o = net.forward(x, emulate_bf16=True, accumulate=acc)
+            for tag in ("a", "b"):
+                pth, ith = g[tag + "_thresholds"]
+                dets = orc.postprocess(o["bbox_xywh"].numpy(), o["class_prob"].numpy(), o["class_idx"].numpy(),
+                                       [f.shape for f in frames], float(pth), float(ith), audit=True)
+                for f in range(len(frames)):
+                    a = agreement(dets[f], g, "%s_f%d_" % (tag, f))
+                    key = "%s_f%d" % (tag, f)
+                    if acc == "f32":
+                        entry[key] = a
+                    else:
+                        entry[key]["jaccard_f64acc"] = a["jaccard"]
+                    print(model, acc, key, a)
+        table[model] = entry
+    with open(os.path.join(GOLDEN, "bf16_agreement.json"), "w") as fh:
+        json.dump(table, fh, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
