@@ -60,7 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip pcie_inclusive / other_configs / bf16_agreement (A/B runs, profiling)")
-    ap.add_argument("--cpu-budget", type=float, default=25.0, help="seconds of CPU-baseline work (bounded sample)")
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU-baseline work (bounded sample)")
     ap.add_argument("--profile-passes", type=int, default=3)
     ap.add_argument("--dump-ops", default=None, help="write the per-op timing table (text) to this file")
     ap.add_argument("--streams", type=int, default=3,
@@ -339,18 +339,20 @@ def cpu_baseline(cfg, params, model, dim, budget_s):
     spent = 0.0
     for batch, share in ((1, 0.2), (16, 0.8)):
         times = []
-        warm = 0
+        warm, want_warm = 0, 3
         limit = spent + budget_s * share if batch == 1 else budget_s
         while len(times) < 10:
             c0 = time.perf_counter()
             orc.inference(onet, frames[:batch], 0.05, 0.3)
             dt = time.perf_counter() - c0
             spent += dt
-            if warm < 3 and (batch == 1 or spent + 2 * dt < limit):
+            if warm == 0 and (limit - spent) / dt < 12:
+                want_warm = 1                     # the budget cannot hold 3 + 10 iterations: 1 warm-up, as many timed as fit
+            if warm < want_warm:
                 warm += 1
                 continue
             times.append(dt)
-            if spent + dt > limit and len(times) >= 2:
+            if spent + dt > limit and len(times) >= 3:
                 break
         med = float(np.median(times))
         out[batch] = dict(fps=round(batch / med, 3), median_s=round(med, 4), warmup=warm, timed=len(times))
