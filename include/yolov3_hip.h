@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define Y3_ABI_VERSION 1
+#define Y3_ABI_VERSION 2
 
 /* error codes */
 #define Y3_OK 0
@@ -100,6 +100,31 @@ typedef struct y3_op {
 
 typedef struct y3_plan y3_plan;
 
+/*
+ * Kernel-selection options of ONE plan (fixed when the plan is created).  y3_options_default() fills in the
+ * library's defaults -- the measured-best choices, profiles/ -- as modified by y3_set_tuning(); results do not
+ * depend on them beyond floating-point summation order.
+ *   auto_mask        per-layer kernel choice bits, default 157: halo-reuse kernel for every 3x3 stride-1 conv it fits
+ *                    (bit 0: rows > 64 px, bit 4: 33..64, bit 2: <= 32), the 2-D patch kernel for rows wider than
+ *                    128 px (bit 7), the wave-specialised implicit GEMM for 1x1 layers with Cin >= 1024 (bit 3);
+ *                    0 = implicit GEMM v2 everywhere; bits 1 / 5 / 6 route more layers to the wave-specialised
+ *                    implicit GEMM (api.hip)
+ *   halo_persistent  0 [default] one tile per workgroup, 1 persistent tile loop (bf16 networks; float32 keeps 0)
+ *   igemm_version    1 register-staged, 2 LDS-DMA double-buffered [default], 3 wave-specialised
+ *   igemm_ns         LDS stages of version 3 (3 or 4; less means 3);  igemm_bm  64 = 64-pixel tiles for version 3 (bf16)
+ *   use_graph        1: y3_plan_run replays a captured hipGraph (one launch per forward) on non-default streams;
+ *                    0 [default]: every kernel is launched individually (measured 1 % faster at batch 16)
+ *   fuse_stem        1 [default]: conv pairs flagged Y3_F_FUSE_NEXT run as one kernel where one exists
+ *   fuse_head        1 [default]: detection-head conv + YOLO decode in one launch (bf16 networks)
+ *   fuse_spp         1 [default]: three stride-1 max-pools (5 / 9 / 13) of one tensor in one launch
+ *   decode_lanes     4 [default]: four lanes per box in the bf16 decode; 1: sequential class loop everywhere
+ */
+typedef struct y3_options {
+  int32_t auto_mask, halo_persistent, igemm_version, igemm_ns, igemm_bm;
+  int32_t use_graph, fuse_stem, fuse_head, fuse_spp, decode_lanes;
+  int32_t reserved[6];
+} y3_options;
+
 /* library / device ------------------------------------------------------------------- */
 int y3_abi_version(void);
 const char *y3_last_error(void);
@@ -109,6 +134,9 @@ int y3_device_count(void);
 /* plan executor: replaces the block loop of Darknet.forward (darknet.py:366-399) -------- */
 /* copies `ops` (host array); `d_zero` = >= 256 bytes of zeroed device memory that outlives the plan */
 int y3_plan_create(const y3_op *ops, int n_ops, const void *d_zero, y3_plan **out_plan);
+/* same with explicit options (NULL = the current defaults); the plan keeps its own copy */
+int y3_plan_create_ex(const y3_op *ops, int n_ops, const void *d_zero, const y3_options *options, y3_plan **out_plan);
+void y3_options_default(y3_options *options);
 void y3_plan_destroy(y3_plan *plan);
 /* launches every op on `stream` (with the "use_graph" knob: from the second call on, on a non-default stream, as one
  * captured hipGraph per distinct d_input); `d_input` feeds ops flagged Y3_F_PLAN_INPUT */
@@ -129,18 +157,10 @@ double y3_plan_op_bytes(const y3_plan *plan, int op_index);
  * out accordingly.                                                                              */
 int y3_conv_path(const y3_op *op);
 
-/* process-wide tuning knobs for A/B measurements (tools/conv_bench.py, bench.py --tuning):
- *   "auto_mask"       per-layer kernel choice bits, default 157: halo-reuse kernel for every 3x3 stride-1 conv it
- *                     fits (bit 0: rows > 64 px, bit 4: 33..64, bit 2: <= 32), the 2-D patch kernel for rows wider
- *                     than 128 px (bit 7), the wave-specialised implicit GEMM for 1x1 layers with Cin >= 1024 (bit 3);
- *                     0 = implicit GEMM v2 everywhere; bits 1 / 5 / 6 route more layers to the wave-specialised
- *                     implicit GEMM (api.hip)
- *   "halo_persistent" 0 [default] one tile per workgroup, 1 persistent tile loop (bf16 networks; float32 keeps 0)
- *   "igemm_version"   1 register-staged, 2 LDS-DMA double-buffered [default], 3 wave-specialised
- *   "igemm_ns"        LDS stages of version 3 (3 or 4; less means 3);  "igemm_bm" 64 = 64-pixel tiles for version 3 (bf16)
- *   "use_graph"       1: y3_plan_run replays a captured hipGraph (one launch per forward) on non-default streams;
- *                     0 [default]: every kernel is launched individually (measured 1 % faster at batch 16)
- * Results do not depend on the knobs beyond floating-point summation order.                          */
+/* A/B measurements only (tools/conv_bench.py, bench.py --tuning): changes ONE field of the process-wide DEFAULT
+ * options by name ("auto_mask", "halo_persistent", "igemm_version", "igemm_ns", "igemm_bm", "use_graph", "fuse_stem",
+ * "fuse_head", "fuse_spp", "decode_lanes").  Plans created afterwards without explicit options pick it up; existing
+ * plans keep the options they were created with.                                                                  */
 int y3_set_tuning(const char *key, int value);
 
 /* single op (unit tests): same dispatch as inside a plan */
@@ -176,8 +196,11 @@ int y3_nms(const int64_t *d_tlbr, const float *d_prob, const int64_t *d_cls, int
 int y3_cxywh_to_tlbr(const int64_t *d_xywh, int64_t *d_tlbr, int n, int cols, void *stream);
 
 /* frame resize on device (replaces the host cv2.resize of inference.py:320-326): uint8
- * (src_h,src_w,3) -> (dst_h,dst_w,3), fixed-point bilinear.  d_ytab (dst_h,4) / d_xtab (dst_w,4) int32 rows =
- * {lo index, hi index, weight_lo, weight_hi} with weights summing to 2048 (yolov3/preprocess.py:axis_table). */
+ * (src_h,src_w,3) -> (dst_h,dst_w,3) with OpenCV's 8-bit INTER_LINEAR arithmetic: per channel
+ *   top = S[ylo][xlo]*ax0 + S[ylo][xhi]*ax1,  bot = the same on row yhi   (int, 11-bit coefficients)
+ *   out = (((ay0 * (top >> 4)) >> 16) + ((ay1 * (bot >> 4)) >> 16) + 2) >> 2
+ * d_ytab (dst_h,4) / d_xtab (dst_w,4) int32 rows = {lo index, hi index, weight_lo, weight_hi}: OpenCV's yofs / ibeta
+ * and xofs / ialpha tables, computed on the host (yolov3/preprocess.py:axis_table). */
 int y3_resize_bilinear_u8(const uint8_t *d_src, int src_h, int src_w, uint8_t *d_dst, int dst_h, int dst_w,
                           const int32_t *d_ytab, const int32_t *d_xtab, void *stream);
 

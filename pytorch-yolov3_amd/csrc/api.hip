@@ -14,18 +14,25 @@ namespace {
 thread_local char g_err[512] = "";
 }
 
-// per-layer kernel choice for the MFMA convs (tools/conv_bench.py tables in profiles/): bit 0: wave-specialised halo
-// kernel for 3x3 s1 layers with rows wider than 64; bit 1: wave-specialised igemm (3 stages) for 3x3 layers with rows of
-// 33..64; bit 2: halo kernel for rows <= 32; bit 3: wave-specialised igemm for 1x1 layers with Cin >= 1024;
-// bit 4: halo kernel for rows of 33..64 instead; bit 5: wave-specialised igemm for rows <= 32 instead;
-// bit 7: 2-D patch kernel (8 x 32 output tiles) for 3x3 stride-1 layers with rows wider than 128 px;
-// bit 6: wave-specialised igemm with 64-pixel tiles (3 stages, two workgroups per CU) for bf16 1x1 layers with Cin >= 256
-int g_y3_auto_mask = 157;  // measured best end to end (profiles/r01_ab_kernel_selection.txt): halo kernel at every row width it fits, 2-D patch kernel for rows wider than 128 px, wave-specialised igemm for the deep-K 1x1 layers
-int g_y3_tuning_epoch = 0;      // bumped by every y3_set_tuning call: captured graphs bake the kernel choice in
-int g_y3_use_graph = 0;         // 1: y3_plan_run replays a captured hipGraph when it can (tuning knob "use_graph");
-                                // measured 1 % SLOWER than 78 individual launches (profiles/r01_ab_kernel_selection.txt)
-int g_y3_halo_persistent = 0;   // halo kernel: 0 = one tile per workgroup, 1 = persistent tile loop (conv_halo.hip)   // experimental halo-reuse 3x3 kernels (conv_halo.hip); off: the implicit GEMM measured as fast
-
+// Default options (y3_options_default / y3_set_tuning).  auto_mask, per-layer kernel choice for the MFMA convs
+// (tools/conv_bench.py tables in profiles/): bit 0: wave-specialised halo kernel for 3x3 s1 layers with rows wider than
+// 64; bit 1: wave-specialised igemm (3 stages) for 3x3 layers with rows of 33..64; bit 2: halo kernel for rows <= 32;
+// bit 3: wave-specialised igemm for 1x1 layers with Cin >= 1024; bit 4: halo kernel for rows of 33..64 instead;
+// bit 5: wave-specialised igemm for rows <= 32 instead; bit 7: 2-D patch kernel (8 x 32 output tiles) for 3x3 stride-1
+// layers with rows wider than 128 px; bit 6: wave-specialised igemm with 64-pixel tiles (3 stages, two workgroups per CU)
+// for bf16 1x1 layers with Cin >= 256.  157 = measured best end to end (profiles/r01_ab_kernel_selection.txt).
+static y3_options g_y3_defaults = {/*auto_mask*/ 157, /*halo_persistent*/ 0, /*igemm_version*/ 2, /*igemm_ns*/ 2,
+                                   /*igemm_bm*/ 0, /*use_graph*/ 0, /*fuse_stem*/ 1, /*fuse_head*/ 1, /*fuse_spp*/ 1,
+                                   /*decode_lanes*/ 4, {0, 0, 0, 0, 0, 0}};
+static thread_local const y3_options *tl_y3_opt = nullptr;
+const y3_options &y3_opt() { return tl_y3_opt ? *tl_y3_opt : g_y3_defaults; }
+namespace {
+struct OptScope {   // the launchers called below this frame see the plan's options
+  const y3_options *prev;
+  explicit OptScope(const y3_options *o) : prev(tl_y3_opt) { tl_y3_opt = o; }
+  ~OptScope() { tl_y3_opt = prev; }
+};
+}  // namespace
 
 void y3_set_error(const char *fmt, ...) {
   va_list ap;
@@ -39,14 +46,15 @@ struct y3_plan {
   std::vector<const char *> kernel;
   const void *d_zero;
   std::vector<char> fuse;   // per op: 0 = launch normally, 1 / 3 / 4 = launch fused with the next op (stem pair / residual
-                            // block / head conv + decode), 2 = nothing (fused into the previous op)
+                            // block / head conv + decode), 5 = SPP pyramid with the next TWO ops, 2 = nothing (fused
+                            // into a previous op)
   std::vector<hipEvent_t> events;
   // hipGraph replay (one graph launch per forward instead of ~80 kernel launches): executable graphs keyed by the
   // input pointer they were captured with; the first run of a plan is always eager (one-time function attributes)
   struct GraphEntry { const void *input; hipGraphExec_t exec; };
   std::vector<GraphEntry> graphs;
   bool warmed = false, graph_ok = true;
-  int epoch = 0;            // value of g_y3_tuning_epoch the graphs were captured under
+  y3_options opt;           // fixed at creation
 };
 
 namespace {
@@ -78,8 +86,8 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
         Y3_REQUIRE(op.d_weight && op.d_scale && op.d_bias, "conv block %d: missing parameters", op.block_idx);
       switch (conv_path(op)) {
         case 0: {
-          if (g_y3_auto_mask) {
-            const int am = g_y3_auto_mask, w = op.in_w;
+          if (y3_opt().auto_mask) {
+            const int am = y3_opt().auto_mask, w = op.in_w;
             const bool k3 = op.ksize == 3 && op.stride == 1 && op.in_c >= 128 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32);
             const bool halo_ok = k3 && y3_conv_halo_ws_fits(op);
             bool want_halo = false, want_ws = false;
@@ -92,7 +100,7 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
               return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3, 64);
             if ((am & 128) && op.ksize == 3 && op.stride == 1 && w > 128 && op.out_c >= 128 && y3_conv_patch_fits(op))
               return y3_launch_conv_patch(op, in, d_zero, s, name, dry_run);
-            if (want_halo && halo_ok) return y3_launch_conv_halo(op, in, d_zero, s, name, dry_run, g_y3_halo_persistent != 0);
+            if (want_halo && halo_ok) return y3_launch_conv_halo(op, in, d_zero, s, name, dry_run, y3_opt().halo_persistent != 0);
             if (want_ws) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
           }
           return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run);
@@ -118,6 +126,7 @@ int run_op(y3_plan *plan, size_t i, const void *d_input, hipStream_t s, const ch
   if (plan->fuse[i] == 2) return Y3_OK;
   if (plan->fuse[i] == 3) return y3_launch_conv_fused_resblock(plan->ops[i], plan->ops[i + 1], s, name, false);
   if (plan->fuse[i] == 4) return y3_launch_conv_head_decode(plan->ops[i], plan->ops[i + 1], plan->d_zero, s, name, false);
+  if (plan->fuse[i] == 5) return y3_launch_maxpool_spp(plan->ops[i], plan->ops[i + 1], plan->ops[i + 2], s, name, false);
   if (plan->fuse[i] == 1) {
     const y3_op &op0 = plan->ops[i];
     const void *in = (op0.flags & Y3_F_PLAN_INPUT) ? d_input : op0.d_in;
@@ -153,17 +162,33 @@ int y3_conv_path(const y3_op *op) {
   return conv_path(*op);
 }
 
+void y3_options_default(y3_options *options) {
+  if (options) *options = g_y3_defaults;
+}
+
 int y3_plan_create(const y3_op *ops, int n_ops, const void *d_zero, y3_plan **out_plan) {
+  return y3_plan_create_ex(ops, n_ops, d_zero, nullptr, out_plan);
+}
+
+int y3_plan_create_ex(const y3_op *ops, int n_ops, const void *d_zero, const y3_options *options, y3_plan **out_plan) {
   Y3_REQUIRE(ops && n_ops > 0 && out_plan, "y3_plan_create: bad arguments");
   Y3_REQUIRE(d_zero, "y3_plan_create: d_zero (zeroed device page) is required");
   y3_plan *p = new (std::nothrow) y3_plan;
   Y3_REQUIRE(p, "y3_plan_create: out of host memory");
+  p->opt = options ? *options : g_y3_defaults;
+  OptScope scope(&p->opt);
   p->ops.assign(ops, ops + n_ops);
   p->kernel.assign(n_ops, "");
   p->d_zero = d_zero;
   p->fuse.assign(n_ops, 0);
+  for (int i = 0; i + 2 < n_ops; ++i)
+    if (y3_opt().fuse_spp && y3_maxpool_spp_supported(p->ops[i], p->ops[i + 1], p->ops[i + 2])) {
+      p->fuse[i] = 5;           // SPP pyramid: pool 5 / 9 / 13 of one tensor in one launch
+      p->fuse[i + 1] = p->fuse[i + 2] = 2;
+    }
   for (int i = 0; i + 1 < n_ops; ++i)
-    if ((p->ops[i].flags & Y3_F_FUSE_NEXT) && p->ops[i].kind == Y3_OP_CONV &&
+    if (p->fuse[i] != 0) continue;
+    else if ((p->ops[i].flags & Y3_F_FUSE_NEXT) && p->ops[i].kind == Y3_OP_CONV &&
         y3_conv_fused_stem_s2_supported(p->ops[i], p->ops[i + 1])) {
       p->fuse[i] = 1;
       p->fuse[i + 1] = 2;
@@ -186,6 +211,10 @@ int y3_plan_create(const y3_op *ops, int n_ops, const void *d_zero, y3_plan **ou
     }
     if (p->fuse[i] == 4) {
       (void)y3_launch_conv_head_decode(p->ops[i], p->ops[i + 1], d_zero, nullptr, &p->kernel[i], true);
+      continue;
+    }
+    if (p->fuse[i] == 5) {
+      (void)y3_launch_maxpool_spp(p->ops[i], p->ops[i + 1], p->ops[i + 2], nullptr, &p->kernel[i], true);
       continue;
     }
     const int rc = dispatch(p->ops[i], nullptr, d_zero, nullptr, &p->kernel[i], true);
@@ -217,15 +246,11 @@ static int plan_run_eager(y3_plan *plan, const void *d_input, hipStream_t s) {
 int y3_plan_run(y3_plan *plan, const void *d_input, void *stream) {
   Y3_REQUIRE(plan, "y3_plan_run: null plan");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // graphs need a capturable (non-default) stream; the plan's pointers never change, only d_input may
-  if (!g_y3_use_graph || !plan->graph_ok || s == nullptr || !plan->warmed) {
+  OptScope scope(&plan->opt);
+  // graphs need a capturable (non-default) stream; the plan's pointers and options never change, only d_input may
+  if (!plan->opt.use_graph || !plan->graph_ok || s == nullptr || !plan->warmed) {
     plan->warmed = true;
     return plan_run_eager(plan, d_input, s);
-  }
-  if (plan->epoch != g_y3_tuning_epoch) {         // a knob changed since the capture: the launches may differ now
-    for (auto &g : plan->graphs) (void)hipGraphExecDestroy(g.exec);
-    plan->graphs.clear();
-    plan->epoch = g_y3_tuning_epoch;
   }
   for (auto &g : plan->graphs)
     if (g.input == d_input) {
@@ -261,6 +286,7 @@ int y3_plan_run(y3_plan *plan, const void *d_input, void *stream) {
 int y3_plan_run_timed(y3_plan *plan, const void *d_input, void *stream, float *ms_per_op) {
   Y3_REQUIRE(plan && ms_per_op, "y3_plan_run_timed: bad arguments");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  OptScope scope(&plan->opt);
   const size_t n = plan->ops.size();
   while (plan->events.size() < n + 1) {
     hipEvent_t e;
@@ -308,6 +334,10 @@ double y3_plan_op_bytes(const y3_plan *plan, int op_index) {
     return ((double)a.batch * a.in_h * a.in_w * a.in_c + (double)a.in_c * a.out_c) * 2.0 +
            (double)b.batch * b.in_h * b.in_w * b.n_anchor * 28.0;
   }
+  if (plan->fuse[op_index] == 5) {   // the tensor in once, three pooled tensors out
+    const y3_op &a = plan->ops[op_index];
+    return 4.0 * a.batch * a.in_h * a.in_w * a.in_c * y3_elem_size(a.dtype);
+  }
   if (plan->fuse[op_index] == 3) {   // x in (once), z out, both weight sets
     const y3_op &a = plan->ops[op_index], &b = plan->ops[op_index + 1];
     return ((double)a.batch * a.in_h * a.in_w * a.in_c + (double)b.batch * b.out_h * b.out_w * b.out_c) * 2.0 +
@@ -330,6 +360,20 @@ double y3_plan_op_bytes(const y3_plan *plan, int op_index) {
     case Y3_OP_YOLO: return in_px * o.n_anchor * (o.n_attr * 4.0 + 28.0);
     default: return (in_px * o.in_c + out_px * o.out_c) * es;
   }
+}
+
+int y3_set_tuning(const char *key, int value) {
+  if (!key) return Y3_ERR_INVALID;
+  struct { const char *name; int32_t *field; } fields[] = {
+      {"auto_mask", &g_y3_defaults.auto_mask}, {"halo_persistent", &g_y3_defaults.halo_persistent},
+      {"igemm_version", &g_y3_defaults.igemm_version}, {"igemm_ns", &g_y3_defaults.igemm_ns},
+      {"igemm_bm", &g_y3_defaults.igemm_bm}, {"use_graph", &g_y3_defaults.use_graph},
+      {"fuse_stem", &g_y3_defaults.fuse_stem}, {"fuse_head", &g_y3_defaults.fuse_head},
+      {"fuse_spp", &g_y3_defaults.fuse_spp}, {"decode_lanes", &g_y3_defaults.decode_lanes}};
+  for (auto &f : fields)
+    if (!strcmp(key, f.name)) { *f.field = value; return Y3_OK; }
+  y3_set_error("y3_set_tuning: unknown key %s", key);
+  return Y3_ERR_INVALID;
 }
 
 int y3_op_run(const y3_op *op, const void *d_input, const void *d_zero, void *stream) {

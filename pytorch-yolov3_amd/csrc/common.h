@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "yolov3_hip.h"
 
 typedef __bf16 bf16_t;
@@ -36,6 +38,29 @@ void y3_set_error(const char *fmt, ...);
       return Y3_ERR_INVALID;      \
     }                             \
   } while (0)
+
+// One-time set-up per DEVICE (dynamic-LDS function attributes are per device; so is the CU count a persistent grid is
+// sized by), safe to call from several host threads.
+struct Y3DeviceOnce {
+  std::mutex mu;
+  bool done[32] = {};
+  int n_cu[32] = {};
+  template <typename F>
+  int run(F &&setup, int *cu_out = nullptr) {
+    int dev = 0;
+    Y3_HIP_CHECK(hipGetDevice(&dev));
+    Y3_REQUIRE(dev >= 0 && dev < 32, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done[dev]) {
+      const int rc = setup();
+      if (rc != Y3_OK) return rc;
+      Y3_HIP_CHECK(hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev));
+      done[dev] = true;
+    }
+    if (cu_out) *cu_out = n_cu[dev];
+    return Y3_OK;
+  }
+};
 
 static inline int y3_elem_size(int dtype) { return dtype == Y3_BF16 ? 2 : 4; }
 static inline int y3_ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -183,6 +208,10 @@ int y3_launch_conv_stem_mfma(const y3_op &op, const void *d_in, hipStream_t s, c
                              bool dry_run);
 int y3_launch_maxpool(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
                       bool dry_run);
+// SPP pyramid: three stride-1 max-pools (5 / 9 / 13) of one tensor in one launch (layers.hip)
+bool y3_maxpool_spp_supported(const y3_op &a, const y3_op &b, const y3_op &c);
+int y3_launch_maxpool_spp(const y3_op &a, const y3_op &b, const y3_op &c, hipStream_t s, const char **kernel_name,
+                          bool dry_run);
 int y3_launch_upsample(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
                        bool dry_run);
 int y3_launch_add(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
@@ -202,7 +231,6 @@ int y3_launch_conv_fused_resblock(const y3_op &op0, const y3_op &op1, hipStream_
 bool y3_conv_head_decode_supported(const y3_op &op0, const y3_op &op1);
 int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d_zero, hipStream_t s,
                                const char **kernel_name, bool dry_run);
-extern int g_y3_fuse_stem;
 // halo-reuse 3x3 kernel (conv_halo.hip): whether it can take this conv, and its launcher
 bool y3_conv_halo_ws_fits(const y3_op &op);
 int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
@@ -210,10 +238,7 @@ int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, h
 bool y3_conv_patch_fits(const y3_op &op);
 int y3_launch_conv_patch(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
                          const char **kernel_name, bool dry_run);
-// process-wide tuning knobs (y3_set_tuning)
-extern int g_y3_use_graph;
-extern int g_y3_tuning_epoch;
-extern int g_y3_halo_persistent;
-extern int g_y3_auto_mask; // per-layer kernel selection bits (api.hip)
+// options of the plan being created / run on this thread (api.hip), else the process defaults (y3_set_tuning)
+const y3_options &y3_opt();
 // true when the MFMA implicit-GEMM kernel can take this conv
 bool y3_conv_igemm_supported(const y3_op &op);

@@ -453,12 +453,10 @@ __global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs p
 
 }  // namespace
 
-int g_y3_fuse_stem = 1;   // tuning knob "fuse_stem"
-int g_y3_fuse_dbg = 0;
 
 // op0: the MFMA stem conv (uint8 frames, 3 -> 32, bf16 out); op1: 3x3 stride-2 conv 32 -> 64 reading ONLY op0's output
 bool y3_conv_fused_stem_s2_supported(const y3_op &op0, const y3_op &op1) {
-  if (!g_y3_fuse_stem) return false;
+  if (!y3_opt().fuse_stem) return false;
   if (!y3_conv_stem_mfma_supported(op0) || op0.out_c != 32 || (op0.flags & Y3_F_RESIDUAL)) return false;
   if (!(op0.flags & Y3_F_LEAKY) || !(op1.flags & Y3_F_LEAKY)) return false;   // the kernel hard-wires LeakyReLU(0.1)
   if (op1.kind != Y3_OP_CONV || op1.dtype != Y3_BF16 || op1.ksize != 3 || op1.stride != 2 || op1.pad != 1) return false;
@@ -487,16 +485,16 @@ int y3_launch_conv_fused_stem_s2(const y3_op &op0, const y3_op &op1, const void 
   a.tiles_x = y3_ceil_div(a.Wo, kTO);
   a.tiles_y = y3_ceil_div(a.Ho, kTO);
   a.n_tiles = a.tiles_x * a.tiles_y * a.batch;
-  a.dbg = g_y3_fuse_dbg;
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
-    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_stem_s2_fused_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    int dev = 0;
-    Y3_HIP_CHECK(hipGetDevice(&dev));
-    Y3_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    attr_set = true;
+  a.dbg = 0;
+  static Y3DeviceOnce once;
+  int n_cu = 0;
+  {
+    const int rc = once.run([]() -> int {
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_stem_s2_fused_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+      return Y3_OK;
+    }, &n_cu);
+    if (rc != Y3_OK) return rc;
   }
   const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
   hipLaunchKernelGGL(conv_stem_s2_fused_kernel, dim3(grid), dim3(kThreads), kLds, s, a);
@@ -507,7 +505,7 @@ int y3_launch_conv_fused_stem_s2(const y3_op &op0, const y3_op &op1, const void 
 // op0: 1x1 conv 64 -> 32 whose output only op1 reads; op1: 3x3 stride-1 conv 32 -> 64 with the shortcut operand == op0's
 // input (one Darknet-53 residual block, bf16, LeakyReLU on both)
 bool y3_conv_fused_resblock_supported(const y3_op &op0, const y3_op &op1) {
-  if (!g_y3_fuse_stem) return false;
+  if (!y3_opt().fuse_stem) return false;
   if (op0.kind != Y3_OP_CONV || op1.kind != Y3_OP_CONV || op0.dtype != Y3_BF16 || op1.dtype != Y3_BF16) return false;
   if (op0.ksize != 1 || op0.stride != 1 || op0.in_c != 64 || op0.out_c != 32) return false;
   if (op1.ksize != 3 || op1.stride != 1 || op1.pad != 1 || op1.in_c != 32 || op1.out_c != 64) return false;
@@ -536,15 +534,15 @@ int y3_launch_conv_fused_resblock(const y3_op &op0, const y3_op &op1, hipStream_
   a.tiles_x = y3_ceil_div(a.W, kRT);
   a.tiles_y = y3_ceil_div(a.H, kRT);
   a.n_tiles = a.tiles_x * a.tiles_y * a.batch;
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
-    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_resblock_fused_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kRLds));
-    int dev = 0;
-    Y3_HIP_CHECK(hipGetDevice(&dev));
-    Y3_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    attr_set = true;
+  static Y3DeviceOnce once;
+  int n_cu = 0;
+  {
+    const int rc = once.run([]() -> int {
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_resblock_fused_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kRLds));
+      return Y3_OK;
+    }, &n_cu);
+    if (rc != Y3_OK) return rc;
   }
   const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
   hipLaunchKernelGGL(conv_resblock_fused_kernel, dim3(grid), dim3(kThreads), kRLds, s, a);

@@ -1036,13 +1036,16 @@ int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
     if (lds <= 160 * 1024) { nsb = c; break; }
   }
   Y3_REQUIRE(nsb != 0, "wave-specialised halo kernel: row width %d does not fit", a.W);
-  static bool attr_set = false;
-  if (!attr_set) {
-    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_ws_kernel<T, 3>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_ws_kernel<T, 4>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+  static Y3DeviceOnce once;
+  {
+    const int rc = once.run([]() -> int {
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_ws_kernel<T, 3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_ws_kernel<T, 4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      return Y3_OK;
+    });
+    if (rc != Y3_OK) return rc;
   }
   const dim3 grid(y3_ceil_div(a.M, 256) * a.n_tiles);
   if (nsb == 4) hipLaunchKernelGGL((conv_halo_ws_kernel<T, 4>), grid, dim3(768), lds, s, a);
@@ -1067,17 +1070,17 @@ int launch_halo_wsp(const HaloArgs &a0, hipStream_t s) {
     if (lds <= 160 * 1024) { nsb = c; break; }
   }
   Y3_REQUIRE(nsb != 0 && a.a_bytes >= 32 * 1024, "persistent halo kernel: row width %d does not fit", a.W);
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
-    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_wsp_kernel<T, 3>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_wsp_kernel<T, 4>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    int dev = 0;
-    Y3_HIP_CHECK(hipGetDevice(&dev));
-    Y3_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    attr_set = true;
+  static Y3DeviceOnce once;
+  int n_cu = 0;
+  {
+    const int rc = once.run([]() -> int {
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_wsp_kernel<T, 3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_wsp_kernel<T, 4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      return Y3_OK;
+    }, &n_cu);
+    if (rc != Y3_OK) return rc;
   }
   const int tiles = y3_ceil_div(a.M, 256) * a.n_tiles;
   const int grid = tiles < n_cu ? tiles : n_cu;
@@ -1096,15 +1099,15 @@ int launch_patch_wsp(const HaloArgs &a0, hipStream_t s) {
   a.a_bytes = a.hr_pad * 128;
   const size_t lds = (size_t)4 * 128 * 128 + (size_t)2 * a.a_bytes;
   static_assert(PROWS <= 12 * 32, "all patch slices must be out by tap 5 (4-slot ring)");
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
-    Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_patch_wsp_kernel<T, 4>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    int dev = 0;
-    Y3_HIP_CHECK(hipGetDevice(&dev));
-    Y3_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    attr_set = true;
+  static Y3DeviceOnce once;
+  int n_cu = 0;
+  {
+    const int rc = once.run([]() -> int {
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_patch_wsp_kernel<T, 4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      return Y3_OK;
+    }, &n_cu);
+    if (rc != Y3_OK) return rc;
   }
   const int tiles_x = y3_ceil_div(a.W, TX), tiles_y = y3_ceil_div(a.H, TY);
   const int tiles = tiles_x * tiles_y * (a.M / a.HW) * a.n_tiles;

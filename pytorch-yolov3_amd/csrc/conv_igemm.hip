@@ -921,9 +921,8 @@ void conv_igemm3_kernel(IgemmArgs p) {
   }
 }
 
-static int g_igemm_version = 2;   // 1 = register-staged single buffer, 2 = LDS-DMA double buffer
-static int g_igemm_bm = 0;        // 64 = 64-pixel tiles for the wave-specialised kernel (v3, bf16), else 128
-static int g_igemm_ns = 2;         // v3: LDS stages (3 or 4; smaller values mean 3)
+// y3_options: igemm_version 1 = register-staged single buffer, 2 = LDS-DMA double buffer, 3 = wave-specialised;
+// igemm_bm 64 = 64-pixel tiles for the wave-specialised kernel (bf16), else 128; igemm_ns = its LDS stages (3 or 4)
 
 template <typename T, int BM, int BN, int WM, int WN, int NS>
 int launch_cfg3x(IgemmArgs a, int kmode, hipStream_t s) {
@@ -995,30 +994,11 @@ static void igemm_fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
   mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
 }
 
-// process-wide tuning knobs (y3_set_tuning): kernel generation and tile override, for A/B runs
-
-extern "C" int y3_set_tuning(const char *key, int value) {
-  if (!key) return Y3_ERR_INVALID;
-  ++g_y3_tuning_epoch;
-  if (!strcmp(key, "igemm_version")) { g_igemm_version = value; return Y3_OK; }
-  if (!strcmp(key, "igemm_bm")) { g_igemm_bm = value; return Y3_OK; }
-  if (!strcmp(key, "igemm_ns")) { g_igemm_ns = value; return Y3_OK; }
-  if (!strcmp(key, "auto_mask")) { g_y3_auto_mask = value; return Y3_OK; }
-  if (!strcmp(key, "fuse_head")) { extern int g_y3_fuse_head; g_y3_fuse_head = value; return Y3_OK; }
-  if (!strcmp(key, "use_graph")) { g_y3_use_graph = value; return Y3_OK; }
-  if (!strcmp(key, "halo_persistent")) { g_y3_halo_persistent = value; return Y3_OK; }
-  if (!strcmp(key, "decode_lanes")) { extern int g_y3_decode_lanes; g_y3_decode_lanes = value; return Y3_OK; }
-  if (!strcmp(key, "fuse_dbg")) { extern int g_y3_fuse_dbg; g_y3_fuse_dbg = value; return Y3_OK; }
-  if (!strcmp(key, "fuse_stem")) { g_y3_fuse_stem = value; return Y3_OK; }   // takes effect at y3_plan_create
-  y3_set_error("y3_set_tuning: unknown key %s", key);
-  return Y3_ERR_INVALID;
-}
-
 int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
                          const char **kernel_name, bool dry_run, int force_version, int force_ns, int force_bm) {
-  const int version = force_version ? force_version : g_igemm_version;
-  const int ns = force_ns ? force_ns : g_igemm_ns;
-  const int bm_knob = force_bm ? force_bm : g_igemm_bm;
+  const int version = force_version ? force_version : y3_opt().igemm_version;
+  const int ns = force_ns ? force_ns : y3_opt().igemm_ns;
+  const int bm_knob = force_bm ? force_bm : y3_opt().igemm_bm;
   Y3_REQUIRE(y3_conv_igemm_supported(op), "conv block %d: shape not supported by the igemm kernel",
              op.block_idx);
   const int es = y3_elem_size(op.dtype);
@@ -1102,10 +1082,9 @@ Y3_STAMP_READER(y3_debug_stamps_igemm)
 // ---- detection head: 1x1 conv (bias, no activation, float32 logits) + YOLO decode in one launch -------------------
 // op0: the head conv as the plan holds it (Y3_F_OUT_F32, Cout = anchors * attributes <= 256); op1: the Y3_OP_YOLO op
 // reading it.  bf16 networks only: the float32 parity path keeps the two kernels (sequential class loop).
-int g_y3_fuse_head = 1;   // tuning knob "fuse_head" (takes effect at y3_plan_create)
 
 bool y3_conv_head_decode_supported(const y3_op &op0, const y3_op &op1) {
-  if (!g_y3_fuse_head) return false;
+  if (!y3_opt().fuse_head) return false;
   if (op0.kind != Y3_OP_CONV || op1.kind != Y3_OP_YOLO || op0.dtype != Y3_BF16) return false;
   if (op0.ksize != 1 || op0.stride != 1 || !(op0.flags & Y3_F_OUT_F32)) return false;
   if (op0.flags & (Y3_F_LEAKY | Y3_F_RESIDUAL | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT)) return false;

@@ -213,11 +213,154 @@ int y3_launch_copy(const y3_op &op, const void *d_in, hipStream_t s, const char 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Frame resize on device: uint8 HxWx3 -> net_h x net_w x 3, fixed-point bilinear.
-// Replaces the host `cv2.resize(image, (net_h, net_w))` of /root/reference/yolov3/inference.py:320-326 for
-// frames that are not net-sized.  Integer arithmetic only, identical to yolov3/preprocess.py:
-// resize_bilinear_u8 (the tap tables -- lo index, hi index, 11-bit weights per output row / column -- are
-// computed once on the host and passed in, so host and device results are bit-identical).
+// SPP pyramid (models/yolov3-spp.cfg:576-595): three stride-1 "same" max-pools of sizes 5 / 9 / 13 that read ONE
+// tensor and feed one route concat, as ONE launch.  Reference semantics (darknet.py:16-29): window
+// [y, y+k) x [x, x+k), out-of-range taps contribute 0.0 (ZeroPad2d right/bottom, then an unpadded pool).
+//
+// One workgroup = one frame x one 32-byte channel group (16 bf16 / 8 float32 channels).  The (H+12) x (W+12)
+// zero-padded image of that group is staged in LDS once (16-byte vectors, two per position), then the pyramid is
+// a cascade, exact because max is associative and the windows nest:
+//   R5[y][x]  = max(A[y][x .. x+4])                               (row pass)
+//   P5[y][x]  = max(R5[y .. y+4][x])                              on (H+8) x (W+8)
+//   P9[y][x]  = max(P5[y][x], P5[y+4][x], P5[y][x+4], P5[y+4][x+4])   on (H+4) x (W+4)   ([y,y+9) = [y,y+5) u [y+4,y+9))
+//   P13[y][x] = max of the same four taps of P9                   on H x W
+// 4 + 4 + 3 + 3 = 14 LDS reads per output vector instead of 25 + 81 + 169 global loads, and each result goes
+// straight into its channel slice of the concat buffer (out pointers / pixel stride of the three ops).
+namespace {
+
+struct SppArgs {
+  const char *in;
+  char *out5, *out9, *out13;
+  int H, W, in_ld, ld5, ld9, ld13, cgroups;
+};
+
+template <typename T>
+__device__ __forceinline__ u32x4 vmax16(const u32x4 &a, const u32x4 &b) {
+  if constexpr (sizeof(T) == 4) {
+    const f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b);
+    return __builtin_bit_cast(u32x4, f32x4{fmaxf(x[0], y[0]), fmaxf(x[1], y[1]), fmaxf(x[2], y[2]), fmaxf(x[3], y[3])});
+  } else {
+    const bf16x8 x = __builtin_bit_cast(bf16x8, a), y = __builtin_bit_cast(bf16x8, b);
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (float)x[j] >= (float)y[j] ? x[j] : y[j];
+    return __builtin_bit_cast(u32x4, r);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_spp_kernel(SppArgs p) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 spp_lds[];
+  constexpr int ES = sizeof(T), V = 2;                 // 16-byte vectors per position
+  const int PH = p.H + 12, PW = p.W + 12;
+  const int b = blockIdx.x / p.cgroups, cg = blockIdx.x - b * p.cgroups;
+  u32x4 *A = spp_lds, *Bf = spp_lds + PH * PW * V;
+  const int tid = threadIdx.x;
+  const long long frame = (long long)b * p.H * p.W;
+  const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
+  // 1. stage the zero-padded image
+  for (int idx = tid; idx < PH * PW * V; idx += 256) {
+    const int pos = idx >> 1, v = idx & 1, y = pos / PW, x = pos - y * PW;
+    A[idx] = (y < p.H && x < p.W)
+                 ? *reinterpret_cast<const u32x4 *>(p.in + ((frame + y * p.W + x) * p.in_ld) * ES + cg * 32 + v * 16)
+                 : zero;
+  }
+  __syncthreads();
+  // 2. row pass of the 5 x 5 pool
+  const int W5 = PW - 4, H5 = PH - 4;
+  for (int idx = tid; idx < PH * W5 * V; idx += 256) {
+    const int pos = idx >> 1, v = idx & 1, y = pos / W5, x = pos - y * W5;
+    const u32x4 *a = A + (y * PW + x) * V + v;
+    u32x4 m = vmax16<T>(a[0], a[V]);
+    m = vmax16<T>(m, a[2 * V]);
+    m = vmax16<T>(m, a[3 * V]);
+    Bf[(y * PW + x) * V + v] = vmax16<T>(m, a[4 * V]);
+  }
+  __syncthreads();
+  // 3. column pass -> P5 on (H+8) x (W+8), kept in A; the H x W part is the 5 x 5 pool's output
+  for (int idx = tid; idx < H5 * W5 * V; idx += 256) {
+    const int pos = idx >> 1, v = idx & 1, y = pos / W5, x = pos - y * W5;
+    const u32x4 *r = Bf + (y * PW + x) * V + v;
+    u32x4 m = vmax16<T>(r[0], r[PW * V]);
+    m = vmax16<T>(m, r[2 * PW * V]);
+    m = vmax16<T>(m, r[3 * PW * V]);
+    m = vmax16<T>(m, r[4 * PW * V]);
+    A[(y * PW + x) * V + v] = m;
+    if (y < p.H && x < p.W)
+      *reinterpret_cast<u32x4 *>(p.out5 + ((frame + y * p.W + x) * p.ld5) * ES + cg * 32 + v * 16) = m;
+  }
+  __syncthreads();
+  // 4. P9 on (H+4) x (W+4) from four taps of P5, kept in Bf
+  const int W9 = PW - 8, H9 = PH - 8;
+  for (int idx = tid; idx < H9 * W9 * V; idx += 256) {
+    const int pos = idx >> 1, v = idx & 1, y = pos / W9, x = pos - y * W9;
+    const u32x4 *a = A + (y * PW + x) * V + v;
+    const u32x4 m = vmax16<T>(vmax16<T>(a[0], a[4 * V]), vmax16<T>(a[4 * PW * V], a[(4 * PW + 4) * V]));
+    Bf[(y * PW + x) * V + v] = m;
+    if (y < p.H && x < p.W)
+      *reinterpret_cast<u32x4 *>(p.out9 + ((frame + y * p.W + x) * p.ld9) * ES + cg * 32 + v * 16) = m;
+  }
+  __syncthreads();
+  // 5. P13 on H x W from four taps of P9
+  for (int idx = tid; idx < p.H * p.W * V; idx += 256) {
+    const int pos = idx >> 1, v = idx & 1, y = pos / p.W, x = pos - y * p.W;
+    const u32x4 *a = Bf + (y * PW + x) * V + v;
+    const u32x4 m = vmax16<T>(vmax16<T>(a[0], a[4 * V]), vmax16<T>(a[4 * PW * V], a[(4 * PW + 4) * V]));
+    *reinterpret_cast<u32x4 *>(p.out13 + ((frame + y * p.W + x) * p.ld13) * ES + cg * 32 + v * 16) = m;
+  }
+}
+
+size_t spp_lds_bytes(const y3_op &op) { return (size_t)(op.in_h + 12) * (op.in_w + 12) * 2 * 16 * 2; }
+
+}  // namespace
+
+// ops[0..2]: three consecutive max-pool ops of a plan.  True when they form the SPP pyramid this kernel computes:
+// sizes {5, 9, 13} in any order, stride 1, the same input view, 32-byte channel groups, and the image fits LDS.
+bool y3_maxpool_spp_supported(const y3_op &a, const y3_op &b, const y3_op &c) {
+  const y3_op *o[3] = {&a, &b, &c};
+  int seen = 0;
+  for (const y3_op *q : o) {
+    if (q->kind != Y3_OP_MAXPOOL || q->stride != 1) return false;
+    if (q->ksize == 5) seen |= 1; else if (q->ksize == 9) seen |= 2; else if (q->ksize == 13) seen |= 4; else return false;
+    if (q->d_in != a.d_in || q->in_ld != a.in_ld || q->in_h != a.in_h || q->in_w != a.in_w || q->in_c != a.in_c ||
+        q->batch != a.batch || q->dtype != a.dtype || (q->flags & Y3_F_PLAN_INPUT))
+      return false;
+    const int es = y3_elem_size(q->dtype), vec = 16 / es;
+    if (q->in_c % (2 * vec) || q->in_ld % vec || q->out_ld % vec || ((uintptr_t)q->d_in % 16) || ((uintptr_t)q->d_out % 16))
+      return false;
+    if (q->out_h != q->in_h || q->out_w != q->in_w || q->out_c != q->in_c) return false;
+  }
+  return seen == 7 && spp_lds_bytes(a) <= 64 * 1024;
+}
+
+int y3_launch_maxpool_spp(const y3_op &a, const y3_op &b, const y3_op &c, hipStream_t s, const char **kernel_name,
+                          bool dry_run) {
+  *kernel_name = a.dtype == Y3_BF16 ? "maxpool_spp_pyramid_bf16" : "maxpool_spp_pyramid_f32";
+  if (dry_run) return Y3_OK;
+  const y3_op *o[3] = {&a, &b, &c};
+  SppArgs p;
+  p.in = static_cast<const char *>(a.d_in);
+  p.H = a.in_h; p.W = a.in_w; p.in_ld = a.in_ld;
+  p.cgroups = a.in_c * y3_elem_size(a.dtype) / 32;
+  for (const y3_op *q : o) {
+    if (q->ksize == 5) { p.out5 = static_cast<char *>(q->d_out); p.ld5 = q->out_ld; }
+    else if (q->ksize == 9) { p.out9 = static_cast<char *>(q->d_out); p.ld9 = q->out_ld; }
+    else { p.out13 = static_cast<char *>(q->d_out); p.ld13 = q->out_ld; }
+  }
+  const size_t lds = spp_lds_bytes(a);
+  const dim3 grid((unsigned)(a.batch * p.cgroups)), block(256);
+  if (a.dtype == Y3_BF16) hipLaunchKernelGGL((maxpool_spp_kernel<bf16_t>), grid, block, lds, s, p);
+  else hipLaunchKernelGGL((maxpool_spp_kernel<float>), grid, block, lds, s, p);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Frame resize on device: uint8 HxWx3 -> net_h x net_w x 3, OpenCV's 8-bit INTER_LINEAR
+// arithmetic.  Replaces the host `cv2.resize(image, (net_h, net_w))` of /root/reference/yolov3/inference.py:320-326
+// for frames that are not net-sized.  Integer arithmetic only, identical to yolov3/preprocess.py:
+// resize_bilinear_u8 (the tap tables -- lo index, hi index, 11-bit weights per output row / column, OpenCV's
+// xofs / ialpha / yofs / ibeta -- are computed once on the host and passed in: host and device are bit-identical).
 namespace {
 __global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t *src, int sh, int sw, uint8_t *dst, int dh,
                                                         int dw, const int *ytab, const int *xtab) {
@@ -229,9 +372,10 @@ __global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t *src, int 
   const uint8_t *r0 = src + (long long)ylo * sw * 3, *r1 = src + (long long)yhi * sw * 3;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
+    // OpenCV's two truncating stages (resize.cpp: HResizeLinear to int, then VResizeLinear<uchar, int, short, ...>)
     const int top = r0[xlo * 3 + c] * wx0 + r0[xhi * 3 + c] * wx1;
     const int bot = r1[xlo * 3 + c] * wx0 + r1[xhi * 3 + c] * wx1;
-    int v = (top * wy0 + bot * wy1 + (1 << 21)) >> 22;
+    int v = (((wy0 * (top >> 4)) >> 16) + ((wy1 * (bot >> 4)) >> 16) + 2) >> 2;
     v = v < 0 ? 0 : (v > 255 ? 255 : v);
     dst[(long long)idx * 3 + c] = (uint8_t)v;
   }

@@ -43,6 +43,14 @@ class Y3Op(ctypes.Structure):
     ]
 
 
+class Y3Options(ctypes.Structure):
+    """Mirror of ``struct y3_options`` (include/yolov3_hip.h): kernel-selection options of one plan."""
+    _fields_ = [(name, ctypes.c_int32) for name in (
+        "auto_mask", "halo_persistent", "igemm_version", "igemm_ns", "igemm_bm", "use_graph", "fuse_stem", "fuse_head",
+        "fuse_spp", "decode_lanes")] + [("reserved", ctypes.c_int32 * 6)]
+
+
+ABI_VERSION = 2
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/yolov3_hip.h declares
@@ -52,6 +60,9 @@ PROTOTYPES = {
     "y3_device_count": (ctypes.c_int, []),
     "y3_plan_create": (ctypes.c_int, [ctypes.POINTER(Y3Op), ctypes.c_int, ctypes.c_void_p,
                                       ctypes.POINTER(ctypes.c_void_p)]),
+    "y3_plan_create_ex": (ctypes.c_int, [ctypes.POINTER(Y3Op), ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(Y3Options),
+                                         ctypes.POINTER(ctypes.c_void_p)]),
+    "y3_options_default": (None, [ctypes.POINTER(Y3Options)]),
     "y3_plan_destroy": (None, [ctypes.c_void_p]),
     "y3_plan_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "y3_plan_run_timed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -104,10 +115,22 @@ def lib():
         fn = getattr(handle, name)
         fn.restype = restype
         fn.argtypes = argtypes
-    if handle.y3_abi_version() != 1:
-        raise HipLibraryError("libyolov3_hip.so ABI version {} != 1".format(handle.y3_abi_version()))
+    if handle.y3_abi_version() != ABI_VERSION:
+        raise HipLibraryError("libyolov3_hip.so ABI version {} != {} (rebuild: make -C pytorch-yolov3_amd/csrc)".format(
+            handle.y3_abi_version(), ABI_VERSION))
     _lib = handle
     return _lib
+
+
+def options(**overrides):
+    """The library's default plan options (as modified by ``y3_set_tuning``) with ``overrides`` applied."""
+    opt = Y3Options()
+    lib().y3_options_default(ctypes.byref(opt))
+    for key, val in overrides.items():
+        if key not in dict(Y3Options._fields_) or key == "reserved":
+            raise KeyError("unknown plan option {!r}".format(key))
+        setattr(opt, key, int(val))
+    return opt
 
 
 def check(rc):

@@ -71,7 +71,7 @@ class _CompiledPlan(object):
 
 
 class Darknet(object):
-    def __init__(self, config_fpath, device="cuda", dtype="float32", keep_all=False, fuse=None):
+    def __init__(self, config_fpath, device="cuda", dtype="float32", keep_all=False, fuse=None, options=None):
         """
         Args:
             config_fpath (str): Darknet .cfg file.
@@ -88,6 +88,9 @@ class Darknet(object):
         # conv-pair fusion (stem + stride-2 conv, residual blocks): default on, off with keep_all unless asked for
         # (then the tensor between a fused pair is never written and block_output() of it is meaningless)
         self.fuse = (not self.keep_all) if fuse is None else bool(fuse)
+        # kernel-selection options of this network's plans (include/yolov3_hip.h: y3_options), e.g.
+        # {"auto_mask": 0}; None = the library's defaults at the time a plan is compiled
+        self.options = dict(options) if options else None
         self.device = device
         self.header = None
         self.training = False
@@ -296,7 +299,7 @@ class Darknet(object):
                 # provisional padded sizes so that y3_conv_path can judge the shape
                 op.cout_pad = _round_up(c["cout"], 128)
                 op.k_ld = _round_up(c["k"] * c["k"] * c["cin"], 128 // es)
-                path = lib.y3_conv_path(ctypes.byref(op))
+                path = lib.y3_conv_path(ctypes.byref(op))     # (does not depend on the plan options)
                 wts = self._device_weights(od["slot"], path, bf16, dev)
                 op.cout_pad, op.k_ld = wts["cout_pad"], wts["k_ld"]
                 op.d_weight = wts["weight"].data_ptr()
@@ -339,7 +342,9 @@ class Darknet(object):
                 ops[n].d_bbox, ops[n].d_prob, ops[n].d_cls = (
                     cp.bbox.data_ptr(), cp.prob.data_ptr(), cp.cls.data_ptr())
         handle = ctypes.c_void_p()
-        _hip.check(lib.y3_plan_create(ops, cp.n_ops, self._zero.data_ptr(), ctypes.byref(handle)))
+        opt = _hip.options(**self.options) if self.options else None
+        _hip.check(lib.y3_plan_create_ex(ops, cp.n_ops, self._zero.data_ptr(),
+                                         ctypes.byref(opt) if opt is not None else None, ctypes.byref(handle)))
         cp.handle = handle
         return cp
 

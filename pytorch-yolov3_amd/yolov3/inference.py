@@ -52,8 +52,13 @@ def non_max_suppression(bbox_tlbr, class_prob, class_idx=None, iou_thresh=0.3):
     """Greedy NMS; per class when ``class_idx`` is given.  Returns a list of kept indices.
 
     Same decision rule as the reference (areas with +1, IoU in float64, suppress iff
-    IoU > iou_thresh, highest score first).
+    IoU > iou_thresh, highest score first).  ``bbox_tlbr`` must hold INTEGER pixel corners, which is what
+    ``inference()`` feeds it (inference.py:353-355): the device kernel works on int64 boxes, and float or
+    normalised boxes would be truncated silently, so they are rejected (``cxywh_to_tlbr`` does the same).
     """
+    if np.asarray(bbox_tlbr).size and not np.issubdtype(np.asarray(bbox_tlbr).dtype, np.integer):
+        raise TypeError("non_max_suppression works on integer pixel boxes (got dtype {}); convert with "
+                        ".astype(int) as the reference's inference() does".format(np.asarray(bbox_tlbr).dtype))
     boxes = np.ascontiguousarray(np.asarray(bbox_tlbr)[:, :4] if np.asarray(bbox_tlbr).size else
                                  np.zeros((0, 4)), dtype=np.int64)
     prob = np.ascontiguousarray(class_prob, dtype=np.float32)
@@ -97,6 +102,7 @@ class Detector(object):
         self.cls = torch.empty((batch, rows), dtype=torch.int64, device=device)
         self.row = torch.empty((batch, rows), dtype=torch.int32, device=device)
         self.orig_hw = torch.empty((batch, 2), dtype=torch.int32, device=device)
+        self._records = {}      # kmax -> (batch, kmax, 8) int32 staging buffer of fetch()
 
     def run(self, out, orig_hw, prob_thresh, iou_thresh):
         """out: Darknet.forward dict (device tensors).  orig_hw: (batch,2) int32 tensor/array."""
@@ -115,15 +121,29 @@ class Detector(object):
             self.count.data_ptr(), self.tlbr.data_ptr(), self.prob.data_ptr(), self.cls.data_ptr(),
             self.row.data_ptr(), _hip.stream_ptr()))
 
-    def fetch(self, return_rows=False):
-        counts = self.count.cpu().numpy()
+    def fetch(self, return_rows=False, kmax=1024):
+        """Detections of the last ``run`` on the host: ONE device-to-host copy per batch.  The device packs every
+        frame's first ``kmax`` detections into fixed-size records that also carry the frame's true count
+        (``y3_pack_records``, the multi-GPU gather's format); only if some frame kept more than ``kmax`` boxes is a
+        second, larger copy made."""
+        from .dist import unpack_records
+        lib = _hip.lib()
+        kmax = max(1, min(int(kmax), self.rows))
+        while True:
+            rec = self._records.get(kmax)
+            if rec is None:
+                rec = self._records[kmax] = torch.empty((self.batch, kmax, 8), dtype=torch.int32, device=self.device)
+            _hip.check(lib.y3_pack_records(self.count.data_ptr(), self.tlbr.data_ptr(), self.prob.data_ptr(),
+                                           self.cls.data_ptr(), self.row.data_ptr(), self.batch, self.rows, kmax,
+                                           rec.data_ptr(), None, _hip.stream_ptr()))
+            host = rec.cpu().numpy()                         # the one synchronising copy
+            most = int(host[:, 0, 7].max()) if host.size else 0
+            if most <= kmax:
+                break
+            kmax = min(self.rows, max(most, 2 * kmax))
         results = []
-        for b in range(self.batch):
-            k = int(counts[b])
-            item = [self.tlbr[b, :k].cpu().numpy(), self.prob[b, :k].cpu().numpy(), self.cls[b, :k].cpu().numpy()]
-            if return_rows:
-                item.append(self.row[b, :k].cpu().numpy().astype(np.int64))
-            results.append(item)
+        for item in unpack_records(host):
+            results.append(item[:4] if return_rows else item[:3])
         return results
 
 

@@ -242,9 +242,13 @@ def to_coco(image_filenames, inference_output, class_names):
 
 
 def unique_colors(num_colors):
-    """``num_colors`` evenly spaced hues as 0..255 colour tuples (reference: devtools/coco_util.py:153-157)."""
-    return [tuple(int(255 * c) for c in colorsys.hsv_to_rgb(h, 1.0, 1.0))
-            for h in np.linspace(0, 1, num_colors, endpoint=False)]
+    """``num_colors`` evenly spaced hues as 8-bit BGR tuples, the channel order of the frames they are drawn into
+    (reference: inference.py:80-93)."""
+    colors = []
+    for h in np.linspace(0, 1, num_colors, endpoint=False):
+        r, g, b = colorsys.hsv_to_rgb(h, 1.0, 1.0)
+        colors.append((int(255 * b), int(255 * g), int(255 * r)))
+    return colors
 
 
 def _rect(img, x1, y1, x2, y2, color, thickness):

@@ -119,7 +119,7 @@ def test_inference_golden_tiny(tmp_path):
         res = orc.postprocess(out["bbox_xywh"].numpy(), out["class_prob"].numpy(), out["class_idx"].numpy(),
                               [f.shape for f in frames], float(pth), float(ith), audit=True)
         for f in range(len(frames)):
-            ndiff, nbad = compare_detections(g, "%s_f%d_" % (tag, f), res[f][:3], rows=res[f][3])
+            ndiff, nbad, _ = compare_detections(g, "%s_f%d_" % (tag, f), res[f][:3], rows=res[f][3])
             assert ndiff == 0 and nbad == 0        # same machine, same libraries as the golden run: exact
             # the audit the oracle computes is the one stored with the goldens
             assert np.array_equal(res[f][4], g["%s_f%d_cand_rows" % (tag, f)])

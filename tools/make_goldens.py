@@ -11,7 +11,7 @@ read-only through tools/refshim.py (cv2 stub + np.int alias) and is fed
   ``load_weights``), because real checkpoints need network access;
 * frames that tests can rebuild bit-exactly: JPEGs kept under
   tests/golden/images (decoded with PIL) and procedural scenes
-  (yolov3/synthdata.py).  ``cv2.resize`` is replaced by this build's
+  (yolov3/synthdata.py).  ``cv2.resize`` (absent here) is replaced by this build's restatement of OpenCV's 8-bit INTER_LINEAR,
   ``resize_bilinear_u8`` so that non-net-sized frames can go through the
   reference's ``inference()``; both sides then see the same resized pixels.
 
@@ -277,6 +277,8 @@ def g7_inference(model, net):
             arrays[key + "rows"] = cand[keep].astype(np.int64)      # row index into the M predictions
             arrays[key + "cand_rows"] = cand.astype(np.int64)
             arrays[key + "cand_fragile"] = fragile
+            arrays[key + "cand_tlbr"] = ti.astype(np.int64)         # every candidate's truncated pixel box (pre-NMS)
+            arrays[key + "cand_cls"] = ci[f, cand].astype(np.int64)
             print("G7", model, tag, "frame", f, "cand", len(cand), "kept", len(keep),
                   "fragile", int(fragile.sum()), "classes", len(set(cls.tolist())))
         arrays[tag + "_thresholds"] = np.array([pth, ith])
