@@ -276,5 +276,8 @@ def test_bf16_post_nms_agreement_vs_reference(model):
             else:           # a handful of detections: count rows instead of a ratio
                 ideal_xor = round((1.0 - fl["jaccard"]) * max(fl["kept"], fl["ref_kept"]) * 2)
                 assert nxor <= ideal_xor + 3
-            assert np.median(dp) <= 2.0 * fl["score_med"] + 1e-3 and np.percentile(dp, 99) <= 2.0 * fl["score_p99"] + 5e-3
+            if len(dp) >= 20:
+                assert np.median(dp) <= 2.0 * fl["score_med"] + 1e-3 and np.percentile(dp, 99) <= 2.0 * fl["score_p99"] + 5e-3
+            else:           # a handful of scores: no percentiles, the bf16 score error as such (p99 ~ 2e-2 on these networks)
+                assert dp.max() <= 3e-2
             assert cls_same >= 0.99
