@@ -20,7 +20,8 @@ thread_local char g_err[512] = "";
 // bit 3: wave-specialised igemm for 1x1 layers with Cin >= 1024; bit 4: halo kernel for rows of 33..64 instead;
 // bit 5: wave-specialised igemm for rows <= 32 instead; bit 7: 2-D patch kernel (8 x 32 output tiles) for 3x3 stride-1
 // layers with rows wider than 128 px; bit 6: wave-specialised igemm with 64-pixel tiles (3 stages, two workgroups per CU)
-// for bf16 1x1 layers with Cin >= 256.  157 = measured best end to end (profiles/r01_ab_kernel_selection.txt).
+// for bf16 1x1 layers with Cin >= 256; bit 8: the two-workgroups-per-CU halo kernel (128 x 128 tiles) wherever it fits
+// (rows of up to 62 px).  157 = measured best end to end (profiles/r01_ab_kernel_selection.txt).
 static y3_options g_y3_defaults = {/*auto_mask*/ 157, /*halo_persistent*/ 0, /*igemm_version*/ 2, /*igemm_ns*/ 2,
                                    /*igemm_bm*/ 0, /*use_graph*/ 0, /*fuse_stem*/ 1, /*fuse_head*/ 1, /*fuse_spp*/ 1,
                                    /*decode_lanes*/ 4, {0, 0, 0, 0, 0, 0}};
@@ -100,6 +101,7 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
               return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3, 64);
             if ((am & 128) && op.ksize == 3 && op.stride == 1 && w > 128 && op.out_c >= 128 && y3_conv_patch_fits(op))
               return y3_launch_conv_patch(op, in, d_zero, s, name, dry_run);
+            if ((am & 256) && k3 && y3_conv_halo2_fits(op)) return y3_launch_conv_halo2(op, in, d_zero, s, name, dry_run);
             if (want_halo && halo_ok) return y3_launch_conv_halo(op, in, d_zero, s, name, dry_run, y3_opt().halo_persistent != 0);
             if (want_ws) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
           }

@@ -26,6 +26,8 @@
 // -- every wave loading and computing in lock step, ping-pong wave groups, 32-channel chunks with a
 // deeper ring -- measured 5-25 % slower (profiles/r01_convbench_v2_vs_halo.txt,
 // profiles/r01_convbench_variants.txt) and were removed.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -1010,6 +1012,332 @@ __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two workgroups per CU (conv_halo2_kernel): BM = 128 pixels x BN = 128 channels, 4 MFMA waves (wave tile 64 x 64, one
+// per SIMD) + 2 loader waves = 384 threads, at most 80 KiB of LDS, <= 168 VGPRs -- so TWO such workgroups are resident
+// per CU and each SIMD holds one MFMA wave of either.  Why: stamps on the one-workgroup kernel above show a third of a
+// tile's cycles at 76^2 (a fifth at 38^2) outside the K loop (first operands in flight, epilogue) with the matrix pipe
+// idle, 23 % of the loop itself in barrier / LDS-read bubbles, and whole CUs idle in the last round of tiles (364 tiles
+// on 256 CUs at 38^2, 184 at 19^2).  With two independent workgroups on a CU one's prologue, barrier waits, chunk
+// changes and epilogue run under the other's MFMAs, and twice as many, half as big tiles fill the last round.
+// To fit 80 KiB the halo image is SINGLE-buffered: at a chunk boundary the MFMA waves announce "all halo reads done"
+// (barrier E), the loaders stream the next chunk's 128 + 2W + 2 rows in one go and the K loop resumes at the next
+// step's barrier -- a bubble of one halo load per nine K-steps that the sibling workgroup fills.  Weight ring: 3 slots
+// -- one being read, two in flight (a tile has two K-steps to land); the halo fragments of step it+1's first half are
+// read in step it's MFMA gaps, its weight fragments right after barrier B(it+1).  Border taps: all-zero halo row `hr`, as above.  Rows of up to 62 pixels (3 x 16 KiB + (131 + 2W rows) x 128 B
+// <= 80 KiB): the 38^2 and 19^2 stages of Darknet-53 at 608, all of its 3x3 layers with Cin >= 128 at 416 and below.
+template <typename T, int NSB>
+__global__ __launch_bounds__(384, 3) void conv_halo2_kernel(HaloArgs p) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int WAVES_N = 2;
+  constexpr int NC = 256, NL = 128;                   // consumer / loader threads
+  constexpr int ES = sizeof(T);
+  constexpr int BKE = 128 / ES;
+  constexpr int RPL = NL / 8;                         // rows filled per loader pass (16)
+  constexpr int NBL = BN / RPL / 2;                   // weight-tile passes per loader thread: rows 0..63 (4); the MFMA
+                                                      // waves issue rows 64..127 themselves, CPC pieces of 8 rows each
+  constexpr int CPC = 2;
+  constexpr int B_BYTES = BN * 128;
+  constexpr int MI = 4, NI = 4;
+  static_assert(NSB == 3, "weight ring: weights(it) landed at B(it), it+1 in flight, slot of weights(it-1) refilled after B(it)");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *sB = smem;                                    // [NSB][BN][128]
+  char *sA = smem + NSB * B_BYTES;                    // [hr_pad][128], one buffer
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= NC / 64;
+
+  // Tile order.  Each XCD gets one contiguous run of tile ids (y3_xcd_remap).  n-major: a run walks the pixel tiles of
+  // ONE 128-channel weight panel (1.2 MB at 19^2, 0.6 MB at 38^2), which then stays in that XCD's 4 MiB L2 while the
+  // activations stream past; m-major: a run shares the halo and cycles through all weight panels (9.4 MB at 19^2).
+  const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
+  const int m_tiles = gridDim.x / p.n_tiles;
+  const int m0 = (p.hr_pad & 1 ? tile % m_tiles : tile / p.n_tiles) * BM;
+  const int n0 = (p.hr_pad & 1 ? tile / m_tiles : tile % p.n_tiles) * BN;
+  const int nit = p.nchunks * 9;
+
+  const int wm = (wave & 3) / WAVES_N, wn = (wave & 3) % WAVES_N;
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (loader) {
+    // ---------------- loader waves ----------------
+    __builtin_amdgcn_s_setprio(3);                    // youngest waves: they must win issue arbitration for their few instructions
+    const int ltid = tid - NC;
+    const int lwave = wave - NC / 64;
+    const int slot = ltid & 7;
+    const int row0 = ltid >> 3;
+    const int kc = slot ^ (row0 & 7);
+    const long long q0 = (long long)m0 - p.W - 1;     // flattened input pixel of halo row 0
+    auto issue_halo = [&](int chunk) {
+      for (int pass = 0; pass < p.na; ++pass) {
+        const int row = row0 + pass * RPL;
+        const long long q = q0 + row;
+        const bool ok = row < p.hr && q >= 0 && q < p.M;    // rows >= hr stay zero: row hr is the consumers' zero row
+        const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
+        char *dst = sA + pass * (NL * 16) + lwave * 1024;
+        __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
+      }
+    };
+    const char *b_src[NBL];
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) b_src[i] = p.wgt + ((long long)(n0 + row0 + i * RPL) * p.k_ld) * ES + kc * 16;
+    auto issue_weights = [&](int it, int ring_slot) {  // it = chunk*9 + tap; K offset = tap*Cin + chunk*BKE elements
+      const int chunk = it / 9, tap = it - chunk * 9;
+      const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
+      char *dst = sB + ring_slot * B_BYTES + lwave * 1024;
+#pragma unroll
+      for (int i = 0; i < NBL; ++i)
+        __builtin_amdgcn_global_load_lds((gbl_void *)(b_src[i] + koff), (lds_void *)(dst + i * (NL * 16)), 16, 0, 0);
+    };
+    issue_weights(0, 0);                              // weights first: the halo is the bigger transfer
+    issue_halo(0);
+    issue_weights(1 < nit ? 1 : nit - 1, 1);
+    int tap = 0, chunk = 0, ring = 2;
+#pragma unroll 1
+    for (int it = 0; it < nit; ++it) {
+      // B(it) promises the MFMA waves weights(it) (and, at a chunk start, the halo).  weights(it+1) -- the youngest tile,
+      // issued a K-step ago -- stays in flight across the barrier: with three slots (it being read, it+1 and it+2 in
+      // flight) a tile has TWO K-steps to land.  (The first version made weights(it+1) land by B(it), to let the MFMA
+      // waves pre-read the next step's fragments: one K-step of 512 MFMA cycles to issue 16 KiB from two waves and get
+      // it back from L2 / MALL was not enough, every barrier waited on the memory system: 630-720 TF.)
+      if (tap == 0) wait_vmcnt<0>(); else wait_vmcnt_n<NBL>();
+      __builtin_amdgcn_s_barrier();                   // B(it): also releases the slot of weights(it-1)
+      issue_weights(it + 2 < nit ? it + 2 : nit - 1, ring);
+      ring = ring + 1 == NSB ? 0 : ring + 1;
+      if (tap == 8) {
+        if (chunk + 1 < p.nchunks) {
+          __builtin_amdgcn_s_barrier();               // E(chunk): every fragment of this chunk's halo has been read
+          issue_halo(chunk + 1);
+        }
+        tap = 0;
+        ++chunk;
+      } else {
+        ++tap;
+      }
+    }
+    wait_vmcnt<0>();                                  // the tail's dummy loads must not land on the output tile
+  } else {
+    // ---------------- consumer waves (one per SIMD) ----------------
+    uint32_t tapmask[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const uint32_t m = (uint32_t)(m0 + wm * 64 + mi * 16 + fr);
+      uint32_t mask = 0u;
+      if (m < (uint32_t)p.M) {
+        const uint32_t img = (__umulhi(m, p.mul_hw) + m) >> p.sh_hw;
+        const uint32_t rem = m - img * (uint32_t)p.HW;
+        const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
+        const uint32_t ox = rem - oy * (uint32_t)p.W;
+        const uint32_t vx = (ox >= 1u ? 1u : 0u) | 2u | (ox + 1u < (uint32_t)p.W ? 4u : 0u);
+        mask = (oy >= 1u ? vx : 0u) | (vx << 3) | (oy + 1u < (uint32_t)p.H ? vx << 6 : 0u);
+      }
+      tapmask[mi] = mask;
+    }
+    const int a_lane_row = wm * 64 + fr;
+    const int b_lane_row = wn * 64 + fr;
+    const int b_off0 = b_lane_row * 128 + (((0 + fq) ^ (b_lane_row & 7)) << 4);
+    const int b_off1 = b_lane_row * 128 + (((4 + fq) ^ (b_lane_row & 7)) << 4);
+    typedef const __attribute__((address_space(3))) u32x4 lds_u32x4;
+    const int sA_lds = (int)(size_t)(lds_void *)sA;
+    int zalt[MI], sel[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      zalt[mi] = sA_lds + p.hr * 128 - mi * 2048;
+      asm volatile("" : "+v"(zalt[mi]));
+    }
+    auto read_x0 = [&](u32x4 (&xf)[MI], int a_shift, int tap) {          // halo fragments, K-half 0
+      const int r0 = a_lane_row + a_shift;
+      const int ap = ((r0 << 7) + sA_lds) + ((fq ^ (r0 & 7)) << 4);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        int off = ((tapmask[mi] >> tap) & 1u) ? ap : zalt[mi];
+        asm volatile("" : "+v"(off));
+        sel[mi] = off;
+        xf[mi] = *reinterpret_cast<lds_u32x4 *>(off + mi * 2048);
+      }
+    };
+    auto read_w0 = [&](u32x4 (&wf)[NI], const char *bBuf) {                 // weight fragments, K-half 0
+      const char *bp = bBuf + b_off0;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
+    };
+    auto read_frags1 = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], const char *bBuf) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        int off = sel[mi] ^ 64;
+        asm volatile("" : "+v"(off));
+        xf[mi] = *reinterpret_cast<lds_u32x4 *>(off + mi * 2048);
+      }
+      const char *bp = bBuf + b_off1;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
+    };
+    auto mma_all = [&](const u32x4 (&xf)[MI], const u32x4 (&wf)[NI]) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) MmaH<T>::run(acc[mi][ni], wf[ni], xf[mi]);
+    };
+    auto interleave = [&](int reads) {
+#pragma unroll
+      for (int i = 0; i < reads; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 2 : 8, 0);
+      }
+    };
+    // The MFMA waves carry half of the weight stream: two loader waves alone need ~130-190 cycles per 1 KiB LDS-DMA
+    // piece (issue arbitration against the MFMA waves of their SIMD), 16 + 2 pieces per K-step -- more than the
+    // 512 MFMA cycles of the step (measured: one workgroup alone 1200 cycles per K-step, two per CU 2400).  A piece
+    // issued here stalls this wave for a while, but the sibling workgroup's wave on the same SIMD keeps the matrix pipe
+    // busy.  Wave w owns rows 64 + 16 w .. + 15 of the tile (two pieces); same ring slot / K offset as the loaders.
+    const int crow = 64 + (wave & 3) * (CPC * 8) + (lane >> 3);
+    const char *cb_src[CPC];
+#pragma unroll
+    for (int j = 0; j < CPC; ++j)
+      cb_src[j] = p.wgt + ((long long)(n0 + crow + j * 8) * p.k_ld) * ES + (((lane & 7) ^ (lane >> 3)) << 4);
+    auto issue_my_weights = [&](int it, int ring_slot) {
+      const int chunk = it / 9, tap = it - chunk * 9;
+      const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
+      char *dst = sB + ring_slot * B_BYTES + (64 + (wave & 3) * (CPC * 8)) * 128;
+#pragma unroll
+      for (int j = 0; j < CPC; ++j)
+        __builtin_amdgcn_global_load_lds((gbl_void *)(cb_src[j] + koff), (lds_void *)(dst + j * 1024), 16, 0, 0);
+    };
+    issue_my_weights(0, 0);
+    issue_my_weights(1 < nit ? 1 : nit - 1, 1);
+    wait_vmcnt_n<CPC>();                              // my pieces of weights(0)
+    __builtin_amdgcn_s_barrier();                     // B(0): halo(0) and weights(0) are in LDS
+    u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
+    read_x0(xf0, 0, 0);
+    int tap = 0, chunk = 0, ring = 0;
+#pragma unroll 1
+    for (int it = 0; it < nit; ++it) {
+      if (it) {
+        wait_vmcnt_n<CPC>();                          // my pieces of weights(it) (those of it+1 stay in flight)
+        __builtin_amdgcn_s_barrier();                 // B(it): weights(it) landed; slot of weights(it-1) released
+        if (tap == 0) read_x0(xf0, 0, 0);             // chunk start: the new halo has only just landed
+      }
+      {
+        const int r2 = ring + 2 >= NSB ? ring + 2 - NSB : ring + 2;
+        issue_my_weights(it + 2 < nit ? it + 2 : nit - 1, r2);
+      }
+      // this step's first-half weight fragments can only be read now (their tile was still in flight during step it-1);
+      // the halo fragments of the first half were read in step it-1's MFMA gaps
+      read_w0(wf0, sB + ring * B_BYTES);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags1(xf1, wf1, sB + ring * B_BYTES);
+      mma_all(xf0, wf0);
+      interleave(MI + NI);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      const int tap_n = tap == 8 ? 0 : tap + 1;
+      {
+        // halo fragments of the next step's first half, in this half's MFMA gaps.  At the last tap of a chunk the read is
+        // void (the next chunk's image is not there yet) and is repeated after B(it+1); it stays unconditional so that
+        // the K loop has ONE MFMA site per half (a second copy of the 32 MFMAs in a branch made hipcc keep a second set
+        // of accumulators: 250 VGPRs)
+        const int ky_n = (tap_n * 11) >> 5, kx_n = tap_n - ky_n * 3;
+        read_x0(xf0, ky_n * p.W + kx_n, tap_n);
+      }
+      mma_all(xf1, wf1);
+      interleave(MI);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      if (tap == 8) {
+        // this chunk's halo is read out; the next chunk's arrives in the same buffer
+        if (chunk + 1 < p.nchunks) __builtin_amdgcn_s_barrier();   // E(chunk)
+        ++chunk;
+      }
+      tap = tap_n;
+      ring = ring + 1 == NSB ? 0 : ring + 1;
+    }
+    wait_vmcnt<0>();                                  // the tail's dummy pieces must not land on the output tile
+  }
+  // ---- epilogue (the 256 consumer threads write out; the loaders only keep the barrier count) ----
+  constexpr int SWZ = 15;
+  constexpr int OCT_PER_ROW = BN / 8;
+  constexpr int WR = BM * OCT_PER_ROW / NC;
+  float *sC = reinterpret_cast<float *>(smem);
+  const bool leaky = p.flags & Y3_F_LEAKY;
+  const bool has_res = p.flags & Y3_F_RESIDUAL;
+  const int oc_mine = tid & 15;
+  const int co = n0 + oc_mine * 8;
+  f32x4 sc_lo, sc_hi, bi_lo, bi_hi;
+  u32x4 resv[WR];
+  if (!loader) {
+    sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
+    sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+    bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
+    bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+    if (has_res) {
+#pragma unroll
+      for (int j = 0; j < WR; ++j) {
+        const int m = m0 + (tid >> 4) + j * (NC / 16);
+        const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
+        if constexpr (sizeof(T) == 2) {
+          resv[j] = m < p.M ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();   // all operand reads and all LDS-DMA done: LDS can hold the output tile
+  if (!loader) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int cl = wn * 64 + ni * 16 + fq * 4;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int pl = wm * 64 + mi * 16 + fr;
+        *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
+      }
+    }
+  }
+  __syncthreads();
+  if (loader) return;
+#pragma unroll
+  for (int j = 0; j < WR; ++j) {
+    const int pl = (tid >> 4) + j * (NC / 16);
+    const int m = m0 + pl;
+    if (m >= p.M) continue;
+    const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
+    const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
+    float v[8];
+    y3_bn_leaky8(v, lo, hi, sc_lo, sc_hi, bi_lo, bi_hi, leaky);
+    if (has_res) {
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[j]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+      } else {
+        const float *rp = reinterpret_cast<const float *>(p.res) + (long long)m * p.res_ld + co;
+        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(rp), r1 = *reinterpret_cast<const f32x4 *>(rp + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+      }
+    }
+    T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
+    if constexpr (sizeof(T) == 2) {
+      bf16x8 ov;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ov[r] = (bf16_t)v[r];
+      *reinterpret_cast<bf16x8 *>(op) = ov;
+    } else {
+      *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+}
+
 // n / d == (umulhi(n, mul) + n) >> sh for 0 <= n < 2^31 (round-up method, d >= 1)
 void fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
   if (d <= 1) { mul = 0; sh = 0; return; }
@@ -1050,6 +1378,41 @@ int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
   const dim3 grid(y3_ceil_div(a.M, 256) * a.n_tiles);
   if (nsb == 4) hipLaunchKernelGGL((conv_halo_ws_kernel<T, 4>), grid, dim3(768), lds, s, a);
   else hipLaunchKernelGGL((conv_halo_ws_kernel<T, 3>), grid, dim3(768), lds, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+constexpr int kHalo2Lds = 80 * 1024;   // two workgroups per CU
+
+template <typename T>
+int launch_halo2(const HaloArgs &a0, hipStream_t s) {
+  HaloArgs a = a0;
+  const int hr = 128 + 2 * a.W + 2;
+  a.hr = hr;
+  a.na = y3_ceil_div(hr + 1, 16);                     // + the zero row
+  a.hr_pad = a.na * 16;
+  a.a_bytes = a.hr_pad * 128;
+  size_t lds = (size_t)3 * 128 * 128 + (size_t)a.a_bytes;
+  if (lds < (size_t)128 * 128 * 4) lds = (size_t)128 * 128 * 4;    // the epilogue parks the float32 tile there
+  Y3_REQUIRE(lds <= (size_t)kHalo2Lds, "two-per-CU halo kernel: row width %d does not fit", a.W);
+  static Y3DeviceOnce once;
+  {
+    const int rc = once.run([]() -> int {
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo2_kernel<T, 3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      return Y3_OK;
+    });
+    if (rc != Y3_OK) return rc;
+  }
+  const dim3 grid(y3_ceil_div(a.M, 128) * a.n_tiles);
+  if (getenv("Y3_HALO2_LDS")) lds = (size_t)atoi(getenv("Y3_HALO2_LDS"));   // experiment: > 80 KiB forces one workgroup per CU
+  if (getenv("Y3_HALO2_NMAJOR")) a.hr_pad |= 1;         // experiment: hr_pad is a multiple of 16, bit 0 carries the tile order
+  if (getenv("Y3_DEBUG_OCC")) {
+    int nb = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_halo2_kernel<T, 3>, 384, lds);
+    fprintf(stderr, "conv_halo2: W=%d lds=%zu blocks/CU=%d grid=%u\n", a.W, lds, nb, grid.x);
+  }
+  hipLaunchKernelGGL((conv_halo2_kernel<T, 3>), grid, dim3(384), lds, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -1137,6 +1500,49 @@ bool y3_conv_halo_ws_fits(const y3_op &op) {
   if (!y3_conv_halo_eligible(op)) return false;
   const int na = y3_ceil_div(256 + 2 * op.in_w + 3, 32);
   return na <= 14 && (size_t)3 * 128 * 128 + (size_t)2 * na * 32 * 128 <= 160 * 1024;
+}
+
+// two-workgroups-per-CU halo kernel: 3 weight slots + ONE halo buffer of 131 + 2W rows (padded to 16) within 80 KiB;
+// one channel chunk is enough (the halo is not double-buffered)
+bool y3_conv_halo2_fits(const y3_op &op) {
+  const int es = y3_elem_size(op.dtype);
+  const int bke = 128 / es;
+  if (op.ksize != 3 || op.stride != 1 || op.pad != 1) return false;
+  if (op.flags & (Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR)) return false;
+  if (op.in_c % bke != 0 || op.out_c % 128 != 0 || op.out_ld % 8 != 0 || op.in_ld % (16 / es) != 0) return false;
+  if ((op.flags & Y3_F_RESIDUAL) && op.res_ld % 8 != 0) return false;
+  if (op.k_ld < 9 * op.in_c) return false;
+  const int na = y3_ceil_div(128 + 2 * op.in_w + 3, 16);
+  return (size_t)3 * 128 * 128 + (size_t)na * 16 * 128 <= (size_t)kHalo2Lds;
+}
+
+int y3_launch_conv_halo2(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
+                         const char **kernel_name, bool dry_run) {
+  const int es = y3_elem_size(op.dtype);
+  const bool bf = op.dtype == Y3_BF16;
+  Y3_REQUIRE(y3_conv_halo2_fits(op), "conv block %d: shape not supported by the two-per-CU halo kernel", op.block_idx);
+  *kernel_name = bf ? "conv_halo2_bf16_128x128" : "conv_halo2_f32_128x128";
+  if (dry_run) return Y3_OK;
+  HaloArgs a;
+  a.in = static_cast<const char *>(d_in);
+  a.wgt = static_cast<const char *>(op.d_weight);
+  a.scale = op.d_scale; a.bias = op.d_bias;
+  a.res = static_cast<const char *>(op.d_res);
+  a.out = static_cast<char *>(op.d_out);
+  a.zero = static_cast<const char *>(d_zero);
+  a.H = op.in_h; a.W = op.in_w; a.Cin = op.in_c; a.in_ld = op.in_ld;
+  a.Cout = op.out_c; a.out_ld = op.out_ld; a.res_ld = op.res_ld;
+  a.HW = op.in_h * op.in_w;
+  a.M = op.batch * a.HW;
+  a.k_ld = op.k_ld;
+  a.nchunks = op.in_c / (128 / es);
+  a.n_tiles = op.out_c / 128;
+  a.hr_pad = a.na = a.a_bytes = 0;
+  fast_div((uint32_t)a.HW, a.mul_hw, a.sh_hw);
+  fast_div((uint32_t)a.W, a.mul_w, a.sh_w);
+  a.flags = op.flags;
+  Y3_REQUIRE((long long)op.batch * a.HW < (1ll << 31), "conv block %d: too many pixels for the 32-bit tile index", op.block_idx);
+  return bf ? launch_halo2<bf16_t>(a, s) : launch_halo2<float>(a, s);
 }
 
 // 2-D patch kernel: same layer class, any number (>= 1) of channel chunks, any row width

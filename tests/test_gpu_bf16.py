@@ -85,8 +85,8 @@ def _close_bf16(got, want, what, slack=None):
     return frac
 
 
-def _teacher_forced(model, frames, expect_kernels=()):
-    net = _net(model, keep_all=True, fuse=True)
+def _teacher_forced(model, frames, expect_kernels=(), options=None):
+    net = _net(model, keep_all=True, fuse=True, options=options)
     out = net.forward_frames(frames)
     torch.cuda.synchronize()
     report = net.plan_report()
@@ -211,6 +211,18 @@ def test_bf16_every_block_teacher_forced(model, h, w, batch, kernels):
     checked, frac, names = _teacher_forced(model, frames, kernels)
     print("%s %dx%d b%d: %d blocks checked, worst mismatch share %.4f" % (model, h, w, batch, checked, frac))
     assert checked >= (20 if model == "yolov3-tiny" else 75)      # 107 blocks, 23 convs checked with their shortcut, 3 yolo
+
+
+@pytest.mark.parametrize("model,h,w,batch", [("yolov3", 608, 608, 1), ("yolov3", 416, 416, 2), ("yolov3", 352, 480, 3),
+                                             ("yolov3-spp", 320, 320, 2), ("yolov3-tiny", 416, 416, 2)])
+def test_bf16_every_block_teacher_forced_two_per_cu_halo_kernel(model, h, w, batch):
+    """The same per-block gate with the two-workgroups-per-CU halo kernel (128 x 128 tiles, single halo buffer) on every
+    3x3 layer it fits: rows of 19 / 38 px at 608, 13 / 26 / 52 at 416, 11..60 at 352 x 480 (strips that wrap rows and
+    frames, one to sixteen channel chunks)."""
+    frames = synth_frames(2000 + h + w + batch, batch, h, w)
+    checked, frac, names = _teacher_forced(model, frames, ("conv_halo2",), options={"auto_mask": 157 | 256})
+    print("%s %dx%d b%d: %d blocks checked, worst mismatch share %.4f, %d launches of conv_halo2" % (
+        model, h, w, batch, checked, frac, sum("conv_halo2" in k for k in names)))
 
 
 def _stats(a, b):

@@ -358,6 +358,21 @@ def test_halo_kernels_match_goldens_on_yolov3_fp32():
         lib.y3_set_tuning(b"auto_mask", DEFAULT_KNOBS["auto_mask"])
 
 
+@pytest.mark.parametrize("model", ["yolov3", "yolov3-spp", "yolov3-tiny"])
+def test_two_per_cu_halo_kernel_matches_goldens_fp32(model):
+    """conv_halo2 (128 x 128 tiles, two workgroups per CU) in float32 against the reference's forward goldens."""
+    g = np.load(os.path.join(GOLDEN, "forward_%s.npz" % model))
+    dim = MODEL_DIMS[model]
+    frames = np.stack([resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), dim, dim), synth_frames(5, 1, dim, dim)[0]])
+    net = _net(model, options={"auto_mask": 157 | 256})
+    out = net.forward(torch.from_numpy(orc.frames_to_input(list(frames))))
+    assert any("conv_halo2" in r["kernel"] for r in net.plan_report())
+    np.testing.assert_allclose(out["bbox_xywh"].cpu().numpy(), g["bbox_xywh"], rtol=1e-4, atol=BOX_ATOL)
+    np.testing.assert_allclose(out["class_prob"].cpu().numpy(), g["class_prob"], atol=SCORE_ATOL)
+    flips = (out["class_idx"].cpu().numpy() != g["class_idx"]) & (g["cls_margin"] >= 1e-4)
+    assert flips.sum() == 0
+
+
 @pytest.mark.parametrize("dim,dtype", [(672, "float32"), (672, "bf16"), (1024, "bf16")])
 def test_patch_kernel_edge_tiles_match_implicit_gemm(dim, dtype):
     """2-D patch kernel (8 x 32 output tiles) on maps that are not a multiple of the tile (672 -> 168 = 5.25 x 32 wide,

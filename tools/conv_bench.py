@@ -55,6 +55,7 @@ VARIANTS = [
     ("igemm_v3_ns4", dict(BASE, igemm_version=3, igemm_ns=4)),
     ("igemm_v3_bm64_ns4", dict(BASE, igemm_version=3, igemm_ns=4, igemm_bm=64)),
     ("igemm_v3_bm64_ns3", dict(BASE, igemm_version=3, igemm_ns=3, igemm_bm=64)),
+    ("halo2", dict(BASE, auto_mask=21 | 256)),
 ]
 
 
@@ -69,9 +70,13 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--variants", default=None, help="comma-separated variant names (default: all)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--stamps", action="store_true", help="library built with `make stamps`: print phase cycles")
     args = ap.parse_args()
+    global VARIANTS
+    if args.variants:
+        VARIANTS = [v for v in VARIANTS if v[0] in args.variants.split(",")]
     lib = _hip.lib()
     _hip.require_gpu()
     dev = torch.device("cuda:0")
@@ -82,7 +87,7 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(0)
     results = []
     for name, h, cin, cout, k, s, res, f32out in LAYERS:
-        if args.only and args.only not in name:
+        if args.only and not any(o in name for o in args.only.split(",")):
             continue
         pad = (k - 1) // 2
         ho = (h + 2 * pad - k) // s + 1
