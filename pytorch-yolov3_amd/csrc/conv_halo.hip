@@ -1034,9 +1034,7 @@ __global__ __launch_bounds__(384, 3) void conv_halo2_kernel(HaloArgs p) {
   constexpr int ES = sizeof(T);
   constexpr int BKE = 128 / ES;
   constexpr int RPL = NL / 8;                         // rows filled per loader pass (16)
-  constexpr int NBL = BN / RPL / 2;                   // weight-tile passes per loader thread: rows 0..63 (4); the MFMA
-                                                      // waves issue rows 64..127 themselves, CPC pieces of 8 rows each
-  constexpr int CPC = 2;
+  constexpr int NBL = BN / RPL;                       // weight-tile passes per loader thread (8)
   constexpr int B_BYTES = BN * 128;
   constexpr int MI = 4, NI = 4;
   static_assert(NSB == 3, "weight ring: weights(it) landed at B(it), it+1 in flight, slot of weights(it-1) refilled after B(it)");
@@ -1193,27 +1191,6 @@ __global__ __launch_bounds__(384, 3) void conv_halo2_kernel(HaloArgs p) {
         __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? 2 : 8, 0);
       }
     };
-    // The MFMA waves carry half of the weight stream: two loader waves alone need ~130-190 cycles per 1 KiB LDS-DMA
-    // piece (issue arbitration against the MFMA waves of their SIMD), 16 + 2 pieces per K-step -- more than the
-    // 512 MFMA cycles of the step (measured: one workgroup alone 1200 cycles per K-step, two per CU 2400).  A piece
-    // issued here stalls this wave for a while, but the sibling workgroup's wave on the same SIMD keeps the matrix pipe
-    // busy.  Wave w owns rows 64 + 16 w .. + 15 of the tile (two pieces); same ring slot / K offset as the loaders.
-    const int crow = 64 + (wave & 3) * (CPC * 8) + (lane >> 3);
-    const char *cb_src[CPC];
-#pragma unroll
-    for (int j = 0; j < CPC; ++j)
-      cb_src[j] = p.wgt + ((long long)(n0 + crow + j * 8) * p.k_ld) * ES + (((lane & 7) ^ (lane >> 3)) << 4);
-    auto issue_my_weights = [&](int it, int ring_slot) {
-      const int chunk = it / 9, tap = it - chunk * 9;
-      const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
-      char *dst = sB + ring_slot * B_BYTES + (64 + (wave & 3) * (CPC * 8)) * 128;
-#pragma unroll
-      for (int j = 0; j < CPC; ++j)
-        __builtin_amdgcn_global_load_lds((gbl_void *)(cb_src[j] + koff), (lds_void *)(dst + j * 1024), 16, 0, 0);
-    };
-    issue_my_weights(0, 0);
-    issue_my_weights(1 < nit ? 1 : nit - 1, 1);
-    wait_vmcnt_n<CPC>();                              // my pieces of weights(0)
     __builtin_amdgcn_s_barrier();                     // B(0): halo(0) and weights(0) are in LDS
     u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
     read_x0(xf0, 0, 0);
@@ -1221,13 +1198,8 @@ __global__ __launch_bounds__(384, 3) void conv_halo2_kernel(HaloArgs p) {
 #pragma unroll 1
     for (int it = 0; it < nit; ++it) {
       if (it) {
-        wait_vmcnt_n<CPC>();                          // my pieces of weights(it) (those of it+1 stay in flight)
         __builtin_amdgcn_s_barrier();                 // B(it): weights(it) landed; slot of weights(it-1) released
         if (tap == 0) read_x0(xf0, 0, 0);             // chunk start: the new halo has only just landed
-      }
-      {
-        const int r2 = ring + 2 >= NSB ? ring + 2 - NSB : ring + 2;
-        issue_my_weights(it + 2 < nit ? it + 2 : nit - 1, r2);
       }
       // this step's first-half weight fragments can only be read now (their tile was still in flight during step it-1);
       // the halo fragments of the first half were read in step it-1's MFMA gaps
@@ -1260,7 +1232,6 @@ __global__ __launch_bounds__(384, 3) void conv_halo2_kernel(HaloArgs p) {
       tap = tap_n;
       ring = ring + 1 == NSB ? 0 : ring + 1;
     }
-    wait_vmcnt<0>();                                  // the tail's dummy pieces must not land on the output tile
   }
   // ---- epilogue (the 256 consumer threads write out; the loaders only keep the barrier count) ----
   constexpr int SWZ = 15;
