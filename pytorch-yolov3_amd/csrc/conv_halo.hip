@@ -100,9 +100,12 @@ __device__ __forceinline__ void wait_vmcnt_n() {
 // One raw workgroup barrier per K-step:  loaders: wait(loads older than D-1 steps) ; barrier ; issue
 // weights(it+D+1) + two halo slices of the next chunk.   consumers: barrier ; MFMAs(it) with the fragments of the
 // second K-half and of step it+1's first K-half read in the MFMA gaps.  Ring: NSB = D + 2 weight slots.
-template <typename T, int NSB>
+template <typename T, int NSB, int MI>
 __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
-  constexpr int BM = 256, BN = 128;
+  // MI = 16-pixel fragments per MFMA wave: 4 -> 256-pixel tiles; 3 -> 192-pixel tiles (wave tile 48 x 64), chosen by the
+  // launcher where 256-pixel tiles leave a large part of the last round of workgroups empty (19^2, 38^2 at batch 16)
+  constexpr int WM = MI * 16;                         // pixels per MFMA wave
+  constexpr int BM = 4 * WM, BN = 128;
   constexpr int WAVES_N = 2;
   constexpr int NC = 512, NL = 256;                   // consumer / loader threads
   constexpr int ES = sizeof(T);
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
   constexpr int PER = NBL + HPS;                      // LDS-DMA instructions per loader thread and K-step
   constexpr int B_BYTES = BN * 128;
   constexpr int D = NSB - 2;
-  constexpr int MI = 4, NI = 4;
+  constexpr int NI = 4;
   static_assert(NSB == 3 || NSB == 4, "weight ring has 3 or 4 slots");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     uint32_t tapmask[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      const uint32_t m = (uint32_t)(m0 + wm * 64 + mi * 16 + fr);
+      const uint32_t m = (uint32_t)(m0 + wm * WM + mi * 16 + fr);
       uint32_t mask = 0u;
       if (m < (uint32_t)p.M) {
         const uint32_t img = (__umulhi(m, p.mul_hw) + m) >> p.sh_hw;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       }
       tapmask[mi] = mask;
     }
-    const int a_lane_row = wm * 64 + fr;
+    const int a_lane_row = wm * WM + fr;
     const int b_lane_row = wn * 64 + fr;
     const int b_off0 = b_lane_row * 128 + (((0 + fq) ^ (b_lane_row & 7)) << 4);
     const int b_off1 = b_lane_row * 128 + (((4 + fq) ^ (b_lane_row & 7)) << 4);
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       const int cl = wn * 64 + ni * 16 + fq * 4;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const int pl = wm * 64 + mi * 16 + fr;
+        const int pl = wm * WM + mi * 16 + fr;
         *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
       }
     }
@@ -1317,10 +1320,52 @@ void fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
   mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
 }
 
+// 192-pixel tiles (MI = 3) when they finish sooner than 256-pixel tiles: rounds of workgroups (one per CU) x per-tile
+// time (K-steps x MFMA cycles of the step + ~300 cycles of barrier / LDS bubbles, + ~11 k cycles outside the loop:
+// profiles/r01_halo_kernel_anatomy.txt).  At batch 16: 19^2 184 tiles -> 248 (one round either way, 3/4 of the work per
+// tile), 38^2 364 tiles in two rounds -> 484 in two rounds of 3/4 tiles, 76^2 stays at 722 x 256 pixels.
+static int halo_tile_fragments(int M, int n_tiles, int nchunks, int n_cu) {
+  if (y3_opt().auto_mask & 512) return 4;
+  double best = 0;
+  int best_mi = 4;
+  for (int mi = 4; mi >= 3; --mi) {
+    const long long tiles = (long long)y3_ceil_div(M, 64 * mi) * n_tiles;
+    const double rounds = (double)((tiles + n_cu - 1) / n_cu);
+    const double cost = rounds * (nchunks * 9.0 * (256.0 * mi + 300.0) + 11000.0);
+    if (best == 0 || cost < 0.97 * best) { best = cost; best_mi = mi; }
+  }
+  return best_mi;
+}
+
+static int device_cu_count() {
+  static Y3DeviceOnce once;
+  int n_cu = 0;
+  if (once.run([]() -> int { return Y3_OK; }, &n_cu) != Y3_OK || n_cu <= 0) return 256;   // no device (dry run on a CPU box)
+  return n_cu;
+}
+
 template <typename T>
 int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
   HaloArgs a = a0;
-  const int hr = 256 + 2 * a.W + 2;
+  static Y3DeviceOnce once;
+  int n_cu = 256;
+  {
+    const int rc = once.run([]() -> int {
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_ws_kernel<T, 3, 4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_ws_kernel<T, 4, 4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_ws_kernel<T, 3, 3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_ws_kernel<T, 4, 3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      return Y3_OK;
+    }, &n_cu);
+    if (rc != Y3_OK) return rc;
+  }
+  const int mi = halo_tile_fragments(a.M, a.n_tiles, a.nchunks, n_cu);
+  const int bm = 64 * mi;
+  const int hr = bm + 2 * a.W + 2;
   a.hr = hr;
   a.na = y3_ceil_div(hr + 1, 32);                     // + the zero row
   a.hr_pad = a.na * 32;
@@ -1331,24 +1376,18 @@ int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
   for (int c = 4; c >= 3; --c) {
     if (a.na > (c == 4 ? 12 : 14)) continue;   // all real halo slices out by tap 5 (4 slots) / 6 (3 slots)
     lds = (size_t)c * 128 * 128 + (size_t)2 * a.a_bytes;
-    if (lds < (size_t)256 * 128 * 4) lds = (size_t)256 * 128 * 4;
+    if (lds < (size_t)bm * 128 * 4) lds = (size_t)bm * 128 * 4;
     if (lds <= 160 * 1024) { nsb = c; break; }
   }
   Y3_REQUIRE(nsb != 0, "wave-specialised halo kernel: row width %d does not fit", a.W);
-  static Y3DeviceOnce once;
-  {
-    const int rc = once.run([]() -> int {
-      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_ws_kernel<T, 3>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_ws_kernel<T, 4>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      return Y3_OK;
-    });
-    if (rc != Y3_OK) return rc;
+  const dim3 grid(y3_ceil_div(a.M, bm) * a.n_tiles);
+  if (mi == 3) {
+    if (nsb == 4) hipLaunchKernelGGL((conv_halo_ws_kernel<T, 4, 3>), grid, dim3(768), lds, s, a);
+    else hipLaunchKernelGGL((conv_halo_ws_kernel<T, 3, 3>), grid, dim3(768), lds, s, a);
+  } else {
+    if (nsb == 4) hipLaunchKernelGGL((conv_halo_ws_kernel<T, 4, 4>), grid, dim3(768), lds, s, a);
+    else hipLaunchKernelGGL((conv_halo_ws_kernel<T, 3, 4>), grid, dim3(768), lds, s, a);
   }
-  const dim3 grid(y3_ceil_div(a.M, 256) * a.n_tiles);
-  if (nsb == 4) hipLaunchKernelGGL((conv_halo_ws_kernel<T, 4>), grid, dim3(768), lds, s, a);
-  else hipLaunchKernelGGL((conv_halo_ws_kernel<T, 3>), grid, dim3(768), lds, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -1560,7 +1599,9 @@ int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, h
   const bool bf = op.dtype == Y3_BF16;
   Y3_REQUIRE(y3_conv_halo_ws_fits(op), "conv block %d: shape not supported by the halo kernel", op.block_idx);
   persistent = persistent && bf;   // the persistent variant is a bf16 throughput kernel (float32: > 168 VGPRs of state)
+  const int mi = halo_tile_fragments(op.batch * op.in_h * op.in_w, op.out_c / 128, op.in_c / (128 / es), device_cu_count());
   if (persistent) *kernel_name = "conv_halo_wsp_bf16_256x128";
+  else if (mi == 3) *kernel_name = bf ? "conv_halo_ws_bf16_192x128" : "conv_halo_ws_f32_192x128";
   else *kernel_name = bf ? "conv_halo_ws_bf16_256x128" : "conv_halo_ws_f32_256x128";
   if (dry_run) return Y3_OK;
   HaloArgs a;

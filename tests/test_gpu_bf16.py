@@ -225,6 +225,16 @@ def test_bf16_every_block_teacher_forced_two_per_cu_halo_kernel(model, h, w, bat
         model, h, w, batch, checked, frac, sum("conv_halo2" in k for k in names)))
 
 
+@pytest.mark.parametrize("model,h,w,batch", [("yolov3", 608, 608, 1), ("yolov3", 320, 416, 2)])
+def test_bf16_every_block_teacher_forced_256_pixel_halo_tiles(model, h, w, batch):
+    """The halo kernel picks 192- or 256-pixel tiles per layer from the tile count (192 at these small batches); the same
+    per-block gate with 256-pixel tiles forced (auto_mask bit 9), the choice the batch-16 benchmark makes at 76^2."""
+    frames = synth_frames(3000 + h + w + batch, batch, h, w)
+    checked, frac, names = _teacher_forced(model, frames, ("conv_halo_ws_bf16_256x128",), options={"auto_mask": 157 | 512})
+    assert not any("192x128" in k for k in names)
+    print("%s %dx%d b%d: %d blocks checked, worst mismatch share %.4f" % (model, h, w, batch, checked, frac))
+
+
 def _stats(a, b):
     d = np.abs(a["class_prob"] - b["class_prob"])
     rel = np.abs(a["bbox_xywh"] - b["bbox_xywh"]) / (np.abs(b["bbox_xywh"]) + 1e-6)

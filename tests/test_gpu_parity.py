@@ -343,7 +343,7 @@ def test_halo_kernels_match_goldens_on_yolov3_fp32():
     g = np.load(os.path.join(GOLDEN, "forward_yolov3.npz"))
     frames = np.stack([resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), 608, 608), synth_frames(5, 1, 608, 608)[0]])
     try:
-        for persistent, mask in ((0, 21), (1, 21), (0, 21 | 128), (1, 21 | 128)):
+        for persistent, mask in ((0, 21), (1, 21), (0, 21 | 128), (1, 21 | 128), (0, 21 | 512)):      # 512: 256-pixel tiles only
             _hip.check(lib.y3_set_tuning(b"halo_persistent", persistent))
             _hip.check(lib.y3_set_tuning(b"auto_mask", mask))
             net = _net("yolov3")
