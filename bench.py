@@ -175,7 +175,7 @@ def plumbing_main(args, backend):
 class Workload(object):
     """model x input size x batch x dtype on one GPU: net, resident frames, per-stream detector / gather buffers."""
 
-    def __init__(self, model, dim, batch, dtype, params, dev, rank, world, kmax, nstream):
+    def __init__(self, model, dim, batch, dtype, params, dev, rank, world, kmax, nstream, options=None):
         import yolov3
         from yolov3.inference import Detector
         from yolov3.synthdata import synth_frames
@@ -183,7 +183,12 @@ class Workload(object):
         self.model, self.dim, self.batch, self.dtype, self.dev, self.nstream = model, dim, batch, dtype, dev, nstream
         cfg = os.path.join(ROOT, "pytorch-yolov3_amd", "models", model + ".cfg")
         self.cfg = cfg
-        self.net = yolov3.Darknet(cfg, device=str(dev), dtype=dtype).eval()
+        if options is None and nstream > 1:
+            # several batches in flight: the halo kernel's throughput tile choice (include/yolov3_hip.h, auto_mask bit 9)
+            from yolov3 import _hip
+            options = {"auto_mask": _hip.options().auto_mask | 512}
+        self.options = options
+        self.net = yolov3.Darknet(cfg, device=str(dev), dtype=dtype, options=options).eval()
         self.net.set_params(params)
         self.frames_np = synth_frames(123 + rank, batch, dim, dim)
         # distinct frames per rank (data-parallel shards), resident in HBM before timing starts
@@ -483,6 +488,7 @@ def main(argv=None):
                                        "the headline)" if args.h2d else "resident in HBM", kept),
                        "frames_per_gpu": b, "global_batch": b * world, "parallelism": "dp%d" % world,
                        "batches_in_flight_per_gpu": nstream, "ranks_seen_by_collective": ranks_seen,
+                       "plan_options": wl.options or "library defaults",
                        "collective": ("1 x all_gather_into_tensor(%d x %d x 8 int32 records) per step, side stream" % (
                            b, args.kmax)) if distributed else "none"},
             "roofline": roof,

@@ -21,7 +21,7 @@ thread_local char g_err[512] = "";
 // bit 5: wave-specialised igemm for rows <= 32 instead; bit 7: 2-D patch kernel (8 x 32 output tiles) for 3x3 stride-1
 // layers with rows wider than 128 px; bit 6: wave-specialised igemm with 64-pixel tiles (3 stages, two workgroups per CU)
 // for bf16 1x1 layers with Cin >= 256; bit 8: the two-workgroups-per-CU halo kernel (128 x 128 tiles) wherever it fits
-// (rows of up to 62 px).  157 = measured best end to end (profiles/r01_ab_kernel_selection.txt).
+// (rows of up to 62 px; slower, experiment); bit 9: 256-pixel halo tiles only (throughput mode, conv_halo.hip).  157 = measured best end to end (profiles/r01_ab_kernel_selection.txt).
 static y3_options g_y3_defaults = {/*auto_mask*/ 157, /*halo_persistent*/ 0, /*igemm_version*/ 2, /*igemm_ns*/ 2,
                                    /*igemm_bm*/ 0, /*use_graph*/ 0, /*fuse_stem*/ 1, /*fuse_head*/ 1, /*fuse_spp*/ 1,
                                    /*decode_lanes*/ 4, {0, 0, 0, 0, 0, 0}};

@@ -1323,7 +1323,12 @@ void fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
 // 192-pixel tiles (MI = 3) when they finish sooner than 256-pixel tiles: rounds of workgroups (one per CU) x per-tile
 // time (K-steps x MFMA cycles of the step + ~300 cycles of barrier / LDS bubbles, + ~11 k cycles outside the loop:
 // profiles/r01_halo_kernel_anatomy.txt).  At batch 16: 19^2 184 tiles -> 248 (one round either way, 3/4 of the work per
-// tile), 38^2 364 tiles in two rounds -> 484 in two rounds of 3/4 tiles, 76^2 stays at 722 x 256 pixels.
+// tile), 38^2 364 tiles in two rounds -> 484 in two rounds of 3/4 tiles, 76^2 stays at 722 x 256 pixels.  Measured
+// (profiles/r02d_*): 880 -> 1000 TF at 38^2, 960 -> 1090 TF at 19^2 per launch, the forward of one batch 3 % shorter.
+// This is the LATENCY choice (one batch at a time: inference(), the video loop).  With several batches in flight on
+// their own streams (bench.py) the idle CUs of a short last round are filled by the other batches' kernels anyway and
+// what counts is CU time, which smaller tiles raise (the ~11 k cycles per tile are paid 248 instead of 184 times):
+// 2.3 % fewer frames/s end to end.  Such callers set auto_mask bit 9 (256-pixel tiles only) in their plan options.
 static int halo_tile_fragments(int M, int n_tiles, int nchunks, int n_cu) {
   if (y3_opt().auto_mask & 512) return 4;
   double best = 0;
