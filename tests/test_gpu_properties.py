@@ -1,4 +1,5 @@
-"""Size-independent properties at the benchmark's full size (yolov3 608x608, 16 frames per batch, bf16 and fp32):
+"""Size-independent properties at the full size of every single-GPU configuration of BASELINE.json (yolov3 608x608 and
+yolov3-spp 608x608 at 16 frames per batch in bf16, yolov3-tiny 416x416 at 8 frames in float32; yolov3 also in float32):
 the oracle is too slow there, so these check what must hold whatever the values are -- frames are independent,
 launches are deterministic, NMS is idempotent and order-free, thresholds nest, streams do not interfere."""
 import numpy as np
@@ -14,30 +15,33 @@ from golden_util import MODELS, golden_weights_path
 pytestmark = pytest.mark.gpu
 
 
-def _net(dtype):
-    net = yolov3.Darknet(MODELS["yolov3"], device="cuda", dtype=dtype)
-    net.load_weights(golden_weights_path("yolov3"))
+def _net(dtype, model="yolov3"):
+    net = yolov3.Darknet(MODELS[model], device="cuda", dtype=dtype)
+    net.load_weights(golden_weights_path(model))
     return net.eval()
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "float32"])
-def test_frames_are_independent_at_full_size(dtype):
-    """Row b of a 16-frame batch == the same frame run alone or in another position (no cross-frame term anywhere:
-    BN uses running statistics, NMS is per frame); also checks that two launches give identical bits."""
-    net = _net(dtype)
-    frames = synth_frames(2024, 16, 608, 608)
+@pytest.mark.parametrize("model,dtype,batch,dim", [("yolov3", "bf16", 16, 608), ("yolov3", "float32", 16, 608),
+                                                    ("yolov3-spp", "bf16", 16, 608), ("yolov3-tiny", "float32", 8, 416)])
+def test_frames_are_independent_at_full_size(model, dtype, batch, dim):
+    """Row b of a full batch == the same frame run alone or in another position (no cross-frame term anywhere:
+    BN uses running statistics, NMS is per frame; the tile height the halo kernel picks from the batch size does not
+    change any output's summation order); also checks that two launches give identical bits."""
+    net = _net(dtype, model)
+    frames = synth_frames(2024, batch, dim, dim)
     full = {k: v.clone() for k, v in net.forward_frames(frames).items()}
     again = net.forward_frames(frames)
     for k in full:
         assert torch.equal(full[k], again[k]), (k, "not deterministic")
-    perm = np.array([5, 0, 15, 9])
+    perm = np.array([5, 0, batch - 1, 3])
     sub = net.forward_frames(frames[perm])
     for k in full:
         assert torch.equal(sub[k], full[k][torch.from_numpy(perm).to(full[k].device)]), k
     one = net.forward_frames(frames[7:8])
     for k in full:
         assert torch.equal(one[k][0], full[k][7]), k
-    assert full["bbox_xywh"].shape == (16, 22743, 4) and torch.isfinite(full["class_prob"]).all()
+    rows = 2535 if model == "yolov3-tiny" else 22743
+    assert full["bbox_xywh"].shape == (batch, rows, 4) and torch.isfinite(full["class_prob"]).all()
 
 
 def test_detection_tail_properties_at_full_size():

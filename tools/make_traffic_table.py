@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""HBM-side traffic per launch from the rocprofv3 PMC passes of tools/profile_gpu.sh -> profiles/r02_traffic.json.
+
+FETCH_SIZE and WRITE_SIZE are collected in SEPARATE passes (TCC slots, MI355X_MICROARCH.md "rocprofv3 PMC slots"); both
+are reported in KiB.  gfx950 correction from the same guide (HBM section): FETCH_SIZE counts 64 B per 128-B request for
+wide coalesced streams (16 B per lane, LDS-DMA alike) -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
+The table records the sha256 of the libyolov3_hip.so that was profiled; bench.py only uses a table whose hash matches
+the library it has loaded (otherwise roofline.traffic is null).
+
+Usage (on the GPU box, after tools/profile_gpu.sh <tag> ...):  python3 tools/make_traffic_table.py gpurun_out/prof_<tag> <out.json>
+"""
+import csv
+import glob
+import hashlib
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def plan_name(kernel):
+    """rocprofv3's demangled kernel name -> the name the plan executor reports (y3_plan_op_kernel)."""
+    k = kernel.replace("(anonymous namespace)::", "").replace("void ", "")
+    m = re.match(r"conv_halo_ws_kernel<(__bf16|float), \d+, (\d+)>", k)
+    if m:
+        return "conv_halo_ws_%s_%dx128" % ("bf16" if m.group(1) == "__bf16" else "f32", 64 * int(m.group(2)))
+    m = re.match(r"conv_halo2_kernel<(__bf16|float)", k)
+    if m:
+        return "conv_halo2_%s_128x128" % ("bf16" if m.group(1) == "__bf16" else "f32")
+    return k.split("(")[0]
+
+
+def per_launch(path, counter):
+    acc, n = defaultdict(float), defaultdict(int)
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            if r["Counter_Name"] != counter:
+                continue
+            k = plan_name(r["Kernel_Name"])
+            acc[k] += float(r["Counter_Value"])
+            n[k] += 1
+    return {k: (acc[k] / n[k], n[k]) for k in acc}
+
+
+def main():
+    prof, out = sys.argv[1], sys.argv[2]
+    fetch = glob.glob(os.path.join(prof, "pmc_fetch", "**", "*counter_collection.csv"), recursive=True)
+    write = glob.glob(os.path.join(prof, "pmc_write", "**", "*counter_collection.csv"), recursive=True)
+    if not fetch or not write:
+        raise SystemExit("no PMC csv under %s" % prof)
+    f, w = per_launch(fetch[0], "FETCH_SIZE"), per_launch(write[0], "WRITE_SIZE")
+    with open(os.path.join(ROOT, "pytorch-yolov3_amd", "lib", "libyolov3_hip.so"), "rb") as fh:
+        sha = hashlib.sha256(fh.read()).hexdigest()
+    table = {"lib_sha256": sha,
+             "_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_gpu.sh) over "
+                        "bench.py --streams 1 with the benchmark's plan options; per-launch means; FETCH_SIZE x 2 (gfx950 counts "
+                        "64 B per 128-B request for 16-B-per-lane streams: MI355X_MICROARCH.md, HBM), WRITE_SIZE as read; KiB -> bytes",
+             "kernels": {}}
+    for k in sorted(set(f) & set(w)):
+        table["kernels"][k] = {"fetch_size_kib": round(f[k][0], 1), "write_size_kib": round(w[k][0], 1), "launches": f[k][1],
+                               "traffic_bytes_per_launch": int(round((2.0 * f[k][0] + w[k][0]) * 1024.0))}
+    with open(out, "w") as fh:
+        json.dump(table, fh, indent=1, sort_keys=True)
+    for k, v in sorted(table["kernels"].items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"])[:12]:
+        print("%-48s launches %5d  traffic/launch %8.1f MB" % (k[:48], v["launches"], v["traffic_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
