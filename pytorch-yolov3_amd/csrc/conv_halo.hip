@@ -259,18 +259,27 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     // the halo buffers are 128-byte aligned, which the bit-6 flip relies on)
     typedef const __attribute__((address_space(3))) u32x4 lds_u32x4;
     const int sA_lds = (int)(size_t)(lds_void *)sA;
+    // The zero region is TWO rows (hr, hr + 1: one 256-byte bank row, hr is even) and a masked lane reads the spot of it
+    // that has the bank of the address it would have read -- (ap & 255) | zero base, one v_and_or per fragment.  With a
+    // single shared zero address the masked lanes of a fragment sat on one bank next to an unmasked lane's access:
+    // 2-way conflicts on 11-20 % of the LDS cycles of this kernel (SQ_LDS_BANK_CONFLICT, profiles/), most at 19^2 where
+    // nearly every 16-pixel fragment crosses an image row.
     int zalt[MI], sel[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       zalt[mi] = sA_lds + p.hr * 128 - mi * 2048;
       asm volatile("" : "+v"(zalt[mi]));               // lives in a VGPR: v_cndmask takes one scalar operand, the condition
     }
+    int low8 = 255;
+    asm volatile("" : "+s"(low8));                     // in an SGPR: no VOP3 literals on gfx9
     auto read_frags0 = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], int a_off, const char *bBuf, int a_shift, int tap) {
       const int r0 = a_lane_row + a_shift;
       const int ap = ((r0 << 7) + (a_off + sA_lds)) + ((fq ^ (r0 & 7)) << 4);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        int off = ((tapmask[mi] >> tap) & 1u) ? ap : zalt[mi];
+        int zoff;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(zoff) : "v"(ap), "s"(low8), "v"(zalt[mi]));
+        int off = ((tapmask[mi] >> tap) & 1u) ? ap : zoff;
         asm volatile("" : "+v"(off));                  // keeps `+ mi * 2048` in the ds_read's immediate offset
         sel[mi] = off;
         xf[mi] = *reinterpret_cast<lds_u32x4 *>(off + mi * 2048);
@@ -1372,7 +1381,7 @@ int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
   const int bm = 64 * mi;
   const int hr = bm + 2 * a.W + 2;
   a.hr = hr;
-  a.na = y3_ceil_div(hr + 1, 32);                     // + the zero row
+  a.na = y3_ceil_div(hr + 2, 32);                     // + the two zero rows (hr is even: rows hr, hr + 1 = one 256-byte bank row)
   a.hr_pad = a.na * 32;
   a.a_bytes = a.hr_pad * 128;
   // the next chunk's halo goes out two passes per K-step and must be older than the last loads allowed in flight
@@ -1513,7 +1522,7 @@ bool y3_conv_halo_eligible(const y3_op &op) {
 // real halo slices must be out by tap 6 of the previous chunk (<= 14 passes of 32 rows)
 bool y3_conv_halo_ws_fits(const y3_op &op) {
   if (!y3_conv_halo_eligible(op)) return false;
-  const int na = y3_ceil_div(256 + 2 * op.in_w + 3, 32);
+  const int na = y3_ceil_div(256 + 2 * op.in_w + 4, 32);
   return na <= 14 && (size_t)3 * 128 * 128 + (size_t)2 * na * 32 * 128 <= 160 * 1024;
 }
 
