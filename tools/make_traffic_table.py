@@ -30,6 +30,16 @@ def plan_name(kernel):
     m = re.match(r"conv_halo2_kernel<(__bf16|float)", k)
     if m:
         return "conv_halo2_%s_128x128" % ("bf16" if m.group(1) == "__bf16" else "f32")
+    # rocprofv3 leaves the template kernels of anonymous namespaces mangled: ...conv_halo_ws_kernelIDF16bLi4ELi4EEEv...
+    m = re.search(r"conv_halo_ws_kernelI(DF16b|f)Li\d+ELi(\d+)E", k)
+    if m:
+        return "conv_halo_ws_%s_%dx128" % ("bf16" if m.group(1) == "DF16b" else "f32", 64 * int(m.group(2)))
+    m = re.search(r"conv_halo2_kernelI(DF16b|f)", k)
+    if m:
+        return "conv_halo2_%s_128x128" % ("bf16" if m.group(1) == "DF16b" else "f32")
+    m = re.search(r"\d+(conv_[a-z0-9_]+_kernel|[a-z_]+_kernel)I", k)
+    if m:
+        return m.group(1) + k[k.index(m.group(1)) + len(m.group(1)):].split("EvN")[0]
     return k.split("(")[0]
 
 
