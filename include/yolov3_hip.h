@@ -110,7 +110,9 @@ typedef struct y3_plan y3_plan;
  *                    0 = implicit GEMM v2 everywhere; bits 1 / 5 / 6 route more layers to the wave-specialised
  *                    implicit GEMM (api.hip); bit 8: experimental two-workgroups-per-CU halo kernel; bit 9 (512): halo
  *                    kernel with 256-pixel tiles only -- the THROUGHPUT choice for callers that keep several batches
- *                    in flight on their own streams (default: 192-pixel tiles where they shorten a single forward)
+ *                    in flight on their own streams (default: 192-pixel tiles where they shorten a single forward);
+ *                    bits 10 / 11 switch the small-grid choices off (narrower implicit-GEMM channel tiles / implicit GEMM
+ *                    instead of the halo kernel when a layer has fewer than 192 halo tiles): A/B only
  *   halo_persistent  0 [default] one tile per workgroup, 1 persistent tile loop (bf16 networks; float32 keeps 0)
  *   igemm_version    1 register-staged, 2 LDS-DMA double-buffered [default], 3 wave-specialised
  *   igemm_ns         LDS stages of version 3 (3 or 4; less means 3);  igemm_bm  64 = 64-pixel tiles for version 3 (bf16)

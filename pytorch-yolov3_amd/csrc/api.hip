@@ -21,7 +21,8 @@ thread_local char g_err[512] = "";
 // bit 5: wave-specialised igemm for rows <= 32 instead; bit 7: 2-D patch kernel (8 x 32 output tiles) for 3x3 stride-1
 // layers with rows wider than 128 px; bit 6: wave-specialised igemm with 64-pixel tiles (3 stages, two workgroups per CU)
 // for bf16 1x1 layers with Cin >= 256; bit 8: the two-workgroups-per-CU halo kernel (128 x 128 tiles) wherever it fits
-// (rows of up to 62 px; slower, experiment); bit 9: 256-pixel halo tiles only (throughput mode, conv_halo.hip).  157 = measured best end to end (profiles/r01_ab_kernel_selection.txt).
+// (rows of up to 62 px; slower, experiment); bit 9: 256-pixel halo tiles only (throughput mode, conv_halo.hip); bit 10: implicit-GEMM channel tiles by Cout only (no
+// shrinking on small grids); bit 11: no small-grid / stride-2 rerouting (round-1 selection).  157 = measured best end to end (profiles/r01_ab_kernel_selection.txt).
 static y3_options g_y3_defaults = {/*auto_mask*/ 157, /*halo_persistent*/ 0, /*igemm_version*/ 2, /*igemm_ns*/ 2,
                                    /*igemm_bm*/ 0, /*use_graph*/ 0, /*fuse_stem*/ 1, /*fuse_head*/ 1, /*fuse_spp*/ 1,
                                    /*decode_lanes*/ 4, {0, 0, 0, 0, 0, 0}};
@@ -102,8 +103,21 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
             if ((am & 128) && op.ksize == 3 && op.stride == 1 && w > 128 && op.out_c >= 128 && y3_conv_patch_fits(op))
               return y3_launch_conv_patch(op, in, d_zero, s, name, dry_run);
             if ((am & 256) && k3 && y3_conv_halo2_fits(op)) return y3_launch_conv_halo2(op, in, d_zero, s, name, dry_run);
-            if (want_halo && halo_ok) return y3_launch_conv_halo(op, in, d_zero, s, name, dry_run, y3_opt().halo_persistent != 0);
+            // Small grids (small maps x small batches): a halo tile is 192+ pixels x 128 channels, and below ~3/4 of a
+            // tile per CU most of the chip idles through its long K loop; the 128 x 128 implicit GEMMs have more, shorter
+            // workgroups.  tools/conv_bench.py at batch 1 / 4 / 8 (profiles/r02f_convbench_small_batches.txt): 512 -> 1024
+            // at 19^2 x 8 frames (128 tiles) 615 TFLOP/s on the halo kernel, 722 on the wave-specialised implicit GEMM;
+            // in float32 (yolov3-tiny's 13^2 layers at batch 8) 66 against 93 on the LDS-DMA implicit GEMM.
+            const long long halo_tiles = (long long)y3_ceil_div(op.batch * op.in_h * op.in_w, 192) * (op.out_c / 128);
+            const bool small_grid = !(am & 2048) && k3 && halo_tiles < 192;
+            if (small_grid && op.dtype == Y3_BF16) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
+            if (want_halo && halo_ok && !small_grid) return y3_launch_conv_halo(op, in, d_zero, s, name, dry_run, y3_opt().halo_persistent != 0);
             if (want_ws) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
+            // 3x3 stride-2 layer with 256 input channels (76^2 -> 38^2): 865 against 762 TFLOP/s on the wave-specialised
+            // implicit GEMM at batch 16; the other stride-2 layers measured faster on the LDS-DMA version
+            if (!(am & 2048) && op.ksize == 3 && op.stride == 2 && op.in_c == 256 && op.out_c >= 128 && op.dtype == Y3_BF16 &&
+                !(op.flags & Y3_F_OUT_F32) && (long long)op.batch * op.out_h * op.out_w >= 16384)
+              return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
           }
           return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run);
         }

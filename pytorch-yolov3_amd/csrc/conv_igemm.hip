@@ -1034,8 +1034,15 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
   igemm_fast_div((uint32_t)a.Wo, a.mul_w, a.sh_w);
 
   const bool bf = op.dtype == Y3_BF16;
-  // channel-tile width follows Cout so narrow layers do not multiply zero padding
-  const int bn = op.out_c > 64 ? 128 : (op.out_c > 32 ? 64 : 32);
+  // channel-tile width follows Cout so narrow layers do not multiply zero padding ...
+  int bn = op.out_c > 64 ? 128 : (op.out_c > 32 ? 64 : 32);
+  // ... and shrinks while the grid would leave most CUs without a workgroup (small maps / small batches: 13^2 x 8 frames
+  // of yolov3-tiny has 11 pixel tiles; 128-channel tiles of its 512 -> 1024 layer are 88 workgroups on 256 CUs, two per
+  // CU resident).  Narrower tiles re-read the (small) activation tile more often and keep the weight bytes per FLOP.
+  if (version == 2 && !(op.flags & Y3_F_OUT_F32) && !(y3_opt().auto_mask & 1024)) {
+    const long long m_tiles = y3_ceil_div(a.M, 128);
+    while (bn > 32 && m_tiles * y3_ceil_div(op.out_c, bn) < 256) bn >>= 1;   // 362 / 368 workgroups at 128 measured faster than twice as many at 64
+  }
   // float32-output (detection head) convs: the direct epilogue of v1 measured faster
   if (version == 1 || (version == 2 && bf && (op.flags & Y3_F_OUT_F32))) {
     const bool generic = kmode != 0;

@@ -57,6 +57,7 @@ VARIANTS = [
     ("igemm_v3_bm64_ns3", dict(BASE, igemm_version=3, igemm_ns=3, igemm_bm=64)),
     ("halo2", dict(BASE, auto_mask=21 | 256)),
     ("halo_ws_256", dict(BASE, auto_mask=21 | 512)),
+    ("igemm_v2_bn128", dict(BASE, auto_mask=1024)),
 ]
 
 
