@@ -195,21 +195,32 @@ def test_bf16_every_block_teacher_forced_mini():
     assert checked >= 20
 
 
-@pytest.mark.parametrize("model,h,w,batch,kernels", [
-    ("yolov3-tiny", 416, 416, 2, ("conv_stem_mfma", "conv_igemm", "head_decode", "maxpool")),
-    ("yolov3", 608, 608, 1, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_halo_ws", "conv_patch", "conv_igemm2",
-                             "conv_igemm3", "head_decode")),
-    ("yolov3", 352, 480, 2, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_halo_ws", "head_decode")),
-    ("yolov3", 320, 320, 3, ("conv_halo_ws", "head_decode")),
-    ("yolov3-spp", 608, 608, 1, ("conv_halo_ws", "maxpool", "head_decode")),
-    ("yolov3-spp", 416, 416, 2, ("conv_halo_ws", "maxpool", "head_decode")),
+HALO = {"auto_mask": 157 | 2048}     # round-1 selection: the halo kernel whatever the grid size (bit 11: no small-grid rerouting)
+
+
+@pytest.mark.parametrize("model,h,w,batch,options,kernels", [
+    ("yolov3-tiny", 416, 416, 2, None, ("conv_stem_mfma", "conv_igemm", "head_decode", "maxpool")),
+    # default selection at these small batches: the 3x3 layers with few tiles go to the wave-specialised implicit GEMM
+    ("yolov3", 608, 608, 1, None, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_patch", "conv_igemm2", "conv_igemm3",
+                                   "head_decode")),
+    ("yolov3", 352, 480, 2, None, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_igemm3", "head_decode")),
+    ("yolov3-spp", 416, 416, 2, None, ("conv_igemm3", "maxpool_spp", "head_decode")),
+    # the halo kernel on every layer it fits (what the batch-16 benchmark runs), 192-pixel tiles at these sizes
+    ("yolov3", 608, 608, 1, HALO, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_halo_ws", "conv_patch", "conv_igemm2",
+                                   "conv_igemm3", "head_decode")),
+    ("yolov3", 352, 480, 2, HALO, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_halo_ws", "head_decode")),
+    ("yolov3", 320, 320, 3, HALO, ("conv_halo_ws", "head_decode")),
+    ("yolov3-spp", 608, 608, 1, HALO, ("conv_halo_ws", "maxpool_spp", "head_decode")),
+    ("yolov3-spp", 416, 416, 2, HALO, ("conv_halo_ws", "maxpool_spp", "head_decode")),
+    # batch 8: 76^2 and 38^2 stay on the halo kernel by themselves, 19^2 goes to the implicit GEMM
+    ("yolov3", 608, 608, 8, None, ("conv_halo_ws", "conv_igemm3", "head_decode")),
 ])
-def test_bf16_every_block_teacher_forced(model, h, w, batch, kernels):
+def test_bf16_every_block_teacher_forced(model, h, w, batch, options, kernels):
     frames = synth_frames(1000 + h + w + batch, batch, h, w)
     if (h, w) == (608, 608):
         frames[0] = resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), h, w)
-    checked, frac, names = _teacher_forced(model, frames, kernels)
-    print("%s %dx%d b%d: %d blocks checked, worst mismatch share %.4f" % (model, h, w, batch, checked, frac))
+    checked, frac, names = _teacher_forced(model, frames, kernels, options=options)
+    print("%s %dx%d b%d %s: %d blocks checked, worst mismatch share %.4f" % (model, h, w, batch, options, checked, frac))
     assert checked >= (20 if model == "yolov3-tiny" else 75)      # 107 blocks, 23 convs checked with their shortcut, 3 yolo
 
 
@@ -230,7 +241,7 @@ def test_bf16_every_block_teacher_forced_256_pixel_halo_tiles(model, h, w, batch
     """The halo kernel picks 192- or 256-pixel tiles per layer from the tile count (192 at these small batches); the same
     per-block gate with 256-pixel tiles forced (auto_mask bit 9), the choice the batch-16 benchmark makes at 76^2."""
     frames = synth_frames(3000 + h + w + batch, batch, h, w)
-    checked, frac, names = _teacher_forced(model, frames, ("conv_halo_ws_bf16_256x128",), options={"auto_mask": 157 | 512})
+    checked, frac, names = _teacher_forced(model, frames, ("conv_halo_ws_bf16_256x128",), options={"auto_mask": 157 | 512 | 2048})
     assert not any("192x128" in k for k in names)
     print("%s %dx%d b%d: %d blocks checked, worst mismatch share %.4f" % (model, h, w, batch, checked, frac))
 

@@ -343,7 +343,8 @@ def test_halo_kernels_match_goldens_on_yolov3_fp32():
     g = np.load(os.path.join(GOLDEN, "forward_yolov3.npz"))
     frames = np.stack([resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), 608, 608), synth_frames(5, 1, 608, 608)[0]])
     try:
-        for persistent, mask in ((0, 21), (1, 21), (0, 21 | 128), (1, 21 | 128), (0, 21 | 512)):      # 512: 256-pixel tiles only
+        # 2048: the halo kernel whatever the grid size (two frames are a small grid); 512: 256-pixel tiles only
+        for persistent, mask in ((0, 21 | 2048), (1, 21 | 2048), (0, 21 | 128 | 2048), (1, 21 | 128 | 2048), (0, 21 | 512 | 2048)):
             _hip.check(lib.y3_set_tuning(b"halo_persistent", persistent))
             _hip.check(lib.y3_set_tuning(b"auto_mask", mask))
             net = _net("yolov3")
@@ -621,20 +622,28 @@ def test_plan_options_are_per_plan():
     lib = _hip.lib()
     frames = synth_frames(3, 1, 416, 416)
     plain = _net("yolov3", dtype="bf16", options={"auto_mask": 0, "fuse_stem": 0, "fuse_head": 0})
-    fast = _net("yolov3", dtype="bf16")
+    fast = _net("yolov3", dtype="bf16", options={"auto_mask": 157 | 2048})
+    dflt = _net("yolov3", dtype="bf16")
     o_plain = {k: v.clone() for k, v in plain.forward_frames(frames).items()}
     o_fast = {k: v.clone() for k, v in fast.forward_frames(frames).items()}
-    assert not any("halo" in r["kernel"] or "fused" in r["kernel"] for r in plain.plan_report())
+    o_dflt = {k: v.clone() for k, v in dflt.forward_frames(frames).items()}
+    assert not any("halo" in r["kernel"] or "fused" in r["kernel"] or "igemm3" in r["kernel"] for r in plain.plan_report())
     assert any("halo" in r["kernel"] for r in fast.plan_report())
+    names_dflt = [r["kernel"] for r in dflt.plan_report()]
+    assert any("igemm3" in k for k in names_dflt) and any("fused" in k for k in names_dflt)
     try:
         _hip.check(lib.y3_set_tuning(b"auto_mask", 0))       # must not reach into the existing plans
-        again = fast.forward_frames(frames)
-        assert any("halo" in r["kernel"] for r in fast.plan_report())
-        for k in o_fast:
-            assert torch.equal(again[k], o_fast[k])
+        again = dflt.forward_frames(frames)
+        assert [r["kernel"] for r in dflt.plan_report()] == names_dflt
+        for k in o_dflt:
+            assert torch.equal(again[k], o_dflt[k])
+        late = _net("yolov3", dtype="bf16")                 # created under the changed defaults
+        late.forward_frames(frames)
+        assert not any("halo" in r["kernel"] or "igemm3" in r["kernel"] for r in late.plan_report())
     finally:
         lib.y3_set_tuning(b"auto_mask", DEFAULT_KNOBS["auto_mask"])
     assert float((o_plain["class_prob"] - o_fast["class_prob"]).abs().median()) < 2e-3
+    assert float((o_plain["class_prob"] - o_dflt["class_prob"]).abs().median()) < 2e-3
 
 
 @pytest.mark.parametrize("dtype,dim,batch", [("bf16", 608, 2), ("float32", 416, 1), ("bf16", 320, 3)])

@@ -15,8 +15,8 @@ from golden_util import MODELS, golden_weights_path
 pytestmark = pytest.mark.gpu
 
 
-def _net(dtype, model="yolov3"):
-    net = yolov3.Darknet(MODELS[model], device="cuda", dtype=dtype)
+def _net(dtype, model="yolov3", options=None):
+    net = yolov3.Darknet(MODELS[model], device="cuda", dtype=dtype, options=options)
     net.load_weights(golden_weights_path(model))
     return net.eval()
 
@@ -25,23 +25,34 @@ def _net(dtype, model="yolov3"):
                                                     ("yolov3-spp", "bf16", 16, 608), ("yolov3-tiny", "float32", 8, 416)])
 def test_frames_are_independent_at_full_size(model, dtype, batch, dim):
     """Row b of a full batch == the same frame run alone or in another position (no cross-frame term anywhere:
-    BN uses running statistics, NMS is per frame; the tile height the halo kernel picks from the batch size does not
-    change any output's summation order); also checks that two launches give identical bits."""
-    net = _net(dtype, model)
+    BN uses running statistics, NMS is per frame); also checks that two launches give identical bits.
+    Bit-for-bit with the kernel selection pinned (auto_mask bit 11: the default picks kernels by grid size, and the halo
+    kernel sums chunk-major where the implicit GEMM sums tap-major; the tile height the halo kernel picks from the batch
+    size does not change any output's summation order); with the default selection the small batches agree with the
+    full batch to summation-order noise."""
     frames = synth_frames(2024, batch, dim, dim)
-    full = {k: v.clone() for k, v in net.forward_frames(frames).items()}
-    again = net.forward_frames(frames)
-    for k in full:
-        assert torch.equal(full[k], again[k]), (k, "not deterministic")
     perm = np.array([5, 0, batch - 1, 3])
-    sub = net.forward_frames(frames[perm])
-    for k in full:
-        assert torch.equal(sub[k], full[k][torch.from_numpy(perm).to(full[k].device)]), k
-    one = net.forward_frames(frames[7:8])
-    for k in full:
-        assert torch.equal(one[k][0], full[k][7]), k
     rows = 2535 if model == "yolov3-tiny" else 22743
-    assert full["bbox_xywh"].shape == (batch, rows, 4) and torch.isfinite(full["class_prob"]).all()
+    for options in ({"auto_mask": 157 | 2048}, None):
+        net = _net(dtype, model, options)
+        full = {k: v.clone() for k, v in net.forward_frames(frames).items()}
+        again = net.forward_frames(frames)
+        for k in full:
+            assert torch.equal(full[k], again[k]), (k, "not deterministic")
+        sub = {k: v.clone() for k, v in net.forward_frames(frames[perm]).items()}
+        one = net.forward_frames(frames[7:8])
+        idx = torch.from_numpy(perm).to(full["class_prob"].device)
+        if options is not None:
+            for k in full:
+                assert torch.equal(sub[k], full[k][idx]), k
+                assert torch.equal(one[k][0], full[k][7]), k
+        else:
+            tol = 2e-5 if dtype == "float32" else 5e-2
+            d = (sub["class_prob"] - full["class_prob"][idx]).abs()
+            assert float(d.max()) <= tol and float(d.median()) <= tol / 20, (float(d.max()), float(d.median()))
+            d1 = (one["class_prob"][0] - full["class_prob"][7]).abs()
+            assert float(d1.max()) <= tol
+        assert full["bbox_xywh"].shape == (batch, rows, 4) and torch.isfinite(full["class_prob"]).all()
 
 
 def test_detection_tail_properties_at_full_size():
