@@ -96,7 +96,10 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
             if (k3 && w > 64) want_halo = am & 1;
             else if (k3 && w > 32) { want_halo = am & 16; want_ws = am & 2; }
             else if (k3) { want_halo = am & 4; want_ws = am & 32; }
-            else if (op.ksize == 1 && op.in_c >= 1024 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32)) want_ws = am & 8;
+            else if (op.ksize == 1 && op.in_c >= 1024 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32))
+              // (not below 64 tiles of 128 x 128: yolov3-tiny's 1024 -> 256 at 13^2 x 8 frames is 22 of them; the LDS-DMA
+              // version with narrower channel tiles has four times the workgroups)
+              want_ws = (am & 8) && ((am & 2048) || (long long)y3_ceil_div(op.batch * op.out_h * op.out_w, 128) * y3_ceil_div(op.out_c, 128) >= 64);
             if ((am & 64) && op.ksize == 1 && op.in_c >= 256 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32) &&
                 op.dtype == Y3_BF16)
               return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3, 64);
