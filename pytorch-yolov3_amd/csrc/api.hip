@@ -22,7 +22,8 @@ thread_local char g_err[512] = "";
 // layers with rows wider than 128 px; bit 6: wave-specialised igemm with 64-pixel tiles (3 stages, two workgroups per CU)
 // for bf16 1x1 layers with Cin >= 256; bit 8: the two-workgroups-per-CU halo kernel (128 x 128 tiles) wherever it fits
 // (rows of up to 62 px; slower, experiment); bit 9: 256-pixel halo tiles only (throughput mode, conv_halo.hip); bit 10: implicit-GEMM channel tiles by Cout only (no
-// shrinking on small grids); bit 11: no small-grid / stride-2 rerouting (round-1 selection).  157 = measured best end to end (profiles/r01_ab_kernel_selection.txt).
+// shrinking on small grids); bit 11: no small-grid / stride-2 rerouting (round-1 selection); bit 12: no weights-resident 1x1 kernel (conv_1x1.hip), bit 13: that kernel
+// on every layer it supports, whatever the map size (tests).  157 = measured best end to end (profiles/r01_ab_kernel_selection.txt).
 static y3_options g_y3_defaults = {/*auto_mask*/ 157, /*halo_persistent*/ 0, /*igemm_version*/ 2, /*igemm_ns*/ 2,
                                    /*igemm_bm*/ 0, /*use_graph*/ 0, /*fuse_stem*/ 1, /*fuse_head*/ 1, /*fuse_spp*/ 1,
                                    /*decode_lanes*/ 4, {0, 0, 0, 0, 0, 0}};
@@ -100,6 +101,8 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
               // (not below 64 tiles of 128 x 128: yolov3-tiny's 1024 -> 256 at 13^2 x 8 frames is 22 of them; the LDS-DMA
               // version with narrower channel tiles has four times the workgroups)
               want_ws = (am & 8) && ((am & 2048) || (long long)y3_ceil_div(op.batch * op.out_h * op.out_w, 128) * y3_ceil_div(op.out_c, 128) >= 64);
+            if (!(am & 4096) && y3_conv1x1_wres_supported(op) && ((am & 8192) || y3_conv1x1_wres_pays(op)))
+              return y3_launch_conv1x1_wres(op, in, d_zero, s, name, dry_run);
             if ((am & 64) && op.ksize == 1 && op.in_c >= 256 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32) &&
                 op.dtype == Y3_BF16)
               return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3, 64);

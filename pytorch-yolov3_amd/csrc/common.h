@@ -235,6 +235,11 @@ int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d
 bool y3_conv_halo_ws_fits(const y3_op &op);
 int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
                         const char **kernel_name, bool dry_run, bool persistent);
+// 1x1 conv with LDS-resident weights, persistent workgroups (conv_1x1.hip)
+bool y3_conv1x1_wres_supported(const y3_op &op);
+bool y3_conv1x1_wres_pays(const y3_op &op);
+int y3_launch_conv1x1_wres(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s, const char **kernel_name,
+                           bool dry_run);
 // two workgroups per CU: 128 x 128 tiles, single halo buffer, <= 80 KiB of LDS (conv_halo.hip)
 bool y3_conv_halo2_fits(const y3_op &op);
 int y3_launch_conv_halo2(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,

@@ -1,0 +1,263 @@
+// 1x1 convolution with LDS-resident weights (gfx950, bf16, NHWC): persistent workgroups, streamed activations.
+//
+// Same contract as conv_igemm.hip for the layers it takes (1x1, stride 1, conv -> scale/bias -> LeakyReLU, bf16 in and
+// out, no shortcut operand): the "bottleneck" convs of Darknet-53's residual blocks
+// (/root/reference/yolov3/darknet.py:244-257; models/yolov3.cfg: 256 -> 128 at 76^2, 512 -> 256 at 38^2, ten each).
+//
+// Why: these layers are a GEMM with a short K (4 or 8 K-tiles of 64 channels) over a long M.  On the tiled implicit
+// GEMM every 128 x 128 tile is its own workgroup that first waits for its operands, runs 4 K-steps with one step of
+// prefetch, parks and writes its tile: 23 us per launch at 76^2 and 18 us at 38^2 for ~6 us of HBM traffic and ~3 us of
+// MFMA work (profiles/r02e_per_op.txt) -- latency, not bandwidth.  Here a workgroup loads ITS weight panel
+// (BN output channels x all K, <= 64 KiB) into LDS once and then streams pixel tiles through a 4-slot ring without ever
+// stopping at a tile boundary: the loader waves run NS - 1 K-tiles ahead of the MFMA waves across tiles, so a tile's
+// first MFMA never waits for a cold prologue, and the weights are read from HBM / L2 once per workgroup instead of once
+// per tile.  The epilogue applies scale / bias / LeakyReLU in registers, parks the tile as bf16 (32 KiB, 16-byte slots
+// XOR-swizzled with the pixel) and writes whole 16-byte NHWC chunks.
+//
+// Geometry: BM = 128 pixels, BN = 128 (K <= 256) or 64 (K <= 512) channels, 4 MFMA waves (2 x 2, wave tile 64 x BN/2)
+// + 4 loader waves, LDS = K*BN*2 (weights) + 128*BN*2 (park) + 4 x 16 KiB (ring) <= 160 KiB, one workgroup per CU.
+// Workgroup b owns channel tile b % n_tiles and the pixel tiles (b / n_tiles) + j * (grid / n_tiles).
+#include "common.h"
+
+namespace {
+
+struct WresArgs {
+  const char *in;
+  const char *wgt;
+  const float *scale;
+  const float *bias;
+  char *out;
+  const char *zero;
+  int M, Cin, in_ld, Cout, out_ld, k_ld;
+  int n_kt;        // Cin / 64
+  int n_tiles;     // Cout / BN
+  int m_tiles;     // ceil(M / 128)
+  uint32_t flags;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+template <int N>
+__device__ __forceinline__ void wres_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv1x1_wres_kernel(WresArgs p) {
+  constexpr int BM = 128, NS = 4;
+  constexpr int NC = 256;                            // consumer threads (== loader threads)
+  constexpr int TN = BN / 2;                         // channels per MFMA wave
+  constexpr int MI = 4, NI = TN / 16;
+  constexpr int A_CH = BM / 32;                      // LDS-DMA pieces per loader thread and K-tile (32 rows per pass)
+  constexpr int SLOT = BM * 128;                     // one K-tile of activations: 128 pixels x 64 channels
+  constexpr int OCT = BN / 8;                        // 16-byte chunks per output row
+  constexpr int WR = BM * OCT / NC;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *sW = smem;                                   // [n_kt][BN][128 B]
+  char *sP = smem + p.n_kt * BN * 128;               // [BM][BN * 2 B], 16-byte slots swizzled with the pixel
+  char *sA = sP + BM * BN * 2;                       // [NS][BM][128 B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= NC / 64;
+
+  const int nt = blockIdx.x % p.n_tiles;             // this workgroup's channel tile, fixed: its weights stay in LDS
+  const int n0 = nt * BN;
+  const int mstride = gridDim.x / p.n_tiles;
+  const int mfirst = blockIdx.x / p.n_tiles;
+  const int my_tiles = mfirst < p.m_tiles ? (p.m_tiles - mfirst + mstride - 1) / mstride : 0;
+  const int total = my_tiles * p.n_kt;               // K-tiles of activations this workgroup consumes
+
+  if (loader) {
+    __builtin_amdgcn_s_setprio(3);
+    const int ltid = tid - NC;
+    const int lwave = wave - NC / 64;
+    const int slot = ltid & 7;
+    const int row0 = ltid >> 3;                      // 0..31
+    const int kc = slot ^ (row0 & 7);
+    // ---- weights: n_kt x BN rows of 128 bytes, K-tile major
+    for (int r = row0; r < p.n_kt * BN; r += 32) {
+      const int kt = r / BN, co = r - kt * BN;
+      const char *src = p.wgt + ((long long)(n0 + co) * p.k_ld + kt * 64) * 2 + kc * 16;
+      __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(sW + (r - row0) * 128 + lwave * 1024), 16, 0, 0);
+    }
+    // ---- activations: K-tile s of the stream = K-tile (s % n_kt) of pixel tile mfirst + (s / n_kt) * mstride
+    int s_tile = 0, s_kt = 0;                        // position of the NEXT K-tile to issue
+    auto issue = [&](int stage) {
+      const int m0 = (mfirst + s_tile * mstride) * BM;
+      const bool live = s_tile < my_tiles;
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const int m = m0 + row0 + 32 * i;
+        const char *src = (live && m < p.M) ? p.in + ((long long)m * p.in_ld + s_kt * 64) * 2 + kc * 16 : p.zero;
+        __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(sA + stage * SLOT + i * 4096 + lwave * 1024), 16, 0, 0);
+      }
+      if (++s_kt == p.n_kt) { s_kt = 0; ++s_tile; }
+    };
+    int stage = 0;
+    for (int t = 0; t < NS - 1; ++t) {               // beyond the end of the stream the pieces read the zero page
+      issue(stage);
+      stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    int kt = 0;
+    for (int s = 0; s < total; ++s) {
+      wres_wait_vmcnt<(NS - 2) * A_CH>();            // K-tile s (and the weights before it) landed; NS - 2 tiles in flight
+      __builtin_amdgcn_s_barrier();                  // B(s): tile s visible, slot of tile s - 1 free
+      issue(stage);
+      stage = stage + 1 == NS ? 0 : stage + 1;
+      if (++kt == p.n_kt) {
+        kt = 0;
+        __builtin_amdgcn_s_barrier();                // P: the MFMA waves have parked the finished tile
+      }
+    }
+    wres_wait_vmcnt<0>();
+    return;
+  }
+
+  // ---------------- MFMA waves ----------------
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool leaky = p.flags & Y3_F_LEAKY;
+  const float slope = leaky ? Y3_LEAKY_SLOPE : 1.0f;
+  f32x4 sc[NI], bi[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int c = n0 + wn * TN + ni * 16 + fq * 4;
+    sc[ni] = *reinterpret_cast<const f32x4 *>(p.scale + c);
+    bi[ni] = *reinterpret_cast<const f32x4 *>(p.bias + c);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this wave is in flight inside the loop
+  int stage = 0;
+  for (int j = 0; j < my_tiles; ++j) {
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < p.n_kt; ++kt) {
+      __builtin_amdgcn_s_barrier();                  // B(s)
+      const char *a = sA + stage * SLOT;
+      const char *w = sW + kt * BN * 128;
+      stage = stage + 1 == NS ? 0 : stage + 1;
+      u32x4 xf[2][MI], wf[2][NI];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int row = wn * TN + ni * 16 + fr;
+          wf[g][ni] = *reinterpret_cast<const u32x4 *>(w + row * 128 + (((g * 4 + fq) ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int row = wm * 64 + mi * 16 + fr;
+          xf[g][mi] = *reinterpret_cast<const u32x4 *>(a + row * 128 + (((g * 4 + fq) ^ (row & 7)) << 4));
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[g][ni]),
+                                                                  __builtin_bit_cast(bf16x8, xf[g][mi]), acc[mi][ni], 0, 0, 0);
+    }
+    // ---- epilogue: scale / bias / LeakyReLU in registers (the arithmetic of y3_bn_leaky8), bf16, park, write out
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int pl = wm * 64 + mi * 16 + fr;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int cl = wn * TN + ni * 16 + fq * 4;
+        const f32x2 t0 = f32x2{acc[mi][ni][0], acc[mi][ni][1]} * f32x2{sc[ni][0], sc[ni][1]} + f32x2{bi[ni][0], bi[ni][1]};
+        const f32x2 t1 = f32x2{acc[mi][ni][2], acc[mi][ni][3]} * f32x2{sc[ni][2], sc[ni][3]} + f32x2{bi[ni][2], bi[ni][3]};
+        const f32x2 s0 = t0 * slope, s1 = t1 * slope;
+        bf16x4 o;
+        o[0] = (bf16_t)y3_vmax(t0[0], s0[0]);
+        o[1] = (bf16_t)y3_vmax(t0[1], s0[1]);
+        o[2] = (bf16_t)y3_vmax(t1[0], s1[0]);
+        o[3] = (bf16_t)y3_vmax(t1[1], s1[1]);
+        *reinterpret_cast<bf16x4 *>(sP + pl * (BN * 2) + (((cl >> 3) ^ (pl & (OCT - 1))) << 4) + ((cl >> 2) & 1) * 8) = o;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                    // P: the tile is parked
+    const int m0 = (mfirst + j * mstride) * BM;
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+      const int pl = tid / OCT + i * (NC / OCT);
+      const int oc = tid % OCT;
+      const int m = m0 + pl;
+      const u32x4 v = *reinterpret_cast<const u32x4 *>(sP + pl * (BN * 2) + ((oc ^ (pl & (OCT - 1))) << 4));
+      if (m < p.M) *reinterpret_cast<u32x4 *>(p.out + ((long long)m * p.out_ld + n0 + oc * 8) * 2) = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);              // park reads done before this wave can reach the next tile's park
+  }
+}
+
+int wres_bn(const y3_op &op) {
+  if (op.in_c <= 256 && op.out_c % 128 == 0) return 128;
+  if (op.in_c <= 512 && op.out_c % 64 == 0) return 64;
+  return 0;
+}
+
+}  // namespace
+
+// 1x1 stride-1 bf16 conv without shortcut operand whose weight panel fits LDS
+bool y3_conv1x1_wres_supported(const y3_op &op) {
+  if (op.kind != Y3_OP_CONV || op.dtype != Y3_BF16 || op.ksize != 1 || op.stride != 1 || op.pad != 0) return false;
+  if (op.flags & (Y3_F_RESIDUAL | Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT)) return false;
+  if (op.in_c % 64 != 0 || op.in_c < 128 || op.in_ld % 8 != 0 || op.out_ld % 8 != 0 || op.k_ld < op.in_c) return false;
+  if (((uintptr_t)op.d_in | (uintptr_t)op.d_out) % 16 != 0) return false;
+  return wres_bn(op) != 0;
+}
+
+// ... on a map large enough to keep every CU streaming at least two pixel tiles (below that the tiled kernels are as good)
+bool y3_conv1x1_wres_pays(const y3_op &op) {
+  const int bn = wres_bn(op);
+  return bn != 0 && (long long)y3_ceil_div(op.batch * op.in_h * op.in_w, 128) * (op.out_c / bn) >= 512;
+}
+
+int y3_launch_conv1x1_wres(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s, const char **kernel_name,
+                           bool dry_run) {
+  Y3_REQUIRE(y3_conv1x1_wres_supported(op), "conv block %d: not a shape for the weights-resident 1x1 kernel", op.block_idx);
+  const int bn = wres_bn(op);
+  *kernel_name = bn == 128 ? "conv1x1_wres_bf16_128x128" : "conv1x1_wres_bf16_128x64";
+  if (dry_run) return Y3_OK;
+  WresArgs a;
+  a.in = static_cast<const char *>(d_in);
+  a.wgt = static_cast<const char *>(op.d_weight);
+  a.scale = op.d_scale; a.bias = op.d_bias;
+  a.out = static_cast<char *>(op.d_out);
+  a.zero = static_cast<const char *>(d_zero);
+  a.M = op.batch * op.in_h * op.in_w;
+  a.Cin = op.in_c; a.in_ld = op.in_ld; a.Cout = op.out_c; a.out_ld = op.out_ld; a.k_ld = op.k_ld;
+  a.n_kt = op.in_c / 64;
+  a.n_tiles = op.out_c / bn;
+  a.m_tiles = y3_ceil_div(a.M, 128);
+  a.flags = op.flags;
+  static Y3DeviceOnce once;
+  int n_cu = 0;
+  {
+    const int rc = once.run([]() -> int {
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wres_kernel<128>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wres_kernel<64>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      return Y3_OK;
+    }, &n_cu);
+    if (rc != Y3_OK) return rc;
+  }
+  const size_t lds = (size_t)a.n_kt * bn * 128 + (size_t)128 * bn * 2 + (size_t)4 * 128 * 128;
+  Y3_REQUIRE(lds <= 160 * 1024, "conv block %d: weight panel does not fit LDS", op.block_idx);
+  int grid = n_cu - n_cu % a.n_tiles;                // one workgroup per CU, a whole number of them per channel tile
+  const long long tiles = (long long)a.m_tiles * a.n_tiles;
+  if (grid > tiles) grid = (int)tiles;
+  if (bn == 128) hipLaunchKernelGGL(conv1x1_wres_kernel<128>, dim3(grid), dim3(512), lds, s, a);
+  else hipLaunchKernelGGL(conv1x1_wres_kernel<64>, dim3(grid), dim3(512), lds, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}

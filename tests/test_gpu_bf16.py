@@ -214,6 +214,10 @@ HALO = {"auto_mask": 157 | 2048}     # round-1 selection: the halo kernel whatev
     ("yolov3-spp", 416, 416, 2, HALO, ("conv_halo_ws", "maxpool_spp", "head_decode")),
     # batch 8: 76^2 and 38^2 stay on the halo kernel by themselves, 19^2 goes to the implicit GEMM
     ("yolov3", 608, 608, 8, None, ("conv_halo_ws", "conv_igemm3", "head_decode")),
+    # the weights-resident persistent 1x1 kernel on every layer it supports (bit 13; by itself it starts at 512 tiles)
+    ("yolov3", 608, 608, 2, {"auto_mask": 157 | 8192}, ("conv1x1_wres_bf16_128x128", "conv1x1_wres_bf16_128x64")),
+    ("yolov3", 352, 480, 3, {"auto_mask": 157 | 8192}, ("conv1x1_wres_bf16_128x128", "conv1x1_wres_bf16_128x64")),
+    ("yolov3-spp", 416, 416, 1, {"auto_mask": 157 | 8192}, ("conv1x1_wres",)),
 ])
 def test_bf16_every_block_teacher_forced(model, h, w, batch, options, kernels):
     frames = synth_frames(1000 + h + w + batch, batch, h, w)

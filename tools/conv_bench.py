@@ -45,7 +45,7 @@ LAYERS = [
 
 # knob sets (y3_set_tuning) compared per layer; auto_mask 0 = implicit GEMM everywhere, 21 = halo kernel where it fits,
 # +128 = 2-D patch kernel for rows wider than 128 px
-BASE = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 0, "halo_persistent": 0}
+BASE = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 0, "halo_persistent": 0}   # auto_mask 0: no rerouting at all
 VARIANTS = [
     ("igemm_v2", dict(BASE)),
     ("halo_ws", dict(BASE, auto_mask=21)),
@@ -58,6 +58,7 @@ VARIANTS = [
     ("halo2", dict(BASE, auto_mask=21 | 256)),
     ("halo_ws_256", dict(BASE, auto_mask=21 | 512)),
     ("igemm_v2_bn128", dict(BASE, auto_mask=1024)),
+    ("wres_1x1", dict(BASE, auto_mask=8192)),           # weights-resident persistent 1x1 kernel wherever it is supported
 ]
 
 
