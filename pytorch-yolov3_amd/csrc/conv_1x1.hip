@@ -215,10 +215,14 @@ bool y3_conv1x1_wres_supported(const y3_op &op) {
   return wres_bn(op) != 0;
 }
 
-// ... on a map large enough to keep every CU streaming at least two pixel tiles (below that the tiled kernels are as good)
+// ... where it measured faster than the tiled kernels (profiles/r02h_convbench_1x1.txt, batch 16): ONE channel tile (every
+// workgroup streams the activations once: 256 -> 128 at 76^2 14.3 against 18.9 us, 128 -> 64 at 152^2 23.3 against 28.9 us
+// = 6.1 TB/s) on a map large enough to keep every CU streaming at least two pixel tiles.  With several channel tiles
+// (512 -> 256 at 38^2 as 4 x 64 channels, 384 -> 128 as 2 x 64) every tile's workgroups re-read the activations and the
+// 64 x 32 wave tiles feed the matrix pipe worse: 17.9 against 14.2 us, 26.1 against 23.9 us.
 bool y3_conv1x1_wres_pays(const y3_op &op) {
   const int bn = wres_bn(op);
-  return bn != 0 && (long long)y3_ceil_div(op.batch * op.in_h * op.in_w, 128) * (op.out_c / bn) >= 512;
+  return bn != 0 && op.out_c == bn && (long long)y3_ceil_div(op.batch * op.in_h * op.in_w, 128) >= 512;
 }
 
 int y3_launch_conv1x1_wres(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s, const char **kernel_name,
