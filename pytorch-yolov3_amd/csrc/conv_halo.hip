@@ -26,8 +26,6 @@
 // -- every wave loading and computing in lock step, ping-pong wave groups, 32-channel chunks with a
 // deeper ring -- measured 5-25 % slower (profiles/r01_convbench_v2_vs_halo.txt,
 // profiles/r01_convbench_variants.txt) and were removed.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -1060,13 +1058,12 @@ __global__ __launch_bounds__(384, 3) void conv_halo2_kernel(HaloArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave >= NC / 64;
 
-  // Tile order.  Each XCD gets one contiguous run of tile ids (y3_xcd_remap).  n-major: a run walks the pixel tiles of
-  // ONE 128-channel weight panel (1.2 MB at 19^2, 0.6 MB at 38^2), which then stays in that XCD's 4 MiB L2 while the
-  // activations stream past; m-major: a run shares the halo and cycles through all weight panels (9.4 MB at 19^2).
+  // Tile order: each XCD gets one contiguous run of tile ids (y3_xcd_remap) that shares the halo and cycles through the
+  // weight panels.  (The other order -- a run walks the pixel tiles of ONE weight panel, which then stays in that XCD's
+  // L2 -- measured the same: 748 against 713 TFLOP/s at 38^2, 629 against 614 at 19^2.)
   const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
-  const int m_tiles = gridDim.x / p.n_tiles;
-  const int m0 = (p.hr_pad & 1 ? tile % m_tiles : tile / p.n_tiles) * BM;
-  const int n0 = (p.hr_pad & 1 ? tile / m_tiles : tile % p.n_tiles) * BN;
+  const int m0 = (tile / p.n_tiles) * BM;
+  const int n0 = (tile % p.n_tiles) * BN;
   const int nit = p.nchunks * 9;
 
   const int wm = (wave & 3) / WAVES_N, wn = (wave & 3) % WAVES_N;
@@ -1429,13 +1426,6 @@ int launch_halo2(const HaloArgs &a0, hipStream_t s) {
     if (rc != Y3_OK) return rc;
   }
   const dim3 grid(y3_ceil_div(a.M, 128) * a.n_tiles);
-  if (getenv("Y3_HALO2_LDS")) lds = (size_t)atoi(getenv("Y3_HALO2_LDS"));   // experiment: > 80 KiB forces one workgroup per CU
-  if (getenv("Y3_HALO2_NMAJOR")) a.hr_pad |= 1;         // experiment: hr_pad is a multiple of 16, bit 0 carries the tile order
-  if (getenv("Y3_DEBUG_OCC")) {
-    int nb = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_halo2_kernel<T, 3>, 384, lds);
-    fprintf(stderr, "conv_halo2: W=%d lds=%zu blocks/CU=%d grid=%u\n", a.W, lds, nb, grid.x);
-  }
   hipLaunchKernelGGL((conv_halo2_kernel<T, 3>), grid, dim3(384), lds, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;

@@ -218,6 +218,10 @@ HALO = {"auto_mask": 157 | 2048}     # round-1 selection: the halo kernel whatev
     ("yolov3", 608, 608, 2, {"auto_mask": 157 | 8192}, ("conv1x1_wres_bf16_128x128", "conv1x1_wres_bf16_128x64")),
     ("yolov3", 352, 480, 3, {"auto_mask": 157 | 8192}, ("conv1x1_wres_bf16_128x128", "conv1x1_wres_bf16_128x64")),
     ("yolov3-spp", 416, 416, 1, {"auto_mask": 157 | 8192}, ("conv1x1_wres",)),
+    # THE BENCHMARKED CONFIGURATION, block by block: 16 frames of 608 x 608 with bench.py's plan options (256-pixel halo
+    # tiles in several rounds of workgroups, the weights-resident 1x1 kernel by itself, the stride-2 layer on igemm3)
+    ("yolov3", 608, 608, 16, {"auto_mask": 157 | 512}, ("conv_halo_ws_bf16_256x128", "conv1x1_wres_bf16_128x128",
+                                                        "conv1x1_wres_bf16_128x64", "conv_igemm3", "conv_patch", "head_decode")),
 ])
 def test_bf16_every_block_teacher_forced(model, h, w, batch, options, kernels):
     frames = synth_frames(1000 + h + w + batch, batch, h, w)
