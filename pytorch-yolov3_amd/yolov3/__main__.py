@@ -58,16 +58,23 @@ def _abspath(p):
 
 
 def _write_frames(frames, fps, path):
+    """``-o``: .mp4 like the reference's write_mp4 (__main__.py:13-33) when OpenCV is there; .avi (Motion JPEG) / .y4m
+    through this package's own writers; anything else is taken as a directory of PNG frames."""
+    from .stream import _cv2
+    cv2 = _cv2()
     if path.endswith(".mp4"):
-        from .stream import _cv2
-        cv2 = _cv2()
         if cv2 is None:
-            raise RuntimeError("writing .mp4 needs OpenCV (cv2), which is not installed; give a directory instead")
+            raise RuntimeError("writing .mp4 needs OpenCV (cv2), which is not installed; give a .avi (Motion JPEG) or "
+                               ".y4m file name or a directory instead")
         h, w = frames[0].shape[:2]
         writer = cv2.VideoWriter(path, cv2.VideoWriter_fourcc(*"mp4v"), int(fps), (w, h))
         for frame in frames:
             writer.write(frame)
         writer.release()
+        return
+    if path.lower().endswith((".avi", ".y4m")):
+        from .videoio import write_video
+        write_video(path, frames, fps)
         return
     from PIL import Image
     os.makedirs(path, exist_ok=True)
@@ -113,6 +120,7 @@ def main(argv=None):
                 stream.draw_boxes(image, bbox_tlbr, class_idx=class_idx, class_names=class_names)
                 frames.append(image)
     elif args["video"]:
+        fps = stream.video_fps(args["video"], fps)
         results = stream.detect_in_video(net, args["video"], device=device, prob_thresh=args["prob_thresh"],
                                          nms_iou_thresh=args["iou_thresh"], class_names=class_names,
                                          frames=frames, show_video=False, batch_size=args["batch_size"])

@@ -8,8 +8,9 @@ separate HIP streams (each with its own activation arena and detection buffers),
 only earns its throughput on batches; results are yielded in frame order and are identical to
 calling ``inference()`` on every frame by itself.
 
-Decoding / display are not part of the GPU path: images are decoded with PIL; video files and
-cameras need OpenCV, which this image does not ship -- those entry points raise a RuntimeError
+Decoding / display are not part of the GPU path: images are decoded with PIL; video files are read with OpenCV
+when it is installed (any codec) and otherwise by ``videoio.py`` (Motion-JPEG AVI and YUV4MPEG2, pure Python);
+cameras and windows need OpenCV, which this image does not ship -- those entry points raise a RuntimeError
 that says so instead of silently doing something else.
 """
 import colorsys
@@ -123,8 +124,25 @@ def detect_in_images(net, path, batch_size=16, prob_thresh=0.05, nms_iou_thresh=
     return names, results
 
 
+def video_fps(filepath, default=25.0):
+    """Frame rate of a video file (``default`` for a directory of frames or when the container does not say)."""
+    if os.path.isdir(filepath):
+        return default
+    cv2 = _cv2()
+    if cv2 is not None:
+        cap = cv2.VideoCapture(filepath)
+        fps = cap.get(cv2.CAP_PROP_FPS)
+        cap.release()
+        return fps or default
+    from .videoio import open_video
+    fps, frames = open_video(filepath)
+    frames.close()
+    return fps or default
+
+
 def _video_frames(filepath):
-    """Frames of ``filepath``: a directory of images (sorted) or, with OpenCV present, a video file."""
+    """Frames of ``filepath``: a directory of images (sorted) or a video file (any codec with OpenCV, Motion-JPEG
+    AVI / YUV4MPEG2 without)."""
     if os.path.isdir(filepath):
         directory, names = list_image_files(filepath)
         for n in names:
@@ -132,8 +150,11 @@ def _video_frames(filepath):
         return
     cv2 = _cv2()
     if cv2 is None:
-        raise RuntimeError("reading video files needs OpenCV (cv2), which is not installed; pass a directory of "
-                           "frames or use detect_in_frames() with your own decoder")
+        from .videoio import open_video           # Motion-JPEG .avi / .y4m; raises ValueError for anything else
+        _, frames = open_video(filepath)
+        for frame in frames:
+            yield frame
+        return
     cap = cv2.VideoCapture(filepath)
     try:
         while True:

@@ -84,8 +84,10 @@ def test_cli_flags_mirror_the_reference():
 def test_video_and_camera_need_opencv_and_say_so(tmp_path):
     if stream._cv2() is not None:
         pytest.skip("OpenCV present")
-    with pytest.raises(RuntimeError, match="OpenCV"):
-        list(stream._video_frames(str(tmp_path / "clip.mp4")))
+    clip = tmp_path / "clip.mp4"
+    clip.write_bytes(b"\x00\x00\x00\x18ftypmp42" + b"\x00" * 64)
+    with pytest.raises(ValueError, match="OpenCV"):         # an .mp4 needs a codec library; .avi (MJPEG) / .y4m do not
+        list(stream._video_frames(str(clip)))
     with pytest.raises(RuntimeError, match="OpenCV"):
         stream.detect_in_cam(None)
 
@@ -230,3 +232,66 @@ def test_bench_refuses_more_gpus_than_visible_on_the_gpu_box():
     assert proc.returncode != 0
     assert "%d GPUs requested, %d visible" % (want, want - 1) in proc.stderr
     assert not [l for l in proc.stdout.splitlines() if l.startswith("{")]
+
+
+def test_video_io_without_opencv(tmp_path):
+    """Motion-JPEG AVI and YUV4MPEG2, the two containers readable without a codec library (yolov3/videoio.py): what
+    the writer produces the reader returns frame for frame (AVI: exactly the JPEG decode of every frame; y4m: YCbCr
+    4:2:0 round trip of smooth frames within a few grey levels), frame rates survive, other files are refused."""
+    import io
+    from PIL import Image
+    from yolov3 import videoio
+    yy, xx = np.mgrid[0:46, 0:62]
+    frames = [np.stack([(xx * 3 + i * 7) % 256, (yy * 5) % 256, (xx + yy + i) % 256], axis=-1).astype(np.uint8) for i in range(5)]
+    avi = str(tmp_path / "clip.avi")
+    videoio.write_avi_mjpeg(avi, frames, fps=30, quality=95)
+    fps, got = videoio.open_video(avi)
+    got = list(got)
+    assert fps == 30 and len(got) == 5
+    for src, g in zip(frames, got):
+        buf = io.BytesIO()
+        Image.fromarray(src[:, :, ::-1]).save(buf, format="JPEG", quality=95)
+        want = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))[:, :, ::-1]
+        assert g.shape == src.shape and np.array_equal(g, want)
+    ys, xs = np.mgrid[0:40, 0:60]
+    smooth = [np.stack([np.full((40, 60), 40 + 10 * i), (xs * 2 + 30) % 200, (ys * 3 + 20) % 200],
+                       axis=-1).astype(np.uint8) for i in range(3)]
+    y4m = str(tmp_path / "clip.y4m")
+    videoio.write_video(y4m, smooth, fps=24)
+    fps, got = videoio.open_video(y4m)
+    got = list(got)
+    assert fps == 24 and len(got) == 3
+    for src, g in zip(smooth, got):
+        assert g.shape == src.shape and np.abs(g.astype(int) - src.astype(int)).mean() < 4
+    grey = np.full((8, 8, 3), 128, np.uint8)          # a grey frame survives YCbCr exactly to +-1
+    videoio.write_y4m(y4m, [grey], 25)
+    assert np.abs(list(videoio.open_video(y4m)[1])[0].astype(int) - 128).max() <= 1
+    bad = tmp_path / "clip.mp4"
+    bad.write_bytes(b"\x00\x00\x00\x18ftypmp42" + b"\x00" * 64)
+    with pytest.raises(ValueError):
+        videoio.open_video(str(bad))
+    assert stream.video_fps(avi) == 30
+
+
+@pytest.mark.gpu
+def test_cli_video_file_round_trip(tmp_path):
+    """`yolov3 --video clip.avi -o out.avi` without OpenCV: detections equal running the decoded frames through
+    detect_in_frames, and the annotated output video has as many frames as the input."""
+    from yolov3 import videoio
+    from yolov3.__main__ import main as cli_main
+    frames = [f for f in synth_frames(11, 5, 208, 256)]
+    clip = str(tmp_path / "in.avi")
+    videoio.write_avi_mjpeg(clip, frames, fps=12)
+    decoded = list(videoio.open_video(clip)[1])
+    net = _net()
+    want = list(stream.detect_in_frames(net, decoded, batch_size=2, prob_thresh=0.2))
+    out = str(tmp_path / "out.avi")
+    out_json = str(tmp_path / "out.json")
+    rc = cli_main(["-V", clip, "-c", MODELS["yolov3-tiny"], "-w", golden_weights_path("yolov3-tiny"), "-p", "0.2",
+                   "--dtype", "float32", "-b", "2", "-o", out, "--json", out_json])
+    assert rc == 0
+    fps, annotated = videoio.open_video(out)
+    assert fps == 12 and len(list(annotated)) == 5
+    with open(out_json) as fh:
+        ds = json.load(fh)
+    assert len(ds["images"]) == 5 and len(ds["annotations"]) == sum(len(r[1]) for r in want)
