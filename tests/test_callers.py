@@ -14,6 +14,8 @@ from yolov3 import stream
 from yolov3.__main__ import build_parser, main as cli_main
 from yolov3.devtools import coco_util
 
+from yolov3.synthdata import synth_frames
+
 from golden_util import GOLDEN, MODELS, golden_weights_path, load_jpeg_bgr
 
 
