@@ -60,7 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip pcie_inclusive / other_configs / bf16_agreement (A/B runs, profiling)")
-    ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU-baseline work (bounded sample)")
+    ap.add_argument("--cpu-budget", type=float, default=22.0, help="seconds of CPU-baseline work (bounded sample)")
     ap.add_argument("--profile-passes", type=int, default=3)
     ap.add_argument("--dump-ops", default=None, help="write the per-op timing table (text) to this file")
     ap.add_argument("--streams", type=int, default=3,

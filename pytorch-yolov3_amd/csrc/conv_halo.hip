@@ -176,16 +176,24 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
 #pragma unroll
     for (int i = 0; i < NBL; ++i) b_src[i] = p.wgt + ((long long)(n0 + row0 + i * RPL) * p.k_ld) * ES + kc * 16;
     auto issue_weights = [&](int it, int ring_slot) {  // it = chunk*9 + tap; K offset = tap*Cin + chunk*BKE elements
-      const int chunk = it / 9, tap = it - chunk * 9;
-      const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
       char *dst = sB + ring_slot * B_BYTES + lwave * 1024;
+      if (it < nit) {
+        const int chunk = it / 9, tap = it - chunk * 9;
+        const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
 #pragma unroll
-      for (int i = 0; i < NBL; ++i)
-        __builtin_amdgcn_global_load_lds((gbl_void *)(b_src[i] + koff), (lds_void *)(dst + i * (NL * 16)), 16, 0, 0);
+        for (int i = 0; i < NBL; ++i)
+          __builtin_amdgcn_global_load_lds((gbl_void *)(b_src[i] + koff), (lds_void *)(dst + i * (NL * 16)), 16, 0, 0);
+      } else {
+        // past the last K-step: the instruction count per step stays (counted waits) but the pieces read the zero page --
+        // a real weight tile here is 16 KiB nobody uses, and the epilogue's barrier waits for it to land
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+          __builtin_amdgcn_global_load_lds((gbl_void *)p.zero, (lds_void *)(dst + i * (NL * 16)), 16, 0, 0);
+      }
     };
     for (int pass = 0; pass < p.na; ++pass) issue_halo_pass(0, pass, true);
 #pragma unroll
-    for (int j = 0; j <= D; ++j) issue_weights(j < nit ? j : nit - 1, j);
+    for (int j = 0; j <= D; ++j) issue_weights(j, j);
     Y3_COARSE(6);
     int tap = 0, chunk = 0, ring = (D + 1) % NSB;
 #pragma unroll 1
@@ -204,8 +212,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       const bool live = chunk + 1 < p.nchunks;
       const int p0 = 2 * tap < p.na ? 2 * tap : p.na - 1;
       const int p1 = 2 * tap + 1 < p.na ? 2 * tap + 1 : p.na - 1;
-      const int itw = it + 1 + D < nit ? it + 1 + D : nit - 1;
-      issue_weights(itw, ring);                       // ring == (it + 1 + D) % NSB: the slot of weights(it-1), free
+      issue_weights(it + 1 + D, ring);                // ring == (it + 1 + D) % NSB: the slot of weights(it-1), free
       if (live || !has_res) {
         issue_halo_pass(chunk + 1, p0, live);
         issue_halo_pass(chunk + 1, p1, live);
