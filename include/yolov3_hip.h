@@ -118,7 +118,8 @@ typedef struct y3_plan y3_plan;
  *   igemm_ns         LDS stages of version 3 (3 or 4; less means 3);  igemm_bm  64 = 64-pixel tiles for version 3 (bf16)
  *   use_graph        1: y3_plan_run replays a captured hipGraph (one launch per forward) on non-default streams;
  *                    0 [default]: every kernel is launched individually (measured 1 % faster at batch 16)
- *   fuse_stem        1 [default]: conv pairs flagged Y3_F_FUSE_NEXT run as one kernel where one exists
+ *   fuse_stem        1 [default]: conv pairs flagged Y3_F_FUSE_NEXT run as one kernel where one exists; 2: same, with the
+ *                    phase-by-phase form of the fused stem kernel (same bits, slower: A/B and tests); 0: never fused
  *   fuse_head        1 [default]: detection-head conv + YOLO decode in one launch (bf16 networks)
  *   fuse_spp         1 [default]: three stride-1 max-pools (5 / 9 / 13) of one tensor in one launch
  *   decode_lanes     4 [default]: four lanes per box in the bf16 decode; 1: sequential class loop everywhere

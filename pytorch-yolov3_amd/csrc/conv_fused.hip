@@ -25,6 +25,7 @@
 // the unfused kernels'; the stem's 27 products sit at other K positions of the MFMA, so a few stem values differ by
 // one bf16 ulp (tests/test_gpu_parity.py::test_fused_first_two_convs_output).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -118,33 +119,53 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
     bi0[ni] = *reinterpret_cast<const f32x4 *>(p.bi0 + ni * 16 + cq);
   }
 
-  // bytes of the frame patch of `tile` that this thread converts (kPre strided elements)
-  auto patch_fetch = [&](int tile, unsigned char (&pre)[kPre]) {
-    int t = tile;
-    const int tx = t % p.tiles_x;
-    t /= p.tiles_x;
-    const int ty = t % p.tiles_y;
-    const int b = t / p.tiles_y;
-    const int iy0 = 2 * ty * kTO - 2, ixb0 = (2 * tx * kTO - 2) * 3;
+  // bytes of the frame patch of a tile that this thread converts (kPre strided elements).  The patch geometry is the same
+  // for every tile, so the element -> (row, byte column) split is done once: per tile only the (uniform) base moves.
+  // Tiles that do not touch the frame border (80 % at 608 x 608) skip the bounds tests.
+  int pr_row[kPre], pr_col[kPre], pr_dst[kPre];
+  uint32_t pr_goff[kPre];
 #pragma unroll
-    for (int j = 0; j < kPre; ++j) {
-      const int i = tid + j * kThreads;
-      const int r = i / (kIR * 3), cb = i - r * (kIR * 3);
-      const int iy = iy0 + r, ixb = ixb0 + cb;
-      unsigned char v = 0;
-      if (i < kPatchElems && (unsigned)iy < (unsigned)p.H && ixb >= 0 && ixb < p.W * 3)
-        v = p.in[((long long)b * p.H + iy) * p.W * 3 + ixb];
-      pre[j] = v;
+  for (int j = 0; j < kPre; ++j) {
+    const int i = tid + j * kThreads;
+    const int r = i / (kIR * 3), cb = i - r * (kIR * 3);
+    pr_row[j] = r;
+    pr_col[j] = cb;
+    pr_goff[j] = (uint32_t)(r * p.W * 3 + cb);
+    pr_dst[j] = r * kInPitch + (cb / 3) * 4 + (cb % 3);
+  }
+  const bool pr_last_live = tid + (kPre - 1) * kThreads < kPatchElems;   // only the last strided element can be past the end
+  auto tile_coords = [&](int tile, int &tx, int &ty, int &b) {
+    int t = tile;
+    tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    ty = t % p.tiles_y;
+    b = t / p.tiles_y;
+  };
+  auto patch_fetch = [&](int tile, unsigned char (&pre)[kPre]) {
+    int tx, ty, b;
+    tile_coords(tile, tx, ty, b);
+    const int iy0 = 2 * ty * kTO - 2, ixb0 = (2 * tx * kTO - 2) * 3;
+    const bool interior = iy0 >= 0 && iy0 + kIR <= p.H && ixb0 >= 0 && ixb0 + kIR * 3 <= p.W * 3;
+    if (interior) {
+      const unsigned char *base = p.in + ((long long)b * p.H + iy0) * p.W * 3 + ixb0;   // uniform: scalar base + lane offset
+#pragma unroll
+      for (int j = 0; j < kPre; ++j) pre[j] = (j < kPre - 1 || pr_last_live) ? base[pr_goff[j]] : (unsigned char)0;
+    } else {
+#pragma unroll
+      for (int j = 0; j < kPre; ++j) {
+        const int iy = iy0 + pr_row[j], ixb = ixb0 + pr_col[j];
+        unsigned char v = 0;
+        if ((j < kPre - 1 || pr_last_live) && (unsigned)iy < (unsigned)p.H && ixb >= 0 && ixb < p.W * 3)
+          v = p.in[((long long)b * p.H + iy) * p.W * 3 + ixb];
+        pre[j] = v;
+      }
     }
   };
   auto patch_store = [&](int buf, const unsigned char (&pre)[kPre]) {
     bf16_t *dst = in_tile + buf * (kIR * kInPitch);
 #pragma unroll
-    for (int j = 0; j < kPre; ++j) {
-      const int i = tid + j * kThreads;
-      const int r = i / (kIR * 3), cb = i - r * (kIR * 3);
-      if (i < kPatchElems) dst[r * kInPitch + (cb / 3) * 4 + (cb % 3)] = lut[pre[j]];
-    }
+    for (int j = 0; j < kPre; ++j)
+      if (j < kPre - 1 || pr_last_live) dst[pr_dst[j]] = lut[pre[j]];
   };
 
   for (int i = tid; i < 2 * kIR * kInPitch / 2; i += kThreads) reinterpret_cast<uint32_t *>(in_tile)[i] = 0u;
@@ -158,39 +179,65 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
     patch_store(0, pre);
   }
   for (; tile < p.n_tiles; tile += gridDim.x) {
-    int t = tile;
-    const int tx = t % p.tiles_x;
-    t /= p.tiles_x;
-    const int ty = t % p.tiles_y;
-    const int b = t / p.tiles_y;
+    int tx, ty, b;
+    tile_coords(tile, tx, ty, b);
     const int oy0 = ty * kTO, ox0 = tx * kTO;
     __syncthreads();   // B1: this tile's input patch (and, first time, the weights) are in LDS; stem image is free
 
     // ---- phase 1: stem ------------------------------------------------------------------------------
     const bf16_t *patch = in_tile + buf * (kIR * kInPitch);
-    for (int f = wave; f < ((p.dbg & 1) ? 0 : kNFrag); f += kThreads / 64) {
-      const int q = f * 16 + fr;
-      const int qc = q < kNStem ? q : kNStem - 1;
-      const int sy = qc / kSR, sx = qc - sy * kSR;
-      const bf16_t *base = patch + sy * kInPitch + sx * 4;
-      const u32x2 lo = *reinterpret_cast<const u32x2 *>(base + off_lo);
-      const u32x2 hi = *reinterpret_cast<const u32x2 *>(base + off_hi);
-      const u32x2 s1 = *reinterpret_cast<const u32x2 *>(base + off_s1);
-      const bf16x8 xf0 = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
-      const bf16x8 xf1 = __builtin_bit_cast(bf16x8, fq == 0 ? u32x4{s1[0], s1[1], 0u, 0u} : u32x4{0u, 0u, 0u, 0u});
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[0], xf0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b[0], xf0, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[1], xf1, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b[1], xf1, acc1, 0, 0, 0);
-      const int gy = 2 * oy0 - 1 + sy, gx = 2 * ox0 - 1 + sx;          // stem pixel in frame coordinates
-      const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-      if (q < kNStem) {
+    // Three fragments per wave are in flight at a time: a fragment is one dependent chain LDS read -> two MFMAs ->
+    // scale / bias / leaky -> LDS write, and with two waves per SIMD a chain at a time left every latency exposed
+    // (690 cycles per fragment; the phase was 42 % of the kernel, profiles/r02m_stem_phases.txt).
+    // All stem pixels of a tile lie inside the frame unless the tile touches the frame border.
+    const bool stem_inside = 2 * oy0 - 1 >= 0 && 2 * oy0 - 1 + kSR <= p.H && 2 * ox0 - 1 >= 0 && 2 * ox0 - 1 + kSR <= p.W;
+    constexpr int kFG = 3;                                               // fragments in flight per wave
+    constexpr int kFragIters = (kNFrag + kThreads / 64 - 1) / (kThreads / 64);
+    static_assert(kFragIters % kFG == 0, "fragment groups");
+#pragma unroll 1
+    for (int g = 0; g < ((p.dbg & 1) ? 0 : kFragIters); g += kFG) {
+      u32x2 lo[kFG], hi[kFG], s1[kFG];
+      int qv[kFG], syv[kFG], sxv[kFG];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          u32x2 o = bn_leaky_bf16x4(ni ? acc1 : acc0, sc0[ni], bi0[ni]);
-          if (!inside) o = u32x2{0u, 0u};                               // the second conv's zero padding
-          *reinterpret_cast<u32x2 *>(stem + q * kStemPitch + (ni * 16 + cq) * 2) = o;
+      for (int j = 0; j < kFG; ++j) {
+        const int q = (wave + (g + j) * (kThreads / 64)) * 16 + fr;
+        const int qc = q < kNStem ? q : kNStem - 1;
+        const int sy = qc / kSR, sx = qc - sy * kSR;
+        const bf16_t *base = patch + sy * kInPitch + sx * 4;
+        lo[j] = *reinterpret_cast<const u32x2 *>(base + off_lo);
+        hi[j] = *reinterpret_cast<const u32x2 *>(base + off_hi);
+        s1[j] = *reinterpret_cast<const u32x2 *>(base + off_s1);
+        qv[j] = q;
+        syv[j] = sy;
+        sxv[j] = sx;
+      }
+      f32x4 acc0[kFG], acc1[kFG];
+#pragma unroll
+      for (int j = 0; j < kFG; ++j) {
+        const bf16x8 xf0 = __builtin_bit_cast(bf16x8, u32x4{lo[j][0], lo[j][1], hi[j][0], hi[j][1]});
+        acc0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[0], xf0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b[0], xf0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < kFG; ++j) {
+        const bf16x8 xf1 = __builtin_bit_cast(bf16x8, fq == 0 ? u32x4{s1[j][0], s1[j][1], 0u, 0u} : u32x4{0u, 0u, 0u, 0u});
+        acc0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[1], xf1, acc0[j], 0, 0, 0);
+        acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b[1], xf1, acc1[j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < kFG; ++j) {
+        if (qv[j] < kNStem) {
+          bool inside = true;
+          if (!stem_inside) {
+            const int gy = 2 * oy0 - 1 + syv[j], gx = 2 * ox0 - 1 + sxv[j];   // stem pixel in frame coordinates
+            inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+          }
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            u32x2 o = bn_leaky_bf16x4(ni ? acc1[j] : acc0[j], sc0[ni], bi0[ni]);
+            if (!inside) o = u32x2{0u, 0u};                             // the second conv's zero padding
+            *reinterpret_cast<u32x2 *>(stem + qv[j] * kStemPitch + (ni * 16 + cq) * 2) = o;
+          }
         }
       }
     }
@@ -256,6 +303,384 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised, pipelined form of the kernel above (the default).  Same arithmetic, same bits; what changes is WHO
+// does what WHEN.  The kernel above runs its phases one after the other in every wave -- stem, stride-2 conv, write-out
+// -- with four workgroup barriers per tile and two waves per SIMD: every LDS / MFMA / global latency of those dependent
+// chains is exposed (profiles/r02m_stem_phases.txt: 7 k cycles per 256 outputs for ~1.1 k instructions per wave; with
+// stem, conv, stores and patch handling all switched off 2 k cycles remain).  Here a workgroup owns 16 x 8 output
+// tiles, keeps TWO stem images (17 x 33 pixels each) in LDS, and splits its waves by role:
+//   waves 0-7   "conv":  stride-2 conv of tile t out of image t (one output row of 16 pixels x 64 channels each: 36
+//               MFMAs), then a wave-private write-out (the wave stages its own 16 pixels x 128 bytes and stores them as
+//               two 1 KiB runs);
+//   waves 8..   "stem":  fetch the input patch of tile t+2 (bytes in registers), compute the stem image of tile t+1
+//               from patch t+1 (MFMA + scale / bias / leaky, VALU bound), convert patch t+2 into LDS.
+// The matrix work of one tile and the vector work of the next run on the same SIMDs at the same time, twice the waves
+// hide each other's latencies, and ONE workgroup barrier per tile is left.  Patch geometry and the stem fragments' LDS
+// addresses do not depend on the tile and are computed once per workgroup.
+constexpr int kPX = 16, kPY = 8;                  // output tile: 16 wide, 8 tall (one output row per conv wave)
+constexpr int kPSX = 2 * kPX + 1;                 // stem columns per tile (33)
+constexpr int kPSY = 2 * kPY + 1;                 // stem rows per tile (17)
+constexpr int kPIX = kPSX + 2, kPIY = kPSY + 2;   // input patch 35 x 19 pixels
+constexpr int kPNStem = kPSX * kPSY;              // 561
+constexpr int kPNFrag = (kPNStem + 15) / 16;      // 36 fragments of 16 stem pixels
+constexpr int kPInBytes = kPIY * kInPitch * 2;    // one input patch (bf16): 5472 bytes
+constexpr int kPStemBytes = kPNStem * kStemPitch; // 44880
+constexpr int kPStage = 8 * 16 * 128;             // write-out staging: 8 conv waves x 16 pixels x 128 bytes
+constexpr int kPLds = 2 * kPInBytes + 2 * kPStemBytes + 64 * kW1Pitch + 512 + kPStage;
+static_assert(kPLds <= 160 * 1024, "LDS budget");
+static_assert(kPX == 16 && kPY == 8, "one 16-pixel output row per conv wave");
+
+template <int NC>   // conv waves (4: two output rows each, 8: one); the other 16 - NC waves are stem waves
+__global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
+  constexpr int NS = 16 - NC, NT = 1024;
+  constexpr int MR = kPY / NC;                                         // output rows per conv wave
+  constexpr int kIters = (kPNFrag + NS - 1) / NS;                      // stem fragments per stem wave
+  constexpr int kPairs = kPIY * ((kPIX * 3 + 1) / 2);                  // the patch as byte pairs: 19 rows x 53
+  constexpr int kPre = (kPairs + 64 * NS - 1) / (64 * NS);             // pairs per stem thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *in_tile = smem;                                                // [2][kPIY][kInPitch] bf16
+  char *stem0 = smem + 2 * kPInBytes;                                  // [2][kPNStem][kStemPitch]
+  char *w1s = stem0 + 2 * kPStemBytes;                                 // [64][kW1Pitch]
+  bf16_t *lut = reinterpret_cast<bf16_t *>(w1s + 64 * kW1Pitch);       // lut[v] = bf16(v / 255.0f)
+  char *stage = reinterpret_cast<char *>(lut) + 512;                   // [8][16][128]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int cq = fq * 4;
+  const bool is_stem = wave >= NC;
+
+  // ---- once per workgroup ----
+  for (int i = tid; i < 64 * 36; i += NT) {                            // second conv's weights: 36 chunks of 16 bytes per channel
+    const int co = i / 36, ch = i - co * 36;
+    *reinterpret_cast<u32x4 *>(w1s + co * kW1Pitch + ch * 16) =
+        *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.w1) + ((long long)co * p.k_ld1) * 2 + ch * 16);
+  }
+  for (int i = tid; i < 2 * kPInBytes / 4; i += NT) reinterpret_cast<uint32_t *>(in_tile)[i] = 0u;
+  if (tid < 256) lut[tid] = (bf16_t)((float)tid / 255.0f);
+  __syncthreads();   // the fourth channel of every patch pixel stays zero from here on
+  const int tile0 = blockIdx.x, stride = gridDim.x;
+  if (tile0 >= p.n_tiles) return;
+  // tile -> (tile column, tile row, frame): divisions once, then carried additions per step (a step advances by `stride`)
+  struct TilePos { int tile, tx, ty, b; };
+  auto pos_of = [&](int tile) {
+    TilePos t;
+    t.tile = tile;
+    t.tx = tile % p.tiles_x;
+    const int r = tile / p.tiles_x;
+    t.ty = r % p.tiles_y;
+    t.b = r / p.tiles_y;
+    return t;
+  };
+  const TilePos dpos = pos_of(stride);
+  auto advance = [&](TilePos &t) {
+    t.tile += stride;
+    t.tx += dpos.tx;
+    int c = t.tx >= p.tiles_x ? 1 : 0;
+    t.tx -= c ? p.tiles_x : 0;
+    t.ty += dpos.ty + c;
+    c = t.ty >= p.tiles_y ? 1 : 0;
+    t.ty -= c ? p.tiles_y : 0;
+    t.b += dpos.b + c;
+  };
+
+  if (is_stem) {
+    // =============================== stem waves ===============================
+    const int sw = wave - NC, stid = tid - 64 * NC;
+    bf16x8 w0a[2], w0b[2];                                             // stem weights, k = ky*12 + kx*4 + c (see above)
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = st * 32 + fq * 8 + j;
+        const int ky = k / 12, rem = k - ky * 12, kx = rem >> 2, c = rem & 3;
+        const bool live = k < 36 && c < 3;
+        const int kold = live ? ky * 9 + kx * 3 + c : 0;
+        const bf16_t za = p.w0[(0 + fr) * 32 + kold], zb = p.w0[(16 + fr) * 32 + kold];
+        w0a[st][j] = live ? za : (bf16_t)0.f;
+        w0b[st][j] = live ? zb : (bf16_t)0.f;
+      }
+    int off_lo, off_hi;                                                 // bytes, relative to the pixel's first patch element
+    {
+      const int k0 = fq * 8, k1 = fq * 8 + 4;
+      off_lo = ((k0 / 12) * kInPitch + (k0 % 12)) * 2;
+      off_hi = ((k1 / 12) * kInPitch + (k1 % 12)) * 2;
+    }
+    constexpr int off_s1 = (2 * kInPitch + 8) * 2;
+    f32x4 sc0[2], bi0[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      sc0[ni] = *reinterpret_cast<const f32x4 *>(p.sc0 + ni * 16 + cq);
+      bi0[ni] = *reinterpret_cast<const f32x4 *>(p.bi0 + ni * 16 + cq);
+    }
+    // fragments of this wave: f = sw + NS j; lane fr handles stem pixel q = 16 f + fr
+    int fr_patch[kIters];                                               // byte offset of the pixel's patch element 0
+    uint32_t fr_live = 0;                                               // bit j: q < kPNStem
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const int q = (sw + NS * j) * 16 + fr;
+      const int qc = q < kPNStem ? q : kPNStem - 1;
+      const int sy = qc / kPSX, sx = qc - sy * kPSX;
+      fr_patch[j] = (sy * kInPitch + sx * 4) * 2;
+      fr_live |= (q < kPNStem ? 1u : 0u) << j;
+    }
+    const int stem_wr = ((sw * 16 + fr) * kStemPitch) + cq * 2;        // + j * NS * 16 * kStemPitch + ni * 32
+    // input patch as byte PAIRS (half the registers per tile in flight): pair k of patch row r = bytes 2k, 2k + 1.
+    // pr_dst: LDS byte offset of the first byte's bf16 element | bit 0: the second byte skips the zero channel (its
+    // element is two further, not one); the last pair of a row only has its first byte inside the patch.
+    constexpr int kRowPairs = (kPIX * 3 + 1) / 2;                       // 53
+    int pr_dst[kPre];
+    uint32_t pr_goff[kPre];
+    uint32_t pr_one = 0;                                                // bit j: only the first byte of pair j is live
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) {
+      const int i = stid + j * 64 * NS;
+      const int r = i / kRowPairs, cb = 2 * (i - r * kRowPairs);
+      pr_goff[j] = (uint32_t)(r * p.W * 3 + cb);
+      pr_dst[j] = (r * kInPitch + (cb / 3) * 4 + (cb % 3)) * 2 | (cb % 3 == 2 ? 1 : 0);
+      pr_one |= (cb + 1 >= kPIX * 3 ? 1u : 0u) << j;
+    }
+    const bool pr_last_live = stid + (kPre - 1) * 64 * NS < kPairs;     // only the last strided pair can be past the end
+    const bool pairs_aligned = ((p.W * 3) & 1) == 0 && (reinterpret_cast<size_t>(p.in) & 1) == 0;
+    auto patch_fetch = [&](const TilePos &t, unsigned short (&pre)[kPre]) {
+      const int tx = t.tx, ty = t.ty, b = t.b;
+      const int iy0 = 2 * ty * kPY - 2, ixb0 = (2 * tx * kPX - 2) * 3;   // ixb0 is even
+      // fast path: the whole patch (and the byte after each row) lies inside the frame, 2-byte loads are aligned
+      const bool interior = pairs_aligned && iy0 >= 0 && iy0 + kPIY <= p.H && ixb0 >= 0 && ixb0 + 2 * kRowPairs <= p.W * 3;
+      if (interior) {
+        const unsigned char *base = p.in + ((long long)b * p.H + iy0) * p.W * 3 + ixb0;   // uniform base + lane offset
+#pragma unroll
+        for (int j = 0; j < kPre; ++j)
+          pre[j] = (j < kPre - 1 || pr_last_live) ? *reinterpret_cast<const unsigned short *>(base + pr_goff[j]) : (unsigned short)0;
+      } else {
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+          const int i = stid + j * 64 * NS;
+          const int r = i / kRowPairs, cb = 2 * (i - r * kRowPairs);
+          const int iy = iy0 + r, ixb = ixb0 + cb;
+          unsigned int v = 0;
+          if ((j < kPre - 1 || pr_last_live) && (unsigned)iy < (unsigned)p.H) {
+            const unsigned char *row = p.in + ((long long)b * p.H + iy) * p.W * 3;
+            if (ixb >= 0 && ixb < p.W * 3) v = row[ixb];
+            if (ixb + 1 >= 0 && ixb + 1 < p.W * 3 && cb + 1 < kPIX * 3) v |= (unsigned int)row[ixb + 1] << 8;
+          }
+          pre[j] = (unsigned short)v;
+        }
+      }
+    };
+    auto patch_store = [&](int buf, const unsigned short (&pre)[kPre]) {
+      char *dst = in_tile + buf * kPInBytes;
+#pragma unroll
+      for (int j = 0; j < kPre; ++j)
+        if (j < kPre - 1 || pr_last_live) {
+          char *d = dst + (pr_dst[j] & ~1);
+          *reinterpret_cast<bf16_t *>(d) = lut[pre[j] & 255];
+          if (!((pr_one >> j) & 1u)) *reinterpret_cast<bf16_t *>(d + 2 + 2 * (pr_dst[j] & 1)) = lut[pre[j] >> 8];
+        }
+    };
+    // stem image of one tile: kFG fragments in flight (LDS reads, two K steps each, scale / bias / leaky, LDS writes)
+    auto stem_image = [&](const char *patch, char *img, const TilePos &t) {
+      const int oy0 = t.ty * kPY, ox0 = t.tx * kPX;
+      const bool all_inside = 2 * oy0 - 1 >= 0 && 2 * oy0 - 1 + kPSY <= p.H && 2 * ox0 - 1 >= 0 && 2 * ox0 - 1 + kPSX <= p.W;
+      auto group = [&](auto g0, auto cnt) {
+        constexpr int g = decltype(g0)::value, G = decltype(cnt)::value;
+        u32x2 lo[G], hi[G], s1[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          const char *base = patch + fr_patch[g + j];
+          lo[j] = *reinterpret_cast<const u32x2 *>(base + off_lo);
+          hi[j] = *reinterpret_cast<const u32x2 *>(base + off_hi);
+          s1[j] = *reinterpret_cast<const u32x2 *>(base + off_s1);
+        }
+        f32x4 a0[G], a1[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          const bf16x8 xf0 = __builtin_bit_cast(bf16x8, u32x4{lo[j][0], lo[j][1], hi[j][0], hi[j][1]});
+          a0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[0], xf0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          a1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b[0], xf0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          // K step 1 only carries tap (2, 2) in k = 32..34 (lanes fq == 0); every other weight of the step is zero, so
+          // the data there only has to be finite: the same (valid) patch bytes again instead of selected zeros
+          const bf16x8 xf1 = __builtin_bit_cast(bf16x8, u32x4{s1[j][0], s1[j][1], s1[j][0], s1[j][1]});
+          a0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[1], xf1, a0[j], 0, 0, 0);
+          a1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b[1], xf1, a1[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          u32x2 o0 = bn_leaky_bf16x4(a0[j], sc0[0], bi0[0]);
+          u32x2 o1 = bn_leaky_bf16x4(a1[j], sc0[1], bi0[1]);
+          if (!all_inside) {                                            // uniform: tiles on the frame border only
+            const int q = (sw + NS * (g + j)) * 16 + fr;
+            const int qc = q < kPNStem ? q : kPNStem - 1;
+            const int sy = qc / kPSX, sx = qc - sy * kPSX;
+            const int gy = 2 * oy0 - 1 + sy, gx = 2 * ox0 - 1 + sx;
+            if (!((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)) {   // the second conv's zero padding
+              o0 = u32x2{0u, 0u};
+              o1 = u32x2{0u, 0u};
+            }
+          }
+          if ((fr_live >> (g + j)) & 1u) {
+            char *dst = img + stem_wr + (g + j) * (NS * 16 * kStemPitch);
+            *reinterpret_cast<u32x2 *>(dst) = o0;
+            *reinterpret_cast<u32x2 *>(dst + 32) = o1;
+          }
+        }
+      };
+      using std::integral_constant;
+      static_assert(kIters == 5 || kIters == 3, "fragment groups");
+      group(integral_constant<int, 0>{}, integral_constant<int, 3>{});
+      if constexpr (kIters == 5) group(integral_constant<int, 3>{}, integral_constant<int, 2>{});
+    };
+
+    // Input patches are fetched FOUR steps ahead of their conversion into LDS (a step is ~2 k cycles, an HBM miss under
+    // load more than that: with one step of distance the stem waves sat on vmcnt and the step took the memory latency).
+    // Four byte-register sets, one per tile in flight; the step loop is unrolled by four so that every set is addressed
+    // statically (set = step index mod 4; a set is refilled in the step after it was converted).
+    unsigned short pre[4][kPre];
+    TilePos fpos = pos_of(tile0);                                       // next tile whose patch is fetched
+    TilePos ipos = fpos;                                                // next tile whose stem image is computed
+    {
+      patch_fetch(fpos, pre[0]);
+      patch_store(0, pre[0]);
+      advance(fpos);
+      if (fpos.tile < p.n_tiles) {
+        patch_fetch(fpos, pre[1]);
+        patch_store(1, pre[1]);
+      }
+      advance(fpos);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();   // S1 (stem waves write the patches; everybody waits)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                                        // the patch of step i + 2 lives in set i % 4
+      if (fpos.tile < p.n_tiles) patch_fetch(fpos, pre[k]);
+      advance(fpos);
+    }
+    stem_image(in_tile, stem0, ipos);                                  // pipeline fill: image of the first tile
+    advance(ipos);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();   // S2
+    int par = 0;
+    Y3_STAMP_DECL
+    auto step = [&](auto setc) {                                        // false: no more tiles
+      constexpr int set = decltype(setc)::value;
+      // here: ipos = tile + stride (image to compute), fpos = tile + 5 stride (patch to fetch)
+      if (fpos.tile < p.n_tiles) patch_fetch(fpos, pre[(set + 3) & 3]);
+      advance(fpos);
+      Y3_STAMP(0);
+      const bool more = ipos.tile < p.n_tiles;
+      if (more) stem_image(in_tile + (par ^ 1) * kPInBytes, stem0 + (par ^ 1) * kPStemBytes, ipos);
+      advance(ipos);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      Y3_STAMP(1);
+      if (ipos.tile < p.n_tiles) patch_store(par, pre[set]);           // patch buffer `par` held this tile's patch: free
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      Y3_STAMP(2);
+      __builtin_amdgcn_s_barrier();   // T: image t+1 complete, image t read for the last time, patch t+2 stored
+      Y3_STAMP(3);
+      par ^= 1;
+      return more;
+    };
+    using std::integral_constant;
+    for (;;) {
+      if (!step(integral_constant<int, 0>{})) break;
+      if (!step(integral_constant<int, 1>{})) break;
+      if (!step(integral_constant<int, 2>{})) break;
+      if (!step(integral_constant<int, 3>{})) break;
+    }
+#ifdef Y3_STAMPS
+    if (tid == 64 * NC) for (int _i = 0; _i < 4; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]);
+#endif
+    return;
+  }
+
+  // =============================== conv waves ===============================
+  // operand addresses: output rows wave * MR + mr of the tile, pixel fr; tap (ky, kx) adds (ky * 33 + kx) * 80
+  const int a_rd = ((2 * wave * MR) * kPSX + 2 * fr) * kStemPitch + fq * 16;   // + mr * 2 * 33 * 80
+  const int b_rd = fr * kW1Pitch + fq * 16;                            // + nf * 16 * kW1Pitch + tap * 64
+  char *my_stage = stage + wave * (MR * 16 * 128);
+  f32x4 s1v[4], b1v[4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) {
+    s1v[nf] = *reinterpret_cast<const f32x4 *>(p.sc1 + nf * 16 + cq);
+    b1v[nf] = *reinterpret_cast<const f32x4 *>(p.bi1 + nf * 16 + cq);
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();     // S1
+  __builtin_amdgcn_s_barrier();     // S2
+  // write-out: lane -> (pixel, 16-byte channel chunk) of a row, as a 32-bit offset from the row's first pixel
+  uint32_t st_off[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) st_off[k] = (uint32_t)((((lane >> 3) + 8 * k) * p.out_ld + (lane & 7) * 8) * 2);
+  int par = 0;
+  Y3_STAMP_DECL
+  for (TilePos pos = pos_of(tile0); pos.tile < p.n_tiles; advance(pos)) {
+    const int b = pos.b;
+    const int oy0 = pos.ty * kPY, ox0 = pos.tx * kPX;
+    const char *img = stem0 + par * kPStemBytes;
+    f32x4 acc[MR][4];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) acc[mr][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      u32x4 xf[MR], wf[4];
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr)
+        xf[mr] = *reinterpret_cast<const u32x4 *>(img + a_rd + ((2 * mr + ky) * kPSX + kx) * kStemPitch);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+        wf[nf] = *reinterpret_cast<const u32x4 *>(w1s + b_rd + nf * 16 * kW1Pitch + tap * 64);
+#pragma unroll
+      for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+          acc[mr][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[nf]),
+                                                                __builtin_bit_cast(bf16x8, xf[mr]), acc[mr][nf], 0, 0, 0);
+    }
+    Y3_STAMP(4);
+    // write-out, wave-private: bn + leaky -> bf16 -> this wave's 16 pixels x 128 bytes per row -> two 1 KiB runs per row
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        const int co = nf * 16 + cq;
+        *reinterpret_cast<u32x2 *>(my_stage + mr * 2048 + fr * 128 + (((co >> 3) ^ (fr & 7)) << 4) + (co & 7) * 2) =
+            bn_leaky_bf16x4(acc[mr][nf], s1v[nf], b1v[nf]);
+      }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+      const int oy = oy0 + wave * MR + mr;
+      char *row = reinterpret_cast<char *>(p.out + (((long long)b * p.Ho + oy) * p.Wo + ox0) * p.out_ld);   // uniform
+      const bool full = ox0 + kPX <= p.Wo;                              // uniform
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int px = (lane >> 3) + 8 * k, ch = lane & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(my_stage + mr * 2048 + px * 128 + ((ch ^ (px & 7)) << 4));
+        if (oy < p.Ho && (full || ox0 + px < p.Wo)) *reinterpret_cast<u32x4 *>(row + st_off[k]) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    Y3_STAMP(5);
+    __builtin_amdgcn_s_barrier();   // T
+    Y3_STAMP(6);
+    par ^= 1;
+  }
+#ifdef Y3_STAMPS
+  if (tid == 0) {
+    for (int _i = 4; _i < 7; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]);
+    atomicAdd(&g_y3_stamps[7], 1ull);
+  }
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------
 // One residual block of Darknet-53 in one kernel, for the block whose 3x3 weights fit in LDS (64 -> 32 -> 64 channels,
@@ -482,9 +907,6 @@ int y3_launch_conv_fused_stem_s2(const y3_op &op0, const y3_op &op1, const void 
   a.sc1 = op1.d_scale; a.bi1 = op1.d_bias; a.flags1 = op1.flags;
   a.out = static_cast<bf16_t *>(op1.d_out);
   a.out_ld = op1.out_ld; a.Ho = op1.out_h; a.Wo = op1.out_w;
-  a.tiles_x = y3_ceil_div(a.Wo, kTO);
-  a.tiles_y = y3_ceil_div(a.Ho, kTO);
-  a.n_tiles = a.tiles_x * a.tiles_y * a.batch;
   a.dbg = 0;
   static Y3DeviceOnce once;
   int n_cu = 0;
@@ -492,12 +914,19 @@ int y3_launch_conv_fused_stem_s2(const y3_op &op0, const y3_op &op1, const void 
     const int rc = once.run([]() -> int {
       Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_stem_s2_fused_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_stem_s2_ws_kernel<4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kPLds));
       return Y3_OK;
     }, &n_cu);
     if (rc != Y3_OK) return rc;
   }
+  const bool pipelined = y3_opt().fuse_stem != 2;                      // fuse_stem 2: the phase-by-phase kernel (A/B)
+  a.tiles_x = y3_ceil_div(a.Wo, pipelined ? kPX : kTO);
+  a.tiles_y = y3_ceil_div(a.Ho, pipelined ? kPY : kTO);
+  a.n_tiles = a.tiles_x * a.tiles_y * a.batch;
   const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
-  hipLaunchKernelGGL(conv_stem_s2_fused_kernel, dim3(grid), dim3(kThreads), kLds, s, a);
+  if (pipelined) hipLaunchKernelGGL(conv_stem_s2_ws_kernel<4>, dim3(grid), dim3(1024), kPLds, s, a);
+  else hipLaunchKernelGGL(conv_stem_s2_fused_kernel, dim3(grid), dim3(kThreads), kLds, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -549,3 +978,5 @@ int y3_launch_conv_fused_resblock(const y3_op &op0, const y3_op &op1, hipStream_
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
+
+Y3_STAMP_READER(y3_debug_stamps_fused)

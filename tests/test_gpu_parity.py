@@ -533,6 +533,28 @@ def test_fused_first_two_convs_output(dim, batch):
     assert (d > 0).mean() < 0.2      # most values identical
 
 
+@pytest.mark.parametrize("dim,batch", [(608, 1), (96, 2), (80, 1), (48, 5), (16, 3)])
+def test_wave_specialised_stem_kernel_is_bit_identical_to_phase_kernel(dim, batch):
+    """The default fused stem kernel (conv waves + stem waves, two stem images in LDS, patches fetched four steps ahead)
+    does the arithmetic of the phase-by-phase kernel (`fuse_stem` = 2) in the same order: same bits, for full tiles,
+    partial tiles (80 -> 40 outputs = 2.5 tiles wide), frame borders, and fewer tiles than the prefetch distance."""
+    from yolov3 import _hip
+    lib = _hip.lib()
+    net = _net("yolov3", dtype="bf16")
+    dev = net._torch_device()
+    frames = synth_frames(5 + dim, batch, dim, dim)
+    try:
+        _hip.check(lib.y3_set_tuning(b"fuse_stem", 2))
+        phase, n0 = _first_two_convs_plan(net, frames, True, dev)
+        _hip.check(lib.y3_set_tuning(b"fuse_stem", 1))
+        ws, n1 = _first_two_convs_plan(net, frames, True, dev)
+    finally:
+        lib.y3_set_tuning(b"fuse_stem", 1)
+    assert n0 == n1 == "conv_stem_s2_fused_u8_bf16"
+    assert np.abs(phase).max() > 0
+    assert np.array_equal(phase, ws)
+
+
 @pytest.mark.parametrize("dim,batch", [(608, 2), (416, 1), (320, 3)])
 def test_fused_stem_and_stride2_conv_matches_unfused(dim, batch):
     """The first two convs of yolov3 / yolov3-spp run as one kernel (uint8 frames -> 32-channel stem kept in LDS ->
