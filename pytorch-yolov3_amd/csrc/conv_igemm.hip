@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "decode_core.h"
 
 namespace {
 
@@ -268,16 +269,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
 
 
 // YOLO decode of `rows` pixels whose float32 logits (conv sums with scale / bias already applied) are parked in LDS with
-// a row stride of LD floats (LD odd in units of banks: the per-box reads of adjacent lanes spread over the banks): the
-// arithmetic of yolo_decode_kernel<4> (four lanes per box).  Each operation rounds separately, like in
-// yolo_decode.hip (built with -ffp-contract=off).
+// a row stride of LD floats (LD odd in units of banks: the per-box reads of adjacent lanes spread over the banks): four
+// lanes per box, decode_core.h -- the same code as yolo_decode_kernel<4>.
 template <int NT, int LD>
 __device__ __forceinline__ void head_decode_rows(const IgemmArgs &p, const float *sL, int mbase, int rows, int tid) {
-#pragma clang fp contract(off)
   const int nbox = rows * p.y_anchors;
+  const uint32_t inv_a = (65536u + (uint32_t)p.y_anchors - 1u) / (uint32_t)p.y_anchors;   // box / anchors for box < 8192
   for (int t = tid; t < nbox * 4; t += NT) {
     const int box = t >> 2, sub = t & 3;
-    const int pl = box / p.y_anchors, a = box - pl * p.y_anchors;
+    const int pl = (int)(((uint32_t)box * inv_a) >> 16), a = box - pl * p.y_anchors;
     const long long m = (long long)mbase + pl;
     const bool live = m < p.M;
     const uint32_t um = (uint32_t)(live ? m : p.M - 1);
@@ -285,45 +285,17 @@ __device__ __forceinline__ void head_decode_rows(const IgemmArgs &p, const float
     const uint32_t rem = um - b * (uint32_t)p.HoWo;
     const uint32_t y = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
     const uint32_t x = rem - y * (uint32_t)p.Wo;
-    const float *t_ = sL + pl * LD + a * p.y_attr;
-    const int ncls = p.y_attr - 5;
-    const int per = (ncls + 3) >> 2;
-    const int c_lo = sub * per, c_hi = c_lo + per < ncls ? c_lo + per : ncls;
-    float mx = -INFINITY;
-    for (int c = c_lo; c < c_hi; ++c) mx = fmaxf(mx, t_[5 + c]);
-    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-    float sum = 0.f, best = -1.f;
-    int best_c = 0;
-    for (int c = c_lo; c < c_hi; ++c) {
-      const float e = expf(t_[5 + c] - mx);
-      sum += e;
-      if (e > best) {
-        best = e;
-        best_c = c;
-      }
-    }
-#pragma unroll
-    for (int d = 1; d <= 2; d <<= 1) {
-      const float os = __shfl_xor(sum, d, 64), ob = __shfl_xor(best, d, 64);
-      const int oc = __shfl_xor(best_c, d, 64);
-      sum += os;
-      if (ob > best || (ob == best && oc < best_c)) {
-        best = ob;
-        best_c = oc;
-      }
-    }
-    if (!live || sub != 0) continue;
-    const float bx = (1.0f / (1.0f + expf(-t_[0])) + (float)x) / (float)p.Wo;
-    const float by = (1.0f / (1.0f + expf(-t_[1])) + (float)y) / (float)p.Ho;
-    const float bw = (expf(t_[2]) * p.y_aw[a]) / p.y_net_w;
-    const float bh = (expf(t_[3]) * p.y_ah[a]) / p.y_net_h;
-    const float obj = 1.0f / (1.0f + expf(-t_[4]));
-    const float score = (best / sum) * obj;
+    float comp, score;
+    int best_c;
+    y3_decode_box4(sL + pl * LD + a * p.y_attr, p.y_attr, sub, (float)x, (float)y, (float)p.Wo, (float)p.Ho, p.y_aw[a],
+                   p.y_ah[a], p.y_net_w, p.y_net_h, comp, score, best_c);
+    if (!live) continue;
     const long long row = (long long)b * p.y_rows_total + p.y_row_offset + (long long)a * p.HoWo + (long long)y * p.Wo + x;
-    *reinterpret_cast<f32x4 *>(p.y_bbox + row * 4) = f32x4{bx, by, bw, bh};
-    p.y_prob[row] = score;
-    p.y_cls[row] = best_c;
+    p.y_bbox[row * 4 + sub] = comp;
+    if (sub == 2) {
+      p.y_prob[row] = score;
+      p.y_cls[row] = best_c;
+    }
   }
 }
 
@@ -355,10 +327,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
   constexpr int STAGE = (BM + BN) * RB;
   static_assert(MI >= 1 && NI >= 1 && A_CH >= 1 && B_CH >= 1, "tile too small");
   // the fp32 output tile is written out in EP passes of RP pixel rows each (it must fit in the stages)
-  constexpr int LDS_BYTES = 2 * STAGE;
+  // (the detection-head form parks its whole padded logit tile at once, so that the decode's passes are full)
+  constexpr int LDS_BYTES = DECODE && BM * (BN + 1) * 4 > 2 * STAGE ? BM * (BN + 1) * 4 : 2 * STAGE;
   constexpr int EP = (BM * BN * 4 + LDS_BYTES - 1) / LDS_BYTES <= 1 ? 1 : ((BM * BN * 4 + LDS_BYTES - 1) / LDS_BYTES <= 2 ? 2 : 4);
   constexpr int RP = BM / EP;
   static_assert(RP * BN * 4 <= LDS_BYTES && (RP % TM == 0 || TM % RP == 0), "epilogue tile must fit in the operand stages");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
@@ -1104,7 +1078,7 @@ bool y3_conv_head_decode_supported(const y3_op &op0, const y3_op &op1) {
 
 int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d_zero, hipStream_t s,
                                const char **kernel_name, bool dry_run) {
-  *kernel_name = "conv_head_decode_bf16_128x256";
+  *kernel_name = "conv_head_decode_bf16_64x256";
   if (dry_run) return Y3_OK;
   IgemmArgs a;
   a.in = static_cast<const char *>(op0.d_in);
@@ -1131,9 +1105,12 @@ int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d
   a.y_row_offset = op1.row_offset; a.y_rows_total = op1.rows_total;
   a.y_net_w = op1.net_w; a.y_net_h = op1.net_h;
   for (int i = 0; i < 8; ++i) { a.y_aw[i] = op1.anchor_w[i]; a.y_ah[i] = op1.anchor_h[i]; }
-  a.m_tiles = y3_ceil_div(a.M, 128);
+  // 64 pixels x all 255 channels per workgroup: 80 KiB of LDS (two operand stages; the padded logit tile of 64 x 257 floats
+  // is parked in them), so two workgroups share a CU and one's decode runs under the other's loads (128-pixel tiles, one
+  // per CU, measured equal in isolation: profiles/r02n_heads.txt)
   a.n_tiles = 1;
-  hipLaunchKernelGGL((conv_igemm2_kernel<bf16_t, 128, 256, 2, 4, 0, true>), dim3(a.m_tiles), dim3(512), 0, s, a);
+  a.m_tiles = y3_ceil_div(a.M, 64);
+  hipLaunchKernelGGL((conv_igemm2_kernel<bf16_t, 64, 256, 1, 4, 0, true>), dim3(a.m_tiles), dim3(256), 0, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }

@@ -12,6 +12,7 @@
 //   prob[row] = max_c softmax(tc)_c * sigmoid(to)       cls[row] = argmax (first on ties), int64
 // Built with -ffp-contract=off: each operation rounds like the reference's separate torch ops.
 #include "common.h"
+#include "decode_core.h"
 
 namespace {
 
@@ -36,10 +37,10 @@ __device__ __forceinline__ float sigmoidf_ref(float x) { return 1.0f / (1.0f + e
 constexpr int kPix = 32;
 
 // LANES threads per box.  LANES == 1: the reference's sequential class loop (float32 parity path).  LANES == 4
-// (bf16 throughput mode): the class range is split over four adjacent lanes -- maxima, exp-sums and the arg-max are
-// combined with xor-shuffles -- which quadruples the threads working out of the same LDS tile (the staging tile, not
-// registers, bounds the boxes in flight per CU); the exp-sum is then a tree of four partial sums instead of one
-// running sum, i.e. equal up to float32 rounding of the sum's last bits.
+// (bf16 throughput mode): decode_core.h -- the class range is split over four adjacent lanes (maxima, exp-sums and the
+// arg-max combined with quad DPP moves), which quadruples the threads working out of the same LDS tile (the staging
+// tile, not registers, bounds the boxes in flight per CU); the class exponentials use the hardware exp2 and the exp-sum
+// is a tree of four partial sums, i.e. the score is equal to ~1e-6 relative, the arg-max and the box are identical.
 template <int LANES>
 __global__ __launch_bounds__(LANES == 1 ? 256 : 384) void yolo_decode_kernel(YoloArgs p) {
   constexpr int NT = LANES == 1 ? 256 : 384;
@@ -72,18 +73,27 @@ __global__ __launch_bounds__(LANES == 1 ? 256 : 384) void yolo_decode_kernel(Yol
     const int b = (int)(pixc / ((long long)p.w * p.h));
     const float *t_ = sm + pl * lds_ld + a * p.n_attr;
 
-    const int ncls = p.n_attr - 5;
-    const int per = (ncls + LANES - 1) / LANES;
-    const int c_lo = sub * per, c_hi = c_lo + per < ncls ? c_lo + per : ncls;
-    float mx = -INFINITY;
-    for (int c = c_lo; c < c_hi; ++c) mx = fmaxf(mx, t_[5 + c]);
     if constexpr (LANES == 4) {
-      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      // bf16 networks: decode_core.h (shared with the fused head kernel)
+      float comp, score;
+      int best_c;
+      y3_decode_box4(t_, p.n_attr, sub, (float)x, (float)y, (float)p.w, (float)p.h, p.aw[a], p.ah[a], p.net_w, p.net_h, comp,
+                     score, best_c);
+      if (!live) continue;
+      const long long row = (long long)b * p.rows_total + p.row_offset + (long long)a * p.h * p.w + (long long)y * p.w + x;
+      p.bbox[row * 4 + sub] = comp;
+      if (sub == 2) {
+        p.prob[row] = score;
+        p.cls[row] = best_c;
+      }
+      continue;
     }
+    const int ncls = p.n_attr - 5;
+    float mx = -INFINITY;
+    for (int c = 0; c < ncls; ++c) mx = fmaxf(mx, t_[5 + c]);
     float sum = 0.f, best = -1.f;
     int best_c = 0;
-    for (int c = c_lo; c < c_hi; ++c) {
+    for (int c = 0; c < ncls; ++c) {
       const float e = expf(t_[5 + c] - mx);
       sum += e;
       if (e > best) {  // strict: first index wins ties, like torch.max
@@ -91,19 +101,7 @@ __global__ __launch_bounds__(LANES == 1 ? 256 : 384) void yolo_decode_kernel(Yol
         best_c = c;
       }
     }
-    if constexpr (LANES == 4) {
-#pragma unroll
-      for (int d = 1; d <= 2; d <<= 1) {
-        const float os = __shfl_xor(sum, d, 64), ob = __shfl_xor(best, d, 64);
-        const int oc = __shfl_xor(best_c, d, 64);
-        sum += os;                                       // both partners add the same two numbers: same result
-        if (ob > best || (ob == best && oc < best_c)) {  // lower class index wins ties
-          best = ob;
-          best_c = oc;
-        }
-      }
-    }
-    if (!live || sub != 0) continue;
+    if (!live) continue;
     const float bx = (sigmoidf_ref(t_[0]) + (float)x) / (float)p.w;
     const float by = (sigmoidf_ref(t_[1]) + (float)y) / (float)p.h;
     const float bw = (expf(t_[2]) * p.aw[a]) / p.net_w;

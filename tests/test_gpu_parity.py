@@ -593,7 +593,7 @@ def test_fused_head_conv_and_decode_matches_separate_kernels(model, dim, batch):
         net = _net(model, dtype="bf16")
         fused = {k: v.clone() for k, v in net.forward_frames(frames).items()}
         names = [r["kernel"] for r in net.plan_report()]
-        assert sum(k == "conv_head_decode_bf16_128x256" for k in names) == (2 if model == "yolov3-tiny" else 3)
+        assert sum(k == "conv_head_decode_bf16_64x256" for k in names) == (2 if model == "yolov3-tiny" else 3)
         _hip.check(lib.y3_set_tuning(b"fuse_head", 0))
         net2 = _net(model, dtype="bf16")
         plain = net2.forward_frames(frames)
