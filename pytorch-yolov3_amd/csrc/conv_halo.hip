@@ -969,24 +969,36 @@ __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int 
     const f32x4 sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
     const f32x4 bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
     const f32x4 bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      // residual first: its latency hides behind the LDS round trip
-      u32x4 resv[2];
-      f32x4 resf[2][2];
+    // shortcut operand: fetched ONE 16-pixel group ahead of its use (two register sets), so that a group's memory
+    // latency runs under the previous group's LDS round trip, arithmetic and stores instead of being waited out four
+    // times per tile (a tile here has only nine K-steps: the epilogue is a third of its time)
+    u32x4 resv[2][2];
+    f32x4 resf[2][2][2];
+    auto res_load = [&](int mi, int set) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int oy = oy0 + 2 * wm + (mi >> 1), ox = ox0 + (mi & 1) * 16 + (lane >> 3) + r * 8;
         const long long m = ((long long)tb * p.H + oy) * p.W + ox;
         if (has_res && oy < p.H && ox < p.W) {
           if constexpr (sizeof(T) == 2) {
-            resv[r] = *reinterpret_cast<const u32x4 *>(p.res + ((long long)m * p.res_ld + co) * ES);
+            resv[set][r] = *reinterpret_cast<const u32x4 *>(p.res + ((long long)m * p.res_ld + co) * ES);
           } else {
             const float *rp = reinterpret_cast<const float *>(p.res) + (long long)m * p.res_ld + co;
-            resf[r][0] = *reinterpret_cast<const f32x4 *>(rp);
-            resf[r][1] = *reinterpret_cast<const f32x4 *>(rp + 4);
+            resf[set][r][0] = *reinterpret_cast<const f32x4 *>(rp);
+            resf[set][r][1] = *reinterpret_cast<const f32x4 *>(rp + 4);
           }
         }
+      }
+    };
+    constexpr bool AHEAD = sizeof(T) == 2;             // (float32: the second register set spills at the 168-VGPR cap)
+    if constexpr (AHEAD) res_load(0, 0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (AHEAD) {
+        if (mi + 1 < MI) res_load(mi + 1, (mi + 1) & 1);
+      } else {
+        res_load(mi, 0);
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)                  // pixel fr, channels ni*16 + fq*4 .. +3; 16-B chunks XOR-swizzled
@@ -1004,12 +1016,12 @@ __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int 
         if (oy < p.H && ox < p.W) {
           if (has_res) {
             if constexpr (sizeof(T) == 2) {
-              const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[r]);
+              const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[AHEAD ? (mi & 1) : 0][r]);
 #pragma unroll
               for (int q = 0; q < 8; ++q) v[q] += (float)rv[q];
             } else {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) { v[q] += resf[r][0][q]; v[4 + q] += resf[r][1][q]; }
+              for (int q = 0; q < 4; ++q) { v[q] += resf[AHEAD ? (mi & 1) : 0][r][0][q]; v[4 + q] += resf[AHEAD ? (mi & 1) : 0][r][1][q]; }
             }
           }
           T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
