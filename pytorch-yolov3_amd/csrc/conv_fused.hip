@@ -8,7 +8,10 @@
 // input patch (6 % extra stem work), keeps them in LDS, and runs the stride-2 conv from there: HBM sees 18 MB of
 // input bytes and the 189 MB output only.
 //
-// Per tile (persistent workgroups, 8 waves, one per CU):
+// Two forms, same arithmetic and bits: conv_stem_s2_fused_kernel below runs the phases one after the other in all eight
+// waves (kept as `fuse_stem` = 2: A/B runs and tests); conv_stem_s2_ws_kernel further down -- the default -- splits sixteen
+// waves by role and overlaps the stem of tile t+1 with the conv of tile t.  The phases, per tile (first form: persistent
+// workgroups, 8 waves, one per CU):
 //   phase 1  stem: 69 fragments of 16 stem pixels.  The input patch is kept as 4 bf16 per pixel (B, G, R, 0), so a
 //            filter row is 12 contiguous elements and a lane's 8 consecutive K values are two aligned 8-byte LDS
 //            reads (k = ky*12 + kx*4 + c; K = 36 padded to 64 = two v_mfma_f32_16x16x32_bf16 steps per 16 channels,
