@@ -315,17 +315,50 @@ def lib_sha256():
         return hashlib.sha256(fh.read()).hexdigest()
 
 
+def device_code_sha256(path=None):
+    """sha256 over the gfx950 code objects inside the library (the clang offload bundles' device entries, in file order).
+    Kernel traffic depends on the device code only: host-side edits (a comment shifts the __LINE__ of an error message)
+    change the file's hash but not this one."""
+    import struct
+    if path is None:
+        from yolov3 import _hip
+        path = os.path.abspath(_hip.LIB_PATH)
+    with open(path, "rb") as fh:
+        data = fh.read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    h = hashlib.sha256()
+    pos, found = 0, 0
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            break
+        nent = struct.unpack_from("<Q", data, i + 24)[0]
+        off = i + 32
+        for _ in range(nent):
+            o, sz, tl = struct.unpack_from("<QQQ", data, off)
+            triple = data[off + 24:off + 24 + tl]
+            off += 24 + tl
+            if sz and not triple.startswith(b"host"):
+                h.update(data[i + o:i + o + sz])
+                found += 1
+        pos = i + 24
+    return h.hexdigest() if found else None
+
+
 def load_traffic_table():
     """HBM-side traffic per launch comes from separate rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a
     pass and counters cannot be read from inside this process): tools/traffic_pmc.sh -> profiles/r02_traffic.json,
-    which records the sha256 of the library it measured.  A table measured on another binary is not used."""
+    which records the sha256 of the library it measured and of its device code objects.  A table measured on other
+    kernels is not used."""
     try:
         with open(TRAFFIC_FILE) as fh:
             table = json.load(fh)
     except (OSError, ValueError):
         return None, "no traffic table"
-    if table.get("lib_sha256") != lib_sha256():
-        return None, "traffic table is from another build of libyolov3_hip.so (stale): null"
+    same = table.get("device_code_sha256") == device_code_sha256() if table.get("device_code_sha256") else \
+        table.get("lib_sha256") == lib_sha256()
+    if not same:
+        return None, "traffic table is from another build of libyolov3_hip.so's kernels (stale): null"
     return table, "HBM bytes per launch, rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE in separate passes (%s, same binary)" % (
         os.path.relpath(TRAFFIC_FILE, ROOT))
 
@@ -494,6 +527,7 @@ def main(argv=None):
             "roofline": roof,
             "cpu_baseline": None,
             "lib_sha256": lib_sha256()[:16],
+            "device_code_sha256": (device_code_sha256() or "")[:16],
         }
         if flops_frame:
             line["end_to_end_tflops"] = round(fps * flops_frame / 1e12, 2)

@@ -64,7 +64,10 @@ def main():
     f, w = per_launch(fetch[0], "FETCH_SIZE"), per_launch(write[0], "WRITE_SIZE")
     with open(os.path.join(ROOT, "pytorch-yolov3_amd", "lib", "libyolov3_hip.so"), "rb") as fh:
         sha = hashlib.sha256(fh.read()).hexdigest()
+    sys.path.insert(0, ROOT)
+    import bench
     table = {"lib_sha256": sha,
+             "device_code_sha256": bench.device_code_sha256(os.path.join(ROOT, "pytorch-yolov3_amd", "lib", "libyolov3_hip.so")),
              "_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_gpu.sh) over "
                         "bench.py --streams 1 with the benchmark's plan options; per-launch means; FETCH_SIZE x 2 (gfx950 counts "
                         "64 B per 128-B request for 16-B-per-lane streams: MI355X_MICROARCH.md, HBM), WRITE_SIZE as read; KiB -> bytes",
