@@ -617,6 +617,57 @@ def test_split_class_decode_matches_sequential_decode():
     torch.testing.assert_close(fast["class_prob"], seq["class_prob"], rtol=2e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("ncls,n_anchor,h,w", [(1, 3, 5, 7), (3, 1, 4, 4), (7, 2, 6, 5), (20, 3, 5, 5), (80, 3, 7, 6),
+                                               (81, 2, 3, 9), (6, 8, 2, 3)])
+@pytest.mark.parametrize("dtype", ["bf16", "float32"])
+def test_yolo_decode_op_any_class_count(dtype, ncls, n_anchor, h, w):
+    """The decode op alone (y3_op_run) against the oracle's YOLOLayer restatement for class counts other than COCO's 80:
+    the four-lanes-per-box form (bf16 networks: decode_core.h) keeps its 80-class lanes in registers and has a generic
+    loop with a ragged last lane for everything else; the float32 form is the sequential loop."""
+    import ctypes
+    from yolov3 import _hip
+    lib = _hip.lib()
+    _hip.require_gpu()
+    dev = torch.device("cuda", 0)
+    rng = np.random.RandomState(ncls * 131 + n_anchor)
+    batch, n_attr = 2, 5 + ncls
+    ld = (n_anchor * n_attr + 3) // 4 * 4
+    x = (rng.randn(batch, n_anchor * n_attr, h, w) * 2.0).astype(np.float32)
+    anchors = [(float(rng.randint(8, 200)), float(rng.randint(8, 200))) for _ in range(n_anchor)]
+    net_w, net_h = 32.0 * w, 32.0 * h
+    nhwc = np.zeros((batch, h, w, ld), dtype=np.float32)
+    nhwc[..., :n_anchor * n_attr] = x.transpose(0, 2, 3, 1)
+    d_in = torch.from_numpy(nhwc).to(dev)
+    rows = n_anchor * h * w
+    bbox = torch.zeros((batch, rows, 4), dtype=torch.float32, device=dev)
+    prob = torch.zeros((batch, rows), dtype=torch.float32, device=dev)
+    cls = torch.full((batch, rows), -1, dtype=torch.int64, device=dev)
+    zero = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    op = _hip.Y3Op()
+    op.kind, op.dtype, op.batch = _hip.OP_YOLO, (_hip.Y3_BF16 if dtype == "bf16" else _hip.Y3_F32), batch
+    op.in_h, op.in_w, op.in_c, op.in_ld = h, w, n_anchor * n_attr, ld
+    op.n_anchor, op.n_attr = n_anchor, n_attr
+    for i, (aw, ah) in enumerate(anchors):
+        op.anchor_w[i], op.anchor_h[i] = aw, ah
+    op.row_offset, op.rows_total = 0, rows
+    op.net_w, op.net_h = net_w, net_h
+    op.d_in, op.d_bbox, op.d_prob, op.d_cls = d_in.data_ptr(), bbox.data_ptr(), prob.data_ptr(), cls.data_ptr()
+    _hip.check(lib.y3_op_run(ctypes.byref(op), None, zero.data_ptr(), _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    bb, pr, ci = orc.yolo_decode(torch.from_numpy(x), anchors)
+    bb = bb.clone()
+    bb[..., 2] /= net_w                                   # Darknet.forward divides w, h by the network size
+    bb[..., 3] /= net_h
+    np.testing.assert_allclose(bbox.cpu().numpy(), bb.numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(prob.cpu().numpy(), pr.numpy(), rtol=1e-5, atol=1e-8)
+    got, want = cls.cpu().numpy(), ci.numpy()
+    differ = got != want
+    if differ.any():                                      # only where the top two class logits are within float rounding
+        t = x.reshape(batch, n_anchor, n_attr, h, w)[:, :, 5:].transpose(0, 1, 3, 4, 2).reshape(batch, rows, ncls)
+        top2 = np.sort(t[differ], axis=-1)[:, -2:]
+        assert np.all(top2[:, 1] - top2[:, 0] < 1e-5), "arg-max differs beyond a rounding tie"
+
+
 def test_graph_replay_equals_eager_launches():
     """With the plan option use_graph, y3_plan_run replays a captured hipGraph on non-default streams (one launch per
     forward instead of ~80); same bits as launching every kernel, for repeated calls and alternating inputs."""
