@@ -617,6 +617,73 @@ def test_split_class_decode_matches_sequential_decode():
     torch.testing.assert_close(fast["class_prob"], seq["class_prob"], rtol=2e-6, atol=1e-9)
 
 
+_HEAD_CFG = """[net]
+batch=1
+height=%(dim)d
+width=%(dim)d
+channels=3
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=2
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=128
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+size=1
+stride=1
+pad=1
+filters=%(filters)d
+activation=linear
+
+[yolo]
+mask = %(mask)s
+anchors = 10,13, 16,30, 33,23, 30,61
+classes=%(ncls)d
+num=4
+"""
+
+
+@pytest.mark.parametrize("ncls,mask", [(60, "0,1,2"), (23, "1,2,3,0"), (80, "0,1,2"), (122, "0,1")])
+def test_fused_head_other_class_counts(tmp_path, ncls, mask):
+    """Fused head conv + decode for heads that are not COCO's 3 x 85: generic class loop of the four-lane decode, 2-4
+    anchors per head, against the two-kernel path and against the bf16-emulating oracle."""
+    n_anchor = len(mask.split(","))
+    cfg = tmp_path / "head.cfg"
+    cfg.write_text(_HEAD_CFG % dict(dim=96, filters=n_anchor * (5 + ncls), mask=mask, ncls=ncls))
+    from yolov3.cfgparse import parse_config
+    blocks, net_info = parse_config(str(cfg))
+    params = W.synth_params(blocks, net_info, seed=3, obj_bias=-2.0, calib=None)
+    frames = synth_frames(900 + ncls, 3, 96, 96)
+    outs = {}
+    for fuse in (1, 0):
+        net = yolov3.Darknet(str(cfg), device="cuda", dtype="bf16", options={"fuse_head": fuse}).eval()
+        net.set_params(params)
+        outs[fuse] = {k: v.clone() for k, v in net.forward_frames(frames).items()}
+        names = [r["kernel"] for r in net.plan_report()]
+        # (heads of at most 128 channels keep the two kernels: the fused tile is 256 channels wide)
+        assert any("head_decode" in k for k in names) == (bool(fuse) and n_anchor * (5 + ncls) > 128), names
+    fused, plain = outs[1], outs[0]
+    assert torch.equal(fused["class_idx"], plain["class_idx"])
+    torch.testing.assert_close(fused["class_prob"], plain["class_prob"], rtol=2e-6, atol=1e-9)
+    torch.testing.assert_close(fused["bbox_xywh"], plain["bbox_xywh"], rtol=2e-6, atol=1e-9)
+    onet = orc.OracleDarknet(str(cfg)).set_params(params)
+    want = onet.forward(torch.from_numpy(orc.frames_to_input(list(frames))), emulate_bf16=True)
+    np.testing.assert_allclose(fused["bbox_xywh"].cpu().numpy(), want["bbox_xywh"].numpy(), rtol=5e-2, atol=5e-3)
+    d = np.abs(fused["class_prob"].cpu().numpy() - want["class_prob"].numpy())
+    assert d.max() < 3e-2 and np.median(d) < 2e-3, (d.max(), np.median(d))
+
+
 @pytest.mark.parametrize("ncls,n_anchor,h,w", [(1, 3, 5, 7), (3, 1, 4, 4), (7, 2, 6, 5), (20, 3, 5, 5), (80, 3, 7, 6),
                                                (81, 2, 3, 9), (6, 8, 2, 3)])
 @pytest.mark.parametrize("dtype", ["bf16", "float32"])
