@@ -243,6 +243,9 @@ class Workload(object):
         for i in range(max(warmup, self.nstream)):
             self.step(self.warm_frames, i, h2d)
         torch.cuda.synchronize()
+        if os.environ.get("Y3_BENCH_DEBUG_AFTER_WARMUP"):      # diagnostic libraries only (timing experiments)
+            from yolov3 import _hip
+            _hip.check(_hip.lib().y3_set_tuning(b"debug", int(os.environ["Y3_BENCH_DEBUG_AFTER_WARMUP"])))
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()

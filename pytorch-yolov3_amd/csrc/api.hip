@@ -29,6 +29,8 @@ static y3_options g_y3_defaults = {/*auto_mask*/ 157, /*halo_persistent*/ 0, /*i
                                    /*decode_lanes*/ 4, {0, 0, 0, 0, 0, 0}};
 static thread_local const y3_options *tl_y3_opt = nullptr;
 const y3_options &y3_opt() { return tl_y3_opt ? *tl_y3_opt : g_y3_defaults; }
+static int g_y3_debug = 0;
+int y3_debug_flags() { return g_y3_debug; }
 namespace {
 struct OptScope {   // the launchers called below this frame see the plan's options
   const y3_options *prev;
@@ -394,6 +396,7 @@ int y3_set_tuning(const char *key, int value) {
       {"fuse_spp", &g_y3_defaults.fuse_spp}, {"decode_lanes", &g_y3_defaults.decode_lanes}};
   for (auto &f : fields)
     if (!strcmp(key, f.name)) { *f.field = value; return Y3_OK; }
+  if (!strcmp(key, "debug")) { g_y3_debug = value; return Y3_OK; }   // read by diagnostic builds only
   y3_set_error("y3_set_tuning: unknown key %s", key);
   return Y3_ERR_INVALID;
 }

@@ -19,6 +19,9 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define Y3_WAVE 64
 #define Y3_LEAKY_SLOPE 0.1f
 
+// diagnostic builds only (y3_set_tuning("debug", v)): 0 in the product
+int y3_debug_flags();
+
 // thread-local error string shared by all translation units
 void y3_set_error(const char *fmt, ...);
 

@@ -687,6 +687,16 @@ __global__ __launch_bounds__(768, 3) void conv_halo_wsp_kernel(HaloArgs p, int n
       ring = ring_n;
     }
     __builtin_amdgcn_s_barrier();                      // E: every consumer is done reading the last chunk's halo
+#ifdef Y3_X_NOEPI
+    // timing-only experiment (y3_set_tuning("debug", 1) in this diagnostic build): no epilogue at all (results wrong)
+    if (p.flags & 0x40000000u) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+      continue;
+    }
+#endif
     // ---- epilogue, per wave: 16 pixels x 64 channels at a time through a private 4 KiB slice of that buffer ----
     float *sC = reinterpret_cast<float *>(sA + ((gchunk + 1) & 1) * p.a_bytes) + wave * 1024;
     const int oc = lane & 7;                           // 8-channel group of this lane's write-out items
@@ -961,6 +971,16 @@ __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int 
       ring = ring_n;
     }
     __builtin_amdgcn_s_barrier();                      // E: every consumer is done reading the last chunk's halo
+#ifdef Y3_X_NOEPI
+    // timing-only experiment (y3_set_tuning("debug", 1) in this diagnostic build): no epilogue at all (results wrong)
+    if (p.flags & 0x40000000u) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+      continue;
+    }
+#endif
     // ---- epilogue, per wave: 16 pixels x 64 channels at a time through a private 4 KiB slice of that buffer ----
     float *sC = reinterpret_cast<float *>(sA + ((gchunk + 1) & 1) * p.a_bytes) + wave * 1024;
     const int oc = lane & 7;                           // 8-channel group of this lane's write-out items
@@ -1573,7 +1593,7 @@ int y3_launch_conv_halo2(const y3_op &op, const void *d_in, const void *d_zero, 
   a.hr_pad = a.na = a.a_bytes = 0;
   fast_div((uint32_t)a.HW, a.mul_hw, a.sh_hw);
   fast_div((uint32_t)a.W, a.mul_w, a.sh_w);
-  a.flags = op.flags;
+  a.flags = op.flags | (y3_debug_flags() ? 0x40000000u : 0u);
   Y3_REQUIRE((long long)op.batch * a.HW < (1ll << 31), "conv block %d: too many pixels for the 32-bit tile index", op.block_idx);
   return bf ? launch_halo2<bf16_t>(a, s) : launch_halo2<float>(a, s);
 }
@@ -1612,7 +1632,7 @@ int y3_launch_conv_patch(const y3_op &op, const void *d_in, const void *d_zero, 
   a.n_tiles = op.out_c / 128;
   a.hr_pad = a.na = a.a_bytes = 0;
   a.mul_hw = a.sh_hw = a.mul_w = a.sh_w = 0;
-  a.flags = op.flags;
+  a.flags = op.flags | (y3_debug_flags() ? 0x40000000u : 0u);
   return bf ? launch_patch_wsp<bf16_t>(a, s) : launch_patch_wsp<float>(a, s);
 }
 
@@ -1644,7 +1664,7 @@ int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, h
   a.hr_pad = a.na = a.a_bytes = 0;
   fast_div((uint32_t)a.HW, a.mul_hw, a.sh_hw);
   fast_div((uint32_t)a.W, a.mul_w, a.sh_w);
-  a.flags = op.flags;
+  a.flags = op.flags | (y3_debug_flags() ? 0x40000000u : 0u);
   Y3_REQUIRE((long long)op.batch * a.HW < (1ll << 31), "conv block %d: too many pixels for the 32-bit tile index", op.block_idx);
   if (persistent) return launch_halo_wsp<bf16_t>(a, s);
   return bf ? launch_halo_ws<bf16_t>(a, s) : launch_halo_ws<float>(a, s);

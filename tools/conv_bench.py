@@ -82,6 +82,8 @@ def main():
         VARIANTS = [v for v in VARIANTS if v[0] in args.variants.split(",")]
     lib = _hip.lib()
     _hip.require_gpu()
+    if os.environ.get("Y3_CONV_BENCH_DEBUG"):          # diagnostic libraries only (timing experiments)
+        _hip.check(lib.y3_set_tuning(b"debug", int(os.environ["Y3_CONV_BENCH_DEBUG"])))
     dev = torch.device("cuda:0")
     bf = args.dtype == "bf16"
     tdt = torch.bfloat16 if bf else torch.float32
