@@ -110,7 +110,6 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
               return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3, 64);
             if ((am & 128) && op.ksize == 3 && op.stride == 1 && w > 128 && op.out_c >= 128 && y3_conv_patch_fits(op))
               return y3_launch_conv_patch(op, in, d_zero, s, name, dry_run);
-            if ((am & 256) && k3 && y3_conv_halo2_fits(op)) return y3_launch_conv_halo2(op, in, d_zero, s, name, dry_run);
             // Small grids (small maps x small batches): a halo tile is 192+ pixels x 128 channels, and below ~3/4 of a
             // tile per CU most of the chip idles through its long K loop; the 128 x 128 implicit GEMMs have more, shorter
             // workgroups.  tools/conv_bench.py at batch 1 / 4 / 8 (profiles/r02f_convbench_small_batches.txt): 512 -> 1024

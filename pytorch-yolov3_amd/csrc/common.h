@@ -244,9 +244,6 @@ bool y3_conv1x1_wres_pays(const y3_op &op);
 int y3_launch_conv1x1_wres(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s, const char **kernel_name,
                            bool dry_run);
 // two workgroups per CU: 128 x 128 tiles, single halo buffer, <= 80 KiB of LDS (conv_halo.hip)
-bool y3_conv_halo2_fits(const y3_op &op);
-int y3_launch_conv_halo2(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
-                         const char **kernel_name, bool dry_run);
 bool y3_conv_patch_fits(const y3_op &op);
 int y3_launch_conv_patch(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
                          const char **kernel_name, bool dry_run);

@@ -49,13 +49,12 @@ BASE = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 0, "halo_
 VARIANTS = [
     ("igemm_v2", dict(BASE)),
     ("halo_ws", dict(BASE, auto_mask=21)),
-    ("halo_wsp", dict(BASE, auto_mask=21, halo_persistent=1)),
+    ("halo_wsq", dict(BASE, auto_mask=21, halo_persistent=1)),      # persistent, epilogue handed to the loader waves
     ("patch_8x32", dict(BASE, auto_mask=21 | 128)),
     ("igemm_v3_ns3", dict(BASE, igemm_version=3, igemm_ns=3)),
     ("igemm_v3_ns4", dict(BASE, igemm_version=3, igemm_ns=4)),
     ("igemm_v3_bm64_ns4", dict(BASE, igemm_version=3, igemm_ns=4, igemm_bm=64)),
     ("igemm_v3_bm64_ns3", dict(BASE, igemm_version=3, igemm_ns=3, igemm_bm=64)),
-    ("halo2", dict(BASE, auto_mask=21 | 256)),
     ("halo_ws_256", dict(BASE, auto_mask=21 | 512)),
     ("igemm_v2_bn128", dict(BASE, auto_mask=1024)),
     ("wres_1x1", dict(BASE, auto_mask=8192)),           # weights-resident persistent 1x1 kernel wherever it is supported
