@@ -184,9 +184,9 @@ class Workload(object):
         cfg = os.path.join(ROOT, "pytorch-yolov3_amd", "models", model + ".cfg")
         self.cfg = cfg
         if options is None and nstream > 1:
-            # several batches in flight: the halo kernel's throughput tile choice (include/yolov3_hip.h, auto_mask bit 9)
+            # several batches in flight: the halo kernel's throughput tile choice (include/yolov3_hip.h: Y3_AM_HALO_TILE256)
             from yolov3 import _hip
-            options = {"auto_mask": _hip.options().auto_mask | 512}
+            options = {"auto_mask": _hip.options().auto_mask | _hip.AM_HALO_TILE256}
         self.options = options
         self.net = yolov3.Darknet(cfg, device=str(dev), dtype=dtype, options=options).eval()
         self.net.set_params(params)

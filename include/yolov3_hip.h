@@ -101,19 +101,33 @@ typedef struct y3_op {
 typedef struct y3_plan y3_plan;
 
 /*
+ * y3_options.auto_mask: per-layer kernel choice of the MFMA convolutions, one bit per rule (profiles/ holds the A/B tables
+ * behind every default).  Results do not depend on it: all MFMA conv kernels sum a layer in the same K order (channel chunk
+ * outermost, filter tap innermost), so a layer's output is bit-identical whichever of them runs.
+ */
+#define Y3_AM_HALO_WIDE 0x0001u      /* halo-reuse kernel for 3x3 stride-1 layers (Cin, Cout >= 128) with rows of more than 64 px */
+#define Y3_AM_IGEMM3_MID 0x0002u     /* wave-specialised implicit GEMM for such layers with rows of 33..64 px (if not HALO_MID)   */
+#define Y3_AM_HALO_NARROW 0x0004u    /* halo-reuse kernel for rows of <= 32 px                                                     */
+#define Y3_AM_IGEMM3_1X1_DEEP 0x0008u /* wave-specialised implicit GEMM for 1x1 layers with Cin >= 1024                            */
+#define Y3_AM_HALO_MID 0x0010u       /* halo-reuse kernel for rows of 33..64 px                                                    */
+#define Y3_AM_IGEMM3_NARROW 0x0020u  /* wave-specialised implicit GEMM for rows of <= 32 px (if not HALO_NARROW)                   */
+#define Y3_AM_IGEMM3_1X1_BM64 0x0040u /* 64-pixel tiles of it for bf16 1x1 layers with Cin >= 256 (A/B only)                       */
+#define Y3_AM_PATCH_WIDE 0x0080u     /* 2-D patch kernel (8 x 32 output tiles) for 3x3 stride-1 layers with rows wider than 128 px */
+#define Y3_AM_HALO_TILE256 0x0200u   /* halo kernel with 256-pixel tiles only: the THROUGHPUT choice of callers that keep several  */
+                                     /* batches in flight on their own streams (default: 192-pixel tiles where they shorten one forward) */
+#define Y3_AM_NO_BN_SHRINK 0x0400u   /* A/B: implicit-GEMM channel tiles by Cout only (no narrower tiles on small grids)           */
+#define Y3_AM_NO_SMALL_GRID 0x0800u  /* A/B: no small-grid / stride-2 rerouting (the round-1 selection)                            */
+#define Y3_AM_NO_WRES 0x1000u        /* A/B: never the weights-resident persistent 1x1 kernel                                      */
+#define Y3_AM_WRES_ALWAYS 0x2000u    /* tests: that kernel on every layer it supports, whatever the map size                       */
+#define Y3_AM_DEFAULT (Y3_AM_HALO_WIDE | Y3_AM_HALO_NARROW | Y3_AM_IGEMM3_1X1_DEEP | Y3_AM_HALO_MID | Y3_AM_PATCH_WIDE)   /* 157 */
+#define Y3_AM_IGEMM_ONLY 0u          /* LDS-DMA implicit GEMM (igemm_version) everywhere                                           */
+
+/*
  * Kernel-selection options of ONE plan (fixed when the plan is created).  y3_options_default() fills in the
- * library's defaults -- the measured-best choices, profiles/ -- as modified by y3_set_tuning(); results do not
- * depend on them beyond floating-point summation order.
- *   auto_mask        per-layer kernel choice bits, default 157: halo-reuse kernel for every 3x3 stride-1 conv it fits
- *                    (bit 0: rows > 64 px, bit 4: 33..64, bit 2: <= 32), the 2-D patch kernel for rows wider than
- *                    128 px (bit 7), the wave-specialised implicit GEMM for 1x1 layers with Cin >= 1024 (bit 3);
- *                    0 = implicit GEMM v2 everywhere; bits 1 / 5 / 6 route more layers to the wave-specialised
- *                    implicit GEMM (api.hip); bit 8: experimental two-workgroups-per-CU halo kernel; bit 9 (512): halo
- *                    kernel with 256-pixel tiles only -- the THROUGHPUT choice for callers that keep several batches
- *                    in flight on their own streams (default: 192-pixel tiles where they shorten a single forward);
- *                    bits 10 / 11 switch the small-grid choices off (narrower implicit-GEMM channel tiles / implicit GEMM
- *                    instead of the halo kernel when a layer has fewer than 192 halo tiles): A/B only
- *   halo_persistent  0 [default] one tile per workgroup, 1 persistent tile loop (bf16 networks; float32 keeps 0)
+ * library's defaults -- the measured-best choices, profiles/ -- as modified by y3_set_tuning().
+ *   auto_mask        Y3_AM_* bits, default Y3_AM_DEFAULT
+ *   unused0          (was halo_persistent: the persistent strip kernels measured slower twice and were removed,
+ *                    profiles/r03b_persistent_halo_wsq_investigation.txt; ignored)
  *   igemm_version    1 register-staged, 2 LDS-DMA double-buffered [default], 3 wave-specialised
  *   igemm_ns         LDS stages of version 3 (3 or 4; less means 3);  igemm_bm  64 = 64-pixel tiles for version 3 (bf16)
  *   use_graph        1: y3_plan_run replays a captured hipGraph (one launch per forward) on non-default streams;
@@ -125,7 +139,7 @@ typedef struct y3_plan y3_plan;
  *   decode_lanes     4 [default]: four lanes per box in the bf16 decode; 1: sequential class loop everywhere
  */
 typedef struct y3_options {
-  int32_t auto_mask, halo_persistent, igemm_version, igemm_ns, igemm_bm;
+  int32_t auto_mask, unused0, igemm_version, igemm_ns, igemm_bm;
   int32_t use_graph, fuse_stem, fuse_head, fuse_spp, decode_lanes;
   int32_t reserved[6];
 } y3_options;
@@ -163,7 +177,7 @@ double y3_plan_op_bytes(const y3_plan *plan, int op_index);
 int y3_conv_path(const y3_op *op);
 
 /* A/B measurements only (tools/conv_bench.py, bench.py --tuning): changes ONE field of the process-wide DEFAULT
- * options by name ("auto_mask", "halo_persistent", "igemm_version", "igemm_ns", "igemm_bm", "use_graph", "fuse_stem",
+ * options by name ("auto_mask", "igemm_version", "igemm_ns", "igemm_bm", "use_graph", "fuse_stem",
  * "fuse_head", "fuse_spp", "decode_lanes").  Plans created afterwards without explicit options pick it up; existing
  * plans keep the options they were created with.                                                                  */
 int y3_set_tuning(const char *key, int value);

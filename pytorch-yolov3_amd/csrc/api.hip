@@ -14,23 +14,27 @@ namespace {
 thread_local char g_err[512] = "";
 }
 
-// Default options (y3_options_default / y3_set_tuning).  auto_mask, per-layer kernel choice for the MFMA convs
-// (tools/conv_bench.py tables in profiles/): bit 0: wave-specialised halo kernel for 3x3 s1 layers with rows wider than
-// 64; bit 1: wave-specialised igemm (3 stages) for 3x3 layers with rows of 33..64; bit 2: halo kernel for rows <= 32;
-// bit 3: wave-specialised igemm for 1x1 layers with Cin >= 1024; bit 4: halo kernel for rows of 33..64 instead;
-// bit 5: wave-specialised igemm for rows <= 32 instead; bit 7: 2-D patch kernel (8 x 32 output tiles) for 3x3 stride-1
-// layers with rows wider than 128 px; bit 6: wave-specialised igemm with 64-pixel tiles (3 stages, two workgroups per CU)
-// for bf16 1x1 layers with Cin >= 256; bit 8: the two-workgroups-per-CU halo kernel (128 x 128 tiles) wherever it fits
-// (rows of up to 62 px; slower, experiment); bit 9: 256-pixel halo tiles only (throughput mode, conv_halo.hip); bit 10: implicit-GEMM channel tiles by Cout only (no
-// shrinking on small grids); bit 11: no small-grid / stride-2 rerouting (round-1 selection); bit 12: no weights-resident 1x1 kernel (conv_1x1.hip), bit 13: that kernel
-// on every layer it supports, whatever the map size (tests).  157 = measured best end to end (profiles/r01_ab_kernel_selection.txt).
-static y3_options g_y3_defaults = {/*auto_mask*/ 157, /*halo_persistent*/ 0, /*igemm_version*/ 2, /*igemm_ns*/ 2,
+// Default options (y3_options_default / y3_set_tuning); the auto_mask bits are named in include/yolov3_hip.h (Y3_AM_*).
+static y3_options g_y3_defaults = {/*auto_mask*/ (int32_t)Y3_AM_DEFAULT, /*unused0*/ 0, /*igemm_version*/ 2, /*igemm_ns*/ 2,
                                    /*igemm_bm*/ 0, /*use_graph*/ 0, /*fuse_stem*/ 1, /*fuse_head*/ 1, /*fuse_spp*/ 1,
                                    /*decode_lanes*/ 4, {0, 0, 0, 0, 0, 0}};
 static thread_local const y3_options *tl_y3_opt = nullptr;
 const y3_options &y3_opt() { return tl_y3_opt ? *tl_y3_opt : g_y3_defaults; }
 static int g_y3_debug = 0;
 int y3_debug_flags() { return g_y3_debug; }
+
+// CU count of the current device (256 on an MI355X; 256 as well when no device is visible: dry runs on a CPU box)
+int y3_device_cus() {
+  static int cus[32] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) { (void)hipGetLastError(); return 256; }
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
 namespace {
 struct OptScope {   // the launchers called below this frame see the plan's options
   const y3_options *prev;
@@ -92,37 +96,40 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
       switch (conv_path(op)) {
         case 0: {
           if (y3_opt().auto_mask) {
-            const int am = y3_opt().auto_mask, w = op.in_w;
+            const unsigned am = (unsigned)y3_opt().auto_mask;
+            const int w = op.in_w;
             const bool k3 = op.ksize == 3 && op.stride == 1 && op.in_c >= 128 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32);
             const bool halo_ok = k3 && y3_conv_halo_ws_fits(op);
             bool want_halo = false, want_ws = false;
-            if (k3 && w > 64) want_halo = am & 1;
-            else if (k3 && w > 32) { want_halo = am & 16; want_ws = am & 2; }
-            else if (k3) { want_halo = am & 4; want_ws = am & 32; }
+            if (k3 && w > 64) want_halo = am & Y3_AM_HALO_WIDE;
+            else if (k3 && w > 32) { want_halo = am & Y3_AM_HALO_MID; want_ws = am & Y3_AM_IGEMM3_MID; }
+            else if (k3) { want_halo = am & Y3_AM_HALO_NARROW; want_ws = am & Y3_AM_IGEMM3_NARROW; }
             else if (op.ksize == 1 && op.in_c >= 1024 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32))
               // (not below 64 tiles of 128 x 128: yolov3-tiny's 1024 -> 256 at 13^2 x 8 frames is 22 of them; the LDS-DMA
               // version with narrower channel tiles has four times the workgroups)
-              want_ws = (am & 8) && ((am & 2048) || (long long)y3_ceil_div(op.batch * op.out_h * op.out_w, 128) * y3_ceil_div(op.out_c, 128) >= 64);
-            if (!(am & 4096) && y3_conv1x1_wres_supported(op) && ((am & 8192) || y3_conv1x1_wres_pays(op)))
+              want_ws = (am & Y3_AM_IGEMM3_1X1_DEEP) &&
+                        ((am & Y3_AM_NO_SMALL_GRID) || (long long)y3_ceil_div(op.batch * op.out_h * op.out_w, 128) * y3_ceil_div(op.out_c, 128) >= y3_device_cus() / 4);
+            if (!(am & Y3_AM_NO_WRES) && y3_conv1x1_wres_supported(op) && ((am & Y3_AM_WRES_ALWAYS) || y3_conv1x1_wres_pays(op)))
               return y3_launch_conv1x1_wres(op, in, d_zero, s, name, dry_run);
-            if ((am & 64) && op.ksize == 1 && op.in_c >= 256 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32) &&
+            if ((am & Y3_AM_IGEMM3_1X1_BM64) && op.ksize == 1 && op.in_c >= 256 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32) &&
                 op.dtype == Y3_BF16)
               return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3, 64);
-            if ((am & 128) && op.ksize == 3 && op.stride == 1 && w > 128 && op.out_c >= 128 && y3_conv_patch_fits(op))
+            if ((am & Y3_AM_PATCH_WIDE) && op.ksize == 3 && op.stride == 1 && w > 128 && op.out_c >= 128 && y3_conv_patch_fits(op))
               return y3_launch_conv_patch(op, in, d_zero, s, name, dry_run);
             // Small grids (small maps x small batches): a halo tile is 192+ pixels x 128 channels, and below ~3/4 of a
             // tile per CU most of the chip idles through its long K loop; the 128 x 128 implicit GEMMs have more, shorter
             // workgroups.  tools/conv_bench.py at batch 1 / 4 / 8 (profiles/r02f_convbench_small_batches.txt): 512 -> 1024
             // at 19^2 x 8 frames (128 tiles) 615 TFLOP/s on the halo kernel, 722 on the wave-specialised implicit GEMM;
             // in float32 (yolov3-tiny's 13^2 layers at batch 8) 66 against 93 on the LDS-DMA implicit GEMM.
+            // (Which kernel runs changes speed only: every MFMA conv kernel sums in the same K order.)
             const long long halo_tiles = (long long)y3_ceil_div(op.batch * op.in_h * op.in_w, 192) * (op.out_c / 128);
-            const bool small_grid = !(am & 2048) && k3 && halo_tiles < 192;
+            const bool small_grid = !(am & Y3_AM_NO_SMALL_GRID) && k3 && halo_tiles < (3 * y3_device_cus()) / 4;
             if (small_grid && op.dtype == Y3_BF16) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
-            if (want_halo && halo_ok && !small_grid) return y3_launch_conv_halo(op, in, d_zero, s, name, dry_run, y3_opt().halo_persistent != 0);
+            if (want_halo && halo_ok && !small_grid) return y3_launch_conv_halo(op, in, d_zero, s, name, dry_run);
             if (want_ws) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
             // 3x3 stride-2 layer with 256 input channels (76^2 -> 38^2): 865 against 762 TFLOP/s on the wave-specialised
             // implicit GEMM at batch 16; the other stride-2 layers measured faster on the LDS-DMA version
-            if (!(am & 2048) && op.ksize == 3 && op.stride == 2 && op.in_c == 256 && op.out_c >= 128 && op.dtype == Y3_BF16 &&
+            if (!(am & Y3_AM_NO_SMALL_GRID) && op.ksize == 3 && op.stride == 2 && op.in_c == 256 && op.out_c >= 128 && op.dtype == Y3_BF16 &&
                 !(op.flags & Y3_F_OUT_F32) && (long long)op.batch * op.out_h * op.out_w >= 16384)
               return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
           }
@@ -388,7 +395,7 @@ double y3_plan_op_bytes(const y3_plan *plan, int op_index) {
 int y3_set_tuning(const char *key, int value) {
   if (!key) return Y3_ERR_INVALID;
   struct { const char *name; int32_t *field; } fields[] = {
-      {"auto_mask", &g_y3_defaults.auto_mask}, {"halo_persistent", &g_y3_defaults.halo_persistent},
+      {"auto_mask", &g_y3_defaults.auto_mask},
       {"igemm_version", &g_y3_defaults.igemm_version}, {"igemm_ns", &g_y3_defaults.igemm_ns},
       {"igemm_bm", &g_y3_defaults.igemm_bm}, {"use_graph", &g_y3_defaults.use_graph},
       {"fuse_stem", &g_y3_defaults.fuse_stem}, {"fuse_head", &g_y3_defaults.fuse_head},

@@ -21,6 +21,8 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // diagnostic builds only (y3_set_tuning("debug", v)): 0 in the product
 int y3_debug_flags();
+// CU count of the current device (api.hip); the launchers' grid-size heuristics scale with it
+int y3_device_cus();
 
 // thread-local error string shared by all translation units
 void y3_set_error(const char *fmt, ...);
@@ -237,13 +239,13 @@ int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d
 // halo-reuse 3x3 kernel (conv_halo.hip): whether it can take this conv, and its launcher
 bool y3_conv_halo_ws_fits(const y3_op &op);
 int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
-                        const char **kernel_name, bool dry_run, bool persistent);
+                        const char **kernel_name, bool dry_run);
 // 1x1 conv with LDS-resident weights, persistent workgroups (conv_1x1.hip)
 bool y3_conv1x1_wres_supported(const y3_op &op);
 bool y3_conv1x1_wres_pays(const y3_op &op);
 int y3_launch_conv1x1_wres(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s, const char **kernel_name,
                            bool dry_run);
-// two workgroups per CU: 128 x 128 tiles, single halo buffer, <= 80 KiB of LDS (conv_halo.hip)
+// 2-D patch form of the halo kernel for rows wider than 128 pixels (conv_halo.hip)
 bool y3_conv_patch_fits(const y3_op &op);
 int y3_launch_conv_patch(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
                          const char **kernel_name, bool dry_run);

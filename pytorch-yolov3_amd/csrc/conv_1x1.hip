@@ -257,7 +257,9 @@ int y3_launch_conv1x1_wres(const y3_op &op, const void *d_in, const void *d_zero
   }
   const size_t lds = (size_t)a.n_kt * bn * 128 + (size_t)128 * bn * 2 + (size_t)4 * 128 * 128;
   Y3_REQUIRE(lds <= 160 * 1024, "conv block %d: weight panel does not fit LDS", op.block_idx);
-  int grid = n_cu - n_cu % a.n_tiles;                // one workgroup per CU, a whole number of them per channel tile
+  // one workgroup per CU, a whole number of them per channel tile (at least one each: more channel tiles than CUs just
+  // means more than one workgroup per CU in turn)
+  int grid = a.n_tiles > n_cu ? a.n_tiles : n_cu - n_cu % a.n_tiles;
   const long long tiles = (long long)a.m_tiles * a.n_tiles;
   if (grid > tiles) grid = (int)tiles;
   if (bn == 128) hipLaunchKernelGGL(conv1x1_wres_kernel<128>, dim3(grid), dim3(512), lds, s, a);

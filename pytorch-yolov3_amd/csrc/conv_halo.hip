@@ -13,19 +13,17 @@
 // 256 + 2W + 2 input pixels that ALL nine taps of those outputs touch -- once.  Tap (ky,kx) of
 // output pixel p is halo row  p + ky*W + kx, so the nine K-steps of a chunk read the same LDS
 // image at nine row offsets.  Row-wrap / image-border taps (the zero padding): conv_halo_ws_kernel
-// and its persistent variant redirect the lane's fragment address to an all-zero row of the halo
-// image (no data instructions).  Only the weight tile (128 rows x
+// redirects the lane's fragment address to an all-zero row of the halo image (no data instructions).  Only the weight tile (128 rows x
 // 128 B) changes per K-step; it streams through a 3- or 4-slot LDS ring.  Bytes through the LDS-DMA
 // path per FLOP drop ~3x versus the 128x128 implicit GEMM.
 //
-// Three kernels: conv_halo_ws_kernel (raster strip, one tile per workgroup; default for rows of up
-// to 128 pixels), conv_halo_wsp_kernel (same, persistent tile loop; faster alone, slower with several
-// batches in flight) and conv_patch_wsp_kernel (persistent, 8 x 32 output tiles with a 2-D input
-// patch and no fragment masking; default for wider rows, where the strip's halo outgrows LDS).
-// Earlier schedules
-// -- every wave loading and computing in lock step, ping-pong wave groups, 32-channel chunks with a
-// deeper ring -- measured 5-25 % slower (profiles/r01_convbench_v2_vs_halo.txt,
-// profiles/r01_convbench_variants.txt) and were removed.
+// Two kernels: conv_halo_ws_kernel (raster strip, one tile per workgroup; default for rows of up to 128 pixels) and
+// conv_patch_wsp_kernel (persistent, 8 x 32 output tiles with a 2-D input patch and no fragment masking; default for
+// wider rows, where the strip's halo outgrows LDS).  Measured slower and removed (history keeps them): schedules where
+// every wave loads and computes in lock step, ping-pong wave groups, 32-channel chunks with a deeper ring
+// (profiles/r01_convbench_*.txt); two workgroups per CU with 128 x 128 tiles; two persistent forms of
+// the strip kernel, the second with the epilogue in registers and the finished tile drained by the loader waves
+// (profiles/r03b_persistent_halo_wsq_investigation.txt).
 #include "common.h"
 
 namespace {
@@ -48,7 +46,6 @@ struct HaloArgs {
   int hr_pad;          // halo rows, padded to a multiple of the loader's rows-per-pass
   int na;              // loader passes per halo (= glds per thread per halo)
   int a_bytes;         // hr_pad * 128
-  int gap;             // persistent strip kernel: bytes between halo buffer 1 and the ring (staging area >= 64 KiB)
   uint32_t mul_hw, sh_hw, mul_w, sh_w;   // n / d == (umulhi(n, mul) + n) >> sh  for n < 2^31
   uint32_t flags;
 };
@@ -119,13 +116,8 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
   static_assert(NSB == 3 || NSB == 4, "weight ring has 3 or 4 slots");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef WS_X_LAYOUT
-  char *sA = smem;
-  char *sB = smem + 2 * p.a_bytes;
-#else
   char *sB = smem;                                    // [NSB][BN][128]
   char *sA = smem + NSB * B_BYTES;                    // [2][hr_pad][128]
-#endif
 
   Y3_STAMP_DECL
   const int tid = threadIdx.x;
@@ -210,24 +202,16 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       // youngest halo slices in flight (they are not needed before the next chunk, and a slice issued at step s is
       // covered by the wait of step s+1): only the weights' landing sits on the barrier's critical path.
       // (guaranteed landed at B(it): the weights issued D steps ago; halo slices issued D + 1 or more steps ago)
-#ifdef WSQ_X_NODMA
-      if (it == 0) wait_vmcnt<0>();
-#else
       if (D == 2) { if (it == 0) wait_vmcnt<NBL>(); else if (it == 1) wait_vmcnt_n<PER>(); else wait_vmcnt_n<PER + HPS>(); }
       else { if (it == 0) wait_vmcnt<0>(); else wait_vmcnt_n<HPS>(); }
-#endif
       Y3_COARSE(3);
       __builtin_amdgcn_s_barrier();
       Y3_COARSE(4);
       const bool live = chunk + 1 < p.nchunks;
       const int p0 = 2 * tap < p.na ? 2 * tap : p.na - 1;
       const int p1 = 2 * tap + 1 < p.na ? 2 * tap + 1 : p.na - 1;
-#ifdef WSQ_X_NODMA
-      if (false) {
-#else
       issue_weights(it + 1 + D, ring);                // ring == (it + 1 + D) % NSB: the slot of weights(it-1), free
       if (live || !has_res) {
-#endif
         issue_halo_pass(chunk + 1, p0, live);
         issue_halo_pass(chunk + 1, p1, live);
       } else {
@@ -235,10 +219,8 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
         // per step for the counted waits).  They stream the tile's SHORTCUT operand instead -- into the idle halo
         // buffer, where nobody reads it: the point is that the epilogue's residual loads (issued after the K loop with
         // nothing left to hide their latency) then hit L2.  Residual layers ran 4-9 % below identical layers without.
-#ifndef WSQ_X_NODMA
         issue_res_slice(2 * tap, chunk + 1);
         issue_res_slice(2 * tap + 1, chunk + 1);
-#endif
       }
       ring = ring + 1 == NSB ? 0 : ring + 1;
       if (++tap == 9) { tap = 0; ++chunk; }
@@ -253,11 +235,6 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     // the younger MFMA wave of each SIMD loses every issue arbitration to its older partner (age order); a static
     // priority for that half evens the pair out (MI355X_MICROARCH.md, two waves per SIMD, item 4): +1-5 % measured
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#ifdef WS_X_STAG
-    const bool stag = wave >= 4;                      // waves 4-7 run half a K-step behind (barrier between the step's halves)
-#else
-    const bool stag = false;
-#endif
     uint32_t tapmask[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -348,7 +325,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     int tap = 0, chunk = 0, ring = 0;
 #pragma unroll 1
     for (int it = 0; it < nit; ++it) {
-      if (it && !stag) {
+      if (it) {
         __builtin_amdgcn_s_barrier();                 // B(it): weights(it+1) landed; slot of weights(it-1) released
         Y3_STAMP(0);
       }
@@ -359,23 +336,12 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
 #define Y3_W0(slot) do {} while (0)
 #endif
       __builtin_amdgcn_sched_barrier(0);
-#ifdef WSQ_X_NOREAD
-#pragma unroll
-      for (int q = 0; q < MI; ++q) { asm volatile("" : "+v"(xf0[q]), "+v"(xf1[q])); }
-#pragma unroll
-      for (int q = 0; q < NI; ++q) { asm volatile("" : "+v"(wf0[q]), "+v"(wf1[q])); }
-      mma_all(xf0, wf0);
-      mma_all(xf1, wf1);
-      continue;
-#endif
       read_frags1(xf1, wf1, sB + ring * B_BYTES);
       mma_all(xf0, wf0);
       interleave();
       __builtin_amdgcn_sched_barrier(0);
       Y3_W0(2);
       __builtin_amdgcn_s_waitcnt(0xC07F);
-      if (stag && it + 1 < nit) __builtin_amdgcn_s_barrier();   // B(it + 1), half a step late
-      __builtin_amdgcn_sched_barrier(0);
       Y3_W0(3);
       const int tap_n = tap == 8 ? 0 : tap + 1;
       const int chunk_n = tap == 8 ? chunk + 1 : chunk;
@@ -496,566 +462,15 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent form of the wave-specialised kernel (bf16): one workgroup per CU walks a list of tiles
-// (tile j of workgroup b = xcd_remap(b) + j * gridDim) and neither the operand streams nor the matrix pipe stop
-// for long at a tile boundary.  Stamps on the one-tile kernel: of ~41 k cycles per tile at 76^2, ~5 k pass before the
-// first MFMA (84-100 KiB of operands to land) and 6-7.6 k after the last one (the float32 tile parked in LDS, read
-// back, scaled, added to the shortcut operand, stored).  Here
-//   * the halo image of the next tile's first chunk is simply "the next chunk" of the double-buffered halo and the
-//     weight ring runs D + 1 K-steps ahead straight into the next tile: no prologue after the first tile;
-//   * the K loop is the one-tile kernel's, instruction for instruction (the first persistent version recomputed
-//     fragment addresses to save registers and lost 7 % in the loop: it is bound by vector-issue slots);
-//   * the epilogue stays in the MFMA waves' registers: the weight rows of a wave's 64-channel slice are handed to the
-//     MFMA in a permuted order (the LOADERS permute their source rows; the LDS image and the fragment reads are
-//     unchanged) such that a lane's sixteen accumulators of one pixel fragment are sixteen CONSECUTIVE channels.
-//     Scale / bias (2 x 16 floats) and the shortcut operand (8 x 16 bytes, L2-warm: the loaders touched it during the
-//     last chunk) arrive in the registers the fragments used, are applied in place, and the finished bf16 tile
-//     (64 KiB) is written into the halo buffer the last chunk has just vacated (+ the free weight slot behind it);
-//   * the four loader waves pick the tile up from there (16 x 16 bytes per thread), free the buffer for the next
-//     tile's second chunk, and store it as whole 256-byte pixel rows two at a time beside their LDS-DMA work of the
-//     next tile's first eight K-steps -- while the MFMA waves are already in that tile's K loop.
-// The matrix pipe idles per tile for the epilogue arithmetic (~350 vector instructions per lane) and two workgroup
-// barriers (E1: every wave is done reading the last chunk; E2: the tile is staged) instead of ~11-13 k cycles.
-// Needs an even number of 64-channel chunks (the vacated buffer is always buffer 1) and K-steps per tile divisible by
-// the ring depth (the ring phase is the same in every tile, so the free slot is always the one behind buffer 1).
-template <int V>
-struct Y3Int { static constexpr int value = V; };
-
-// (the persistent kernel's phase stamps stay active in every diagnostic build, also the one that times ws's K loop as a whole)
-#ifdef Y3_STAMPS
-#define WSQ_STAMP_DECL unsigned long long _st_acc[7] = {0, 0, 0, 0, 0, 0, 0}; unsigned long long _st_prev = y3_now();
-#define WSQ_STAMP(slot) do { const unsigned long long _now = y3_now(); _st_acc[slot] += _now - _st_prev; _st_prev = _now; } while (0)
-#else
-#define WSQ_STAMP_DECL
-#define WSQ_STAMP(slot) do {} while (0)
-#endif
-
-template <int NSB>
-__global__ __launch_bounds__(768, 3) void conv_halo_wsq_kernel(HaloArgs p, int n_tiles_total) {
-  typedef bf16_t T;
-  constexpr int BM = 256, BN = 128;
-  constexpr int WAVES_N = 2;
-  constexpr int NC = 512, NL = 256;
-  constexpr int ES = 2;
-  constexpr int BKE = 128 / ES;
-  constexpr int RPL = NL / 8;
-  constexpr int NBL = BN / RPL;
-  constexpr int HPS = 2;
-#ifdef WSQ_X_NOTOUCH
-  constexpr int NT1 = 0;
-#else
-  constexpr int NT1 = 1;
-#endif
-  constexpr int PERT = NBL + HPS + NT1;               // LDS-DMA instructions per service thread and K-step: weights, halo, one touch
-  constexpr int B_BYTES = BN * 128;
-  constexpr int D = NSB - 2;
-  constexpr int MI = 4, NI = 4;
-  constexpr int NOUT = BM * BN * ES / (NL * 16);      // 16-byte pieces of the staged tile per service thread (16)
-  constexpr int SPS = 2;                              // output stores per service thread and K-step
-  constexpr int NST = NOUT / SPS;                     // K-steps of the next tile over which a tile's stores go out
-  static_assert(NSB == 3 || NSB == 4, "weight ring has 3 or 4 slots");
-
-  // LDS: [halo buffer 0][256 zero bytes][halo buffer 1][gap][ring slot NSB-1][ring slots 0 .. NSB-2][256-byte bit bucket]
-  // [scale, bias of the tile's 128 channels: 1 KiB].  Staging area of the finished tile: buffer 1 .. end of ring slot
-  // NSB-1 (>= 64 KiB, contiguous)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *sA = smem;
-  char *sZ = smem + p.a_bytes;                         // 256 zero bytes between the halo buffers (buffer b at sA + b * (a_bytes + 256))
-  char *sO = sZ + 256;
-  char *sRing = sO + p.a_bytes + p.gap;                // ring slot s lives at sRing + ((s + 1) % NSB) * B_BYTES
-  char *sBk = sRing + NSB * B_BYTES;
-  char *sSB = sBk + 256;
-  auto ring_ptr = [&](int slot) { return sRing + (slot + 1 == NSB ? 0 : slot + 1) * B_BYTES; };
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = wave >= NC / 64;
-  const int nit = p.nchunks * 9;
-  const int grid = gridDim.x;
-  const int tile0 = y3_xcd_remap(blockIdx.x, grid);   // tiles of this workgroup: tile0, tile0 + grid, ...
-  const bool has_res = (p.flags & Y3_F_RESIDUAL) != 0;
-
-  if (loader) {
-    // The service waves run at a raised priority (else their few instructions lose every arbitration against the two MFMA
-    // waves of the SIMD) -- so every VECTOR instruction they issue comes straight out of the MFMA waves' issue slots:
-    // a first version that computed 64-bit source addresses per lane (~95 vector instructions per K-step) stretched the
-    // K-step by 25-35 %.  Here every source is a buffer descriptor + a per-thread offset fixed at kernel start + a
-    // wave-uniform offset in an SGPR; out-of-range rows (before the first / after the last pixel of the tensor) come back
-    // as zeros or are dropped by the descriptor's range check instead of being selected per lane.
-#ifdef WSQ_X_PRIO
-    __builtin_amdgcn_s_setprio(WSQ_X_PRIO);
-#else
-    __builtin_amdgcn_s_setprio(3);
-#endif
-    const int ltid = tid - NC;
-    const int lwave = wave - NC / 64;
-    const int slot = ltid & 7;
-    const int row0 = ltid >> 3;
-    const int kc = slot ^ (row0 & 7);
-    if (ltid < 16) *reinterpret_cast<u32x4 *>(sZ + ltid * 16) = u32x4{0u, 0u, 0u, 0u};   // ordered by the first barrier
-    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(p.in), 0, (int)(((long long)(p.M - 1) * p.in_ld + p.Cin) * ES), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(p.wgt), 0, (int)((long long)p.n_tiles * BN * p.k_ld * ES), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
-        p.out, 0, (int)(((long long)(p.M - 1) * p.out_ld + p.Cout) * ES), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(has_res ? p.res : p.in), 0, has_res ? (int)(((long long)(p.M - 1) * p.res_ld + p.Cout) * ES) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_sb = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(lwave & 2 ? p.bias : p.scale), 0, p.n_tiles * BN * 4, 0x00020000);
-    // halo slice `pass` of chunk `chunk` of the tile whose first halo pixel is q0, into halo buffer `buf`: pixel
-    // q0 + 32 pass + row0; a negative pixel index wraps to an offset beyond the tensor
-    const int vh = row0 * p.in_ld * ES + kc * 16;
-    auto issue_halo_pass = [&](int q0, int chunk, int pass, int buf) {
-      const int u = ((q0 + pass * RPL) * p.in_ld + chunk * BKE) * ES;
-      char *dst = sA + buf * (p.a_bytes + 256) + pass * (NL * 16) + lwave * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in, (lds_void *)dst, 16, vh + u, 0, 0, 0);
-    };
-    // LDS weight row R of a slot (R = 64 wn + 16 ni + rho: row rho of MFMA fragment ni of channel half wn) holds output
-    // channel n0 + 64 wn + 16 (rho >> 2) + 4 ni + (rho & 3): the accumulators of lane quarter fq = rho >> 2 over the
-    // four fragments are then channels 16 fq .. 16 fq + 15 of the wave's slice
-    int vw[NBL];
-#pragma unroll
-    for (int i = 0; i < NBL; ++i) {
-      const int R = row0 + i * RPL;
-#ifdef WSQ_X_NOPERM
-      vw[i] = R * p.k_ld * ES + kc * 16;
-#else
-      vw[i] = ((R & ~63) | (((R >> 2) & 3) << 4) | (((R >> 4) & 3) << 2) | (R & 3)) * p.k_ld * ES + kc * 16;
-#endif
-    }
-    auto issue_weights = [&](int n0, int it, int ring_slot) {
-      const int chunk = it / 9, tap = it - chunk * 9;
-      const int u = (n0 * p.k_ld + tap * p.Cin + chunk * BKE) * ES;
-      char *dst = ring_ptr(ring_slot) + lwave * 1024;
-#pragma unroll
-      for (int i = 0; i < NBL; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void *)(dst + i * (NL * 16)), 16, vw[i], u, 0, 0);
-    };
-    auto tile_m0 = [&](int tile) { return (tile / p.n_tiles) * BM; };
-    auto tile_n0 = [&](int tile) { return (tile % p.n_tiles) * BN; };
-    // prologue of the first tile only
-    {
-      const int q0 = tile_m0(tile0) - p.W - 1;
-      for (int pass = 0; pass < p.na; ++pass) issue_halo_pass(q0, 0, pass, 0);
-#pragma unroll
-      for (int j = 0; j <= D; ++j) issue_weights(tile_n0(tile0), j, j);
-    }
-#ifdef WSQ_X_WSLOADER
-    // experiment (single-tile workgroups only): the one-tile kernel's loader loop, verbatim, in this kernel's LDS layout
-    {
-      const int m0 = tile_m0(tile0), n0 = tile_n0(tile0);
-      const long long q0 = (long long)m0 - p.W - 1;
-      auto ws_halo = [&](int chunk, int pass, bool live) {
-        const int row = row0 + pass * RPL;
-        const long long q = q0 + row;
-        const bool ok = live && row < p.hr && q >= 0 && q < p.M;
-        const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
-        char *dst = sA + (chunk & 1) * (p.a_bytes + 256) + pass * (NL * 16) + lwave * 1024;
-        __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
-      };
-      const char *b_src[NBL];
-#pragma unroll
-      for (int i = 0; i < NBL; ++i) {
-        const int R = row0 + i * RPL;
-        b_src[i] = p.wgt + ((long long)(n0 + ((R & ~63) | (((R >> 2) & 3) << 4) | (((R >> 4) & 3) << 2) | (R & 3))) * p.k_ld) * ES + kc * 16;
-      }
-      auto ws_weights = [&](int it, int ring_slot) {
-        char *dst = ring_ptr(ring_slot) + lwave * 1024;
-        if (it < nit) {
-          const int chunk = it / 9, tap = it - chunk * 9;
-          const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
-#pragma unroll
-          for (int i = 0; i < NBL; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void *)(b_src[i] + koff), (lds_void *)(dst + i * (NL * 16)), 16, 0, 0);
-        } else {
-#pragma unroll
-          for (int i = 0; i < NBL; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void *)p.zero, (lds_void *)(dst + i * (NL * 16)), 16, 0, 0);
-        }
-      };
-      wait_vmcnt<0>();
-      int tap = 0, chunk = 0, ring = (D + 1) % NSB;
-      constexpr int PER = NBL + HPS;
-#pragma unroll 1
-      for (int it = 0; it < nit; ++it) {
-        if (D == 2) { if (it == 0) wait_vmcnt<0>(); else if (it == 1) wait_vmcnt_n<PER>(); else wait_vmcnt_n<PER + HPS>(); }
-        else { if (it == 0) wait_vmcnt<0>(); else wait_vmcnt_n<HPS>(); }
-        __builtin_amdgcn_s_barrier();
-        const bool live = chunk + 1 < p.nchunks;
-        const int p0 = 2 * tap < p.na ? 2 * tap : p.na - 1;
-        const int p1 = 2 * tap + 1 < p.na ? 2 * tap + 1 : p.na - 1;
-        ws_weights(it + 1 + D, ring);
-        ws_halo(chunk + 1, p0, live);
-        ws_halo(chunk + 1, p1, live);
-        ring = ring + 1 == NSB ? 0 : ring + 1;
-        if (++tap == 9) { tap = 0; ++chunk; }
-      }
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_barrier();
-      return;
-    }
-#endif
-    int gstep = 0;                                     // K-steps issued so far, all tiles
-    WSQ_STAMP_DECL
-    u32x4 ov[NOUT];                                    // the previous tile, on its way out
-    bool have_out = false;
-    int out_u = 0;                                     // byte offset of its pixel 0, channel 0 in the output tensor
-    // piece i of a staged tile held by this thread: pixel 16 i + (ltid >> 4), LDS slot ltid & 15 = channel group
-    // (ltid & 15) ^ (pixel & 15) (the MFMA waves' bank swizzle); pixel rows beyond the tensor are dropped by r_out
-    const int o_px = ltid >> 4;
-    const int o_cg = (ltid & 15) ^ (o_px & 15);
-    const int vo = (o_px * p.out_ld + o_cg * 8) * ES;
-    const int vt = ((ltid >> 1) * p.res_ld + (ltid & 1) * 64) * ES;    // touch: one lane per 128-byte line of the shortcut tile
-    for (int tile = tile0; tile < n_tiles_total; tile += grid) {
-      const int next_tile = tile + grid;
-      const bool has_next = next_tile < n_tiles_total;
-      const int m0 = tile_m0(tile);
-      const int q0 = m0 - p.W - 1;
-      const int q0n = tile_m0(has_next ? next_tile : tile) - p.W - 1;
-      const int n0 = tile_n0(tile), n0n = tile_n0(has_next ? next_tile : tile);
-#ifdef WSQ_X_NOSTORE
-      const bool storing = false;
-#else
-      const bool storing = have_out;
-#endif
-      int tap = 0, chunk = 0, ring = (D + 1) % NSB;     // nit % NSB == 0: every tile starts at ring slot 0
-      auto store_piece = [&](auto tag) {
-        constexpr int I = decltype(tag)::value;
-        __builtin_amdgcn_raw_buffer_store_b128(ov[I], r_out, vo, out_u + I * 16 * p.out_ld * ES, 0);
-      };
-      // The step's one 4-byte-per-lane LDS-DMA: at the tile's first step the tile's scale / bias (64 floats per service
-      // wave); at the first two steps of the last chunk a touch of the tile's shortcut operand, one lane per 128-byte
-      // line (512 lines), into a bit bucket -- the MFMA waves load it in the tile's last step and must find it in L2;
-      // else a scale word again.  It is the youngest instruction of its step, so no barrier waits for it before two steps on.
-      auto issue_touch = [&](int it) {
-        if (it == 0)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_sb, (lds_void *)(sSB + lwave * 256), 4, lane * 4, (n0 + (lwave & 1) * 64) * 4, 0, 0);
-        else if (has_res && chunk + 1 == p.nchunks && tap < 2)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_res, (lds_void *)sBk, 4, vt, ((m0 + tap * (NL / 2)) * p.res_ld + n0) * ES, 0, 0);
-        else
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r_sb, (lds_void *)sBk, 4, lane * 4, 0, 0, 0);
-      };
-      // One K-step of the service waves.  SI >= 0: the step also sends two pieces of the previous tile on their way
-      // (static register indices: these steps are unrolled).  Order per step: output stores, weight tile, halo slices,
-      // touch -- the counted wait leaves the youngest halo slices and the touch (with the 4-slot ring the whole previous
-      // step as well) in flight; a step's stores are older than its weight tile, so they never add to what a later
-      // barrier waits for.
-      auto step = [&](int it, auto si_tag, bool prev_stored) {
-        constexpr int SI = decltype(si_tag)::value;
-#ifdef WSQ_X_NODMA
-        if (gstep == 0) wait_vmcnt<0>();
-#else
-        if (D == 2) {
-          if (gstep == 0) wait_vmcnt<NBL>();
-          else if (gstep == 1) wait_vmcnt_n<PERT>();
-          else if (prev_stored) wait_vmcnt_n<PERT + HPS + NT1 + SPS>();
-          else wait_vmcnt_n<PERT + HPS + NT1>();
-        } else {
-          if (gstep == 0) wait_vmcnt<0>(); else wait_vmcnt_n<HPS + NT1>();
-        }
-#endif
-        ++gstep;
-#ifdef WSQ_X_FINE
-        WSQ_STAMP(4);                                  // slot 4: waiting for LDS-DMA to land
-#endif
-        __builtin_amdgcn_s_barrier();
-#ifdef WSQ_X_FINE
-        WSQ_STAMP(5);                                  // slot 5: waiting at the barrier
-#endif
-        if constexpr (SI >= 0) {
-          static_assert(SPS == 2, "two pieces per step");
-          store_piece(Y3Int<(SI >= 0 ? SI : 0) * SPS>{});
-          store_piece(Y3Int<(SI >= 0 ? SI : 0) * SPS + 1>{});
-        }
-#ifndef WSQ_X_NODMA
-        // weight tile D + 1 steps ahead: this tile's, the next tile's, or (nothing left) the last one again
-        const int itw = it + 1 + D;
-        if (itw < nit) issue_weights(n0, itw, ring);
-        else if (has_next) issue_weights(n0n, itw - nit, ring);
-        else issue_weights(n0, nit - 1, ring);
-        // two slices of the next chunk's halo: this tile's chunk + 1, or chunk 0 of the next tile (after the last tile:
-        // of this one again, into a buffer nobody reads any more)
-        const bool in_tile = chunk + 1 < p.nchunks;
-        const int p0 = 2 * tap < p.na ? 2 * tap : p.na - 1;
-        const int p1 = 2 * tap + 1 < p.na ? 2 * tap + 1 : p.na - 1;
-        const int nbuf = (chunk + 1) & 1;
-        issue_halo_pass(in_tile ? q0 : q0n, in_tile ? chunk + 1 : 0, p0, nbuf);
-        issue_halo_pass(in_tile ? q0 : q0n, in_tile ? chunk + 1 : 0, p1, nbuf);
-        if (NT1) issue_touch(it);
-#endif
-        ring = ring + 1 == NSB ? 0 : ring + 1;
-        if (++tap == 9) { tap = 0; ++chunk; }
-#ifdef WSQ_X_FINE
-        WSQ_STAMP(6);                                  // slot 6: issuing
-#endif
-      };
-      int it = 0;
-      if (storing) {
-        step(0, Y3Int<0>{}, false); step(1, Y3Int<1>{}, true); step(2, Y3Int<2>{}, true); step(3, Y3Int<3>{}, true);
-        step(4, Y3Int<4>{}, true); step(5, Y3Int<5>{}, true); step(6, Y3Int<6>{}, true); step(7, Y3Int<7>{}, true);
-        static_assert(NST == 8, "the unrolled store steps above");
-        step(8, Y3Int<-1>{}, true);
-        it = NST + 1;
-      }
-#pragma unroll 1
-      for (; it < nit; ++it) step(it, Y3Int<-1>{}, false);
-#ifndef WSQ_X_FINE
-      WSQ_STAMP(4);
-#endif
-      __builtin_amdgcn_s_barrier();                    // E1 (inside the MFMA waves' last step): they are done reading buffer 1 and ring slot NSB-1
-      __builtin_amdgcn_s_barrier();                    // E2: the finished tile is staged
-#ifndef WSQ_X_FINE
-      WSQ_STAMP(5);
-#else
-      _st_prev = y3_now();
-#endif
-#pragma unroll
-      for (int i = 0; i < NOUT; ++i) ov[i] = *reinterpret_cast<const u32x4 *>(sO + (i * NL + ltid) * 16);
-      __builtin_amdgcn_s_waitcnt(0xC07F);              // pieces in registers: buffer 1 and the ring slot are free again
-#ifndef WSQ_X_FINE
-      WSQ_STAMP(6);
-#else
-      _st_prev = y3_now();
-#endif
-      have_out = true;
-      out_u = (m0 * p.out_ld + n0) * ES;
-#ifdef WSQ_X_NOSTORE
-#pragma unroll
-      for (int i = 0; i < NOUT; ++i) __builtin_amdgcn_raw_buffer_store_b128(ov[i], r_out, vo, out_u + i * 16 * p.out_ld * ES, 0);
-      wait_vmcnt<0>();
-#endif
-    }
-    // the last tile of this workgroup: nothing left to hide its stores behind
-#pragma unroll
-    for (int i = 0; i < NOUT; ++i) __builtin_amdgcn_raw_buffer_store_b128(ov[i], r_out, vo, out_u + i * 16 * p.out_ld * ES, 0);
-#ifdef Y3_STAMPS
-    if (tid == NC) for (int _i = 4; _i < 7; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]);
-#endif
-    return;
-  }
-
-  // ---------------- consumer waves ----------------
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the younger MFMA wave of each SIMD: static priority, +1-5 % measured
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int a_lane_row = wm * 64 + fr;
-  const int b_lane_row = wn * 64 + fr;
-  const int b_off0 = b_lane_row * 128 + (((0 + fq) ^ (b_lane_row & 7)) << 4);
-  const int b_off1 = b_lane_row * 128 + (((4 + fq) ^ (b_lane_row & 7)) << 4);
-  const bool leaky = p.flags & Y3_F_LEAKY;
-  // The two MFMA waves of a SIMD run the same program; in lock step both reach their fragment reads, their MFMAs and
-  // the barrier together and leave the matrix pipe idle together.  Waves 4-7 therefore run HALF A K-STEP behind waves
-  // 0-3: their step barrier sits between the step's two halves instead of in front of the first (MI355X_MICROARCH.md,
-  // two waves per SIMD, item 9).  Same instructions in the same order per wave (results bit for bit the same), same
-  // number of barriers; a step's fragments are still read between the barrier that announces them and the next one.
-#ifdef WSQ_X_NOSTAG
-  const bool stag = false;
-#else
-  const bool stag = wave >= 4;
-#endif
-  typedef const __attribute__((address_space(3))) u32x4 lds_u32x4;
-  const int sA_lds = (int)(size_t)(lds_void *)sA;
-  const int sZ_lds = (int)(size_t)(lds_void *)sZ;
-  int low8 = 255;
-  asm volatile("" : "+s"(low8));                     // in an SGPR: no VOP3 literals on gfx9
-  WSQ_STAMP_DECL
-  for (int tile = tile0; tile < n_tiles_total; tile += grid) {
-    const int m0 = (tile / p.n_tiles) * BM;
-    const int n0 = (tile % p.n_tiles) * BN;
-    uint32_t tapmask[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const uint32_t m = (uint32_t)(m0 + wm * 64 + mi * 16 + fr);
-      uint32_t mask = 0u;
-      if (m < (uint32_t)p.M) {
-        const uint32_t img = (__umulhi(m, p.mul_hw) + m) >> p.sh_hw;
-        const uint32_t rem = m - img * (uint32_t)p.HW;
-        const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
-        const uint32_t ox = rem - oy * (uint32_t)p.W;
-        const uint32_t vx = (ox >= 1u ? 1u : 0u) | 2u | (ox + 1u < (uint32_t)p.W ? 4u : 0u);
-        mask = (oy >= 1u ? vx : 0u) | (vx << 3) | (oy + 1u < (uint32_t)p.H ? vx << 6 : 0u);
-      }
-      tapmask[mi] = mask;
-    }
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // border taps read the 256 zero bytes behind the ring instead of their (wrapped) neighbour, at the spot that has the
-    // bank of the address they would have read: see conv_halo_ws_kernel
-    int zalt[MI], sel[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      zalt[mi] = sZ_lds - mi * 2048;
-      asm volatile("" : "+v"(zalt[mi]));
-    }
-    auto read_frags0 = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], int a_off, const char *bBuf, int a_shift, int tap) {
-      const int r0 = a_lane_row + a_shift;
-      const int ap = ((r0 << 7) + (a_off + sA_lds)) + ((fq ^ (r0 & 7)) << 4);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        int zoff;
-        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(zoff) : "v"(ap), "s"(low8), "v"(zalt[mi]));
-        int off = ((tapmask[mi] >> tap) & 1u) ? ap : zoff;
-        asm volatile("" : "+v"(off));
-        sel[mi] = off;
-        xf[mi] = *reinterpret_cast<lds_u32x4 *>(off + mi * 2048);
-      }
-      const char *bp = bBuf + b_off0;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
-    };
-    auto read_frags1 = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], const char *bBuf) {
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        int off = sel[mi] ^ 64;
-        asm volatile("" : "+v"(off));
-        xf[mi] = *reinterpret_cast<lds_u32x4 *>(off + mi * 2048);
-      }
-      const char *bp = bBuf + b_off1;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
-    };
-    auto mma_all = [&](const u32x4 (&xf)[MI], const u32x4 (&wf)[NI]) {
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) MmaH<T>::run(acc[mi][ni], wf[ni], xf[mi]);
-    };
-    auto interleave = [&]() {
-#pragma unroll
-      for (int i = 0; i < MI + NI; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      }
-    };
-    __builtin_amdgcn_s_barrier();                      // B(0) of this tile
-    WSQ_STAMP(0);
-    u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
-    read_frags0(xf0, wf0, 0, ring_ptr(0), 0, 0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    int tap = 0, chunk = 0, ring = 0;
-#pragma unroll 1
-    for (int it = 0; it < nit - 1; ++it) {
-      if (it && !stag) __builtin_amdgcn_s_barrier();
-#ifdef WSQ_X_FINE
-      WSQ_STAMP(1);                                     // slot 1: waiting at the step's barrier
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-#ifdef WSQ_X_NOREAD
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { asm volatile("" : "+v"(xf0[q]), "+v"(wf0[q]), "+v"(xf1[q]), "+v"(wf1[q])); }
-      mma_all(xf0, wf0);
-      mma_all(xf1, wf1);
-      continue;
-#endif
-      read_frags1(xf1, wf1, ring_ptr(ring));
-      mma_all(xf0, wf0);
-      interleave();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      if (stag) __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      const int tap_n = tap == 8 ? 0 : tap + 1;
-      const int chunk_n = tap == 8 ? chunk + 1 : chunk;
-      const int ring_n = ring + 1 == NSB ? 0 : ring + 1;
-      {
-        const int ky_n = (tap_n * 11) >> 5, kx_n = tap_n - ky_n * 3;
-        read_frags0(xf0, wf0, (chunk_n & 1) * (p.a_bytes + 256), ring_ptr(ring_n), ky_n * p.W + kx_n, tap_n);
-      }
-      mma_all(xf1, wf1);
-      interleave();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      tap = tap_n;
-      chunk = chunk_n;
-      ring = ring_n;
-#ifdef WSQ_X_FINE
-      WSQ_STAMP(2);                                     // slot 2: the step's reads + MFMAs
-#endif
-    }
-    // ---- the tile's last K-step, peeled: no fragments to pre-read; instead barrier E1 once the step's own fragments are
-    // in registers (the last reads of buffer 1 and of ring slot NSB-1), and the shortcut operand's loads go out under the
-    // second half's MFMAs into the registers the first half's fragments have just left.  This lane holds, per pixel
-    // fragment mi, channels co .. co + 15 of pixel fr.
-    const int co = n0 + wn * 64 + fq * 16;
-    u32x4 rv[MI][2];
-    {
-      if (!stag) __builtin_amdgcn_s_barrier();         // B(nit - 1)
-      __builtin_amdgcn_sched_barrier(0);
-      read_frags1(xf1, wf1, ring_ptr(ring));
-      mma_all(xf0, wf0);
-      interleave();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      __builtin_amdgcn_s_barrier();                    // E1
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * 64 + mi * 16 + fr;
-        const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-          rv[mi][h] = (has_res && m < p.M) ? *reinterpret_cast<const u32x4 *>(rp + h * 16)
-                                           : u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};   // -0.0: v + r == v bit for bit
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mma_all(xf1, wf1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#ifdef WSQ_X_FINE
-    WSQ_STAMP(3);
-#else
-    WSQ_STAMP(1);
-#endif
-    // ---- epilogue in registers ----
-    f32x4 sc[NI], bi[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      sc[ni] = *reinterpret_cast<const f32x4 *>(sSB + (wn * 64 + fq * 16 + ni * 4) * 4);
-      bi[ni] = *reinterpret_cast<const f32x4 *>(sSB + 512 + (wn * 64 + fq * 16 + ni * 4) * 4);
-    }
-#ifndef WSQ_X_FINE
-    WSQ_STAMP(2);
-#endif
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int pl = wm * 64 + mi * 16 + fr;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float v[8];
-        y3_bn_leaky8(v, acc[mi][2 * h], acc[mi][2 * h + 1], sc[2 * h], sc[2 * h + 1], bi[2 * h], bi[2 * h + 1], leaky);
-        const bf16x8 r = __builtin_bit_cast(bf16x8, rv[mi][h]);
-        bf16x8 ov;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) ov[q] = (bf16_t)(v[q] + (float)r[q]);
-        const int cg = wn * 8 + fq * 2 + h;
-        *reinterpret_cast<bf16x8 *>(sO + pl * 256 + ((cg ^ fr) << 4)) = ov;
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_s_barrier();                      // E2: the tile is staged; the service waves take it from here
-    WSQ_STAMP(3);
-#ifdef Y3_STAMPS
-    if (tid == 0) atomicAdd(&g_y3_stamps[7], 1ull);
-#endif
-  }
-#ifdef Y3_STAMPS
-  if (tid == 0) for (int _i = 0; _i < 4; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]);
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------
 // 2-D patch form of the persistent wave-specialised kernel, for wide feature maps (rows of more than 128 pixels,
 // where the raster strip's halo of 2W + 2 rows no longer fits in LDS): a workgroup owns an 8 x 32 output tile and
 // stages the 10 x 34 input patch per channel chunk (one LDS row per patch pixel, out-of-frame pixels as zeros).  Tap
 // (ky, kx) of output (y, x) is patch row (y + ky) * 34 + x + kx: rows never wrap, so the fragment masking of the strip
-// kernels disappears.  Loaders, weight ring, barriers and the
-// per-wave epilogue are those of conv_halo_wsp_kernel.  Cost: tiles that hang over the right / bottom edge compute
+// kernel disappears.  Loaders, weight ring and barriers follow conv_halo_ws_kernel, but persistently: one workgroup per
+// CU walks a list of tiles, the patch of the next tile's first chunk is simply "the next chunk" of the double buffer
+// and the weight ring runs straight into the next tile; after a tile's K loop one extra barrier ("everyone is done
+// with the last chunk's buffer"), then each MFMA wave parks 16 pixels x 64 channels at a time in a private 4 KiB
+// slice of that idle buffer and writes them out as 16-byte NHWC chunks.  Cost: tiles that hang over the right / bottom edge compute
 // pixels nobody stores (152 = 4.75 x 32: 5 %), which is why narrow maps stay on the strip kernels.
 template <typename T, int NSB>
 __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int n_tiles_total, int tiles_x, int tiles_y) {
@@ -1377,13 +792,6 @@ static int halo_tile_fragments(int M, int n_tiles, int nchunks, int n_cu) {
   return best_mi;
 }
 
-static int device_cu_count() {
-  static Y3DeviceOnce once;
-  int n_cu = 0;
-  if (once.run([]() -> int { return Y3_OK; }, &n_cu) != Y3_OK || n_cu <= 0) return 256;   // no device (dry run on a CPU box)
-  return n_cu;
-}
-
 template <typename T>
 int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
   HaloArgs a = a0;
@@ -1428,52 +836,6 @@ int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
     if (nsb == 4) hipLaunchKernelGGL((conv_halo_ws_kernel<T, 4, 4>), grid, dim3(768), lds, s, a);
     else hipLaunchKernelGGL((conv_halo_ws_kernel<T, 3, 4>), grid, dim3(768), lds, s, a);
   }
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
-}
-
-// persistent kernel: LDS = two halo buffers + gap + ring + 256 zero bytes; the staging area of a finished tile (64 KiB)
-// is buffer 1 + gap + ring slot NSB-1.  Returns the ring depth that fits (0: none).
-static int halo_wsq_config(int W, int nchunks, int *na_out, int *a_bytes_out, int *gap_out, size_t *lds_out) {
-  const int hr = 256 + 2 * W + 2;
-  const int na = y3_ceil_div(hr, 32);
-  const int a_bytes = na * 32 * 128;
-  const int gap = a_bytes >= 48 * 1024 ? 0 : 48 * 1024 - a_bytes;
-  if (nchunks < 2 || (nchunks & 1)) return 0;          // the vacated halo buffer must always be buffer 1
-  for (int c = 4; c >= 3; --c) {
-    if ((nchunks * 9) % c != 0) continue;              // same ring phase in every tile
-    if (na > (c == 4 ? 12 : 14)) continue;             // all real halo slices out by tap 5 (4 slots) / 6 (3 slots)
-    const size_t lds = (size_t)2 * a_bytes + gap + (size_t)c * 128 * 128 + 256 + 256 + 1024;   // + zero bytes, bit bucket, scale / bias
-    if (lds > 160 * 1024) continue;
-    *na_out = na; *a_bytes_out = a_bytes; *gap_out = gap; *lds_out = lds;
-    return c;
-  }
-  return 0;
-}
-
-int launch_halo_wsq(const HaloArgs &a0, hipStream_t s) {
-  HaloArgs a = a0;
-  size_t lds = 0;
-  a.hr = 256 + 2 * a.W + 2;
-  const int nsb = halo_wsq_config(a.W, a.nchunks, &a.na, &a.a_bytes, &a.gap, &lds);
-  Y3_REQUIRE(nsb != 0, "persistent halo kernel: row width %d / %d chunks do not fit", a.W, a.nchunks);
-  a.hr_pad = a.na * 32;
-  static Y3DeviceOnce once;
-  int n_cu = 0;
-  {
-    const int rc = once.run([]() -> int {
-      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_wsq_kernel<3>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_wsq_kernel<4>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      return Y3_OK;
-    }, &n_cu);
-    if (rc != Y3_OK) return rc;
-  }
-  const int tiles = y3_ceil_div(a.M, 256) * a.n_tiles;
-  const int grid = tiles < n_cu ? tiles : n_cu;
-  if (nsb == 4) hipLaunchKernelGGL((conv_halo_wsq_kernel<4>), dim3(grid), dim3(768), lds, s, a, tiles);
-  else hipLaunchKernelGGL((conv_halo_wsq_kernel<3>), dim3(grid), dim3(768), lds, s, a, tiles);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -1559,26 +921,19 @@ int y3_launch_conv_patch(const y3_op &op, const void *d_in, const void *d_zero, 
   a.k_ld = op.k_ld;
   a.nchunks = op.in_c / (128 / es);
   a.n_tiles = op.out_c / 128;
-  a.hr_pad = a.na = a.a_bytes = a.gap = 0;
+  a.hr_pad = a.na = a.a_bytes = 0;
   a.mul_hw = a.sh_hw = a.mul_w = a.sh_w = 0;
   a.flags = op.flags | (y3_debug_flags() ? 0x40000000u : 0u);
   return bf ? launch_patch_wsp<bf16_t>(a, s) : launch_patch_wsp<float>(a, s);
 }
 
 int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
-                        const char **kernel_name, bool dry_run, bool persistent) {
+                        const char **kernel_name, bool dry_run) {
   const int es = y3_elem_size(op.dtype);
   const bool bf = op.dtype == Y3_BF16;
   Y3_REQUIRE(y3_conv_halo_ws_fits(op), "conv block %d: shape not supported by the halo kernel", op.block_idx);
-  // the persistent variant is a bf16 throughput kernel (its finished tile is staged as 64 KiB of bf16) with its own shape rules
-  {
-    int na = 0, ab = 0, gap = 0;
-    size_t lds = 0;
-    persistent = persistent && bf && op.res_ld % 8 == 0 && halo_wsq_config(op.in_w, op.in_c / (128 / es), &na, &ab, &gap, &lds) != 0;
-  }
-  const int mi = halo_tile_fragments(op.batch * op.in_h * op.in_w, op.out_c / 128, op.in_c / (128 / es), device_cu_count());
-  if (persistent) *kernel_name = "conv_halo_wsq_bf16_256x128";
-  else if (mi == 3) *kernel_name = bf ? "conv_halo_ws_bf16_192x128" : "conv_halo_ws_f32_192x128";
+  const int mi = halo_tile_fragments(op.batch * op.in_h * op.in_w, op.out_c / 128, op.in_c / (128 / es), y3_device_cus());
+  if (mi == 3) *kernel_name = bf ? "conv_halo_ws_bf16_192x128" : "conv_halo_ws_f32_192x128";
   else *kernel_name = bf ? "conv_halo_ws_bf16_256x128" : "conv_halo_ws_f32_256x128";
   if (dry_run) return Y3_OK;
   HaloArgs a;
@@ -1595,12 +950,11 @@ int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, h
   a.k_ld = op.k_ld;
   a.nchunks = op.in_c / (128 / es);
   a.n_tiles = op.out_c / 128;
-  a.hr_pad = a.na = a.a_bytes = a.gap = 0;
+  a.hr_pad = a.na = a.a_bytes = 0;
   fast_div((uint32_t)a.HW, a.mul_hw, a.sh_hw);
   fast_div((uint32_t)a.W, a.mul_w, a.sh_w);
   a.flags = op.flags | (y3_debug_flags() ? 0x40000000u : 0u);
   Y3_REQUIRE((long long)op.batch * a.HW < (1ll << 31), "conv block %d: too many pixels for the 32-bit tile index", op.block_idx);
-  if (persistent) return launch_halo_wsq(a, s);
   return bf ? launch_halo_ws<bf16_t>(a, s) : launch_halo_ws<float>(a, s);
 }
 

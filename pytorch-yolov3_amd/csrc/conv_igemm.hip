@@ -37,7 +37,7 @@ struct IgemmArgs {
   int ks, stride, pad;
   int M, HoWo;
   int k_ld, K;
-  int n_ktiles, ktiles_per_tap;
+  int n_ktiles, ktiles_per_tap, n_taps;
   int m_tiles, n_tiles;
   uint32_t mul_hw, sh_hw, mul_w, sh_w;   // n / d == (umulhi(n, mul) + n) >> sh  for n < 2^31 (d = HoWo, Wo)
   uint32_t flags;
@@ -152,10 +152,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
   u32x4 a_reg[A_CH], b_reg[B_CH];
 
   auto fetch = [&](int kt) {
+    long long koff_k0 = 0;
     if constexpr (!GENERIC_K) {
       // whole K-tile lies inside one filter tap: tap and channel offset are wave-uniform
-      const int tap = kt / p.ktiles_per_tap;
-      const int ci0 = (kt - tap * p.ktiles_per_tap) * BKE;
+      // K order: channel chunk outermost, filter tap innermost -- the order of the halo / patch kernels (conv_halo.hip),
+      // so that a layer sums in the same order whichever kernel the launcher picks for its grid size
+      const int chunk = kt / p.n_taps;
+      const int tap = kt - chunk * p.n_taps;
+      const int ci0 = chunk * BKE;
       const int ky = tap / p.ks, kx = tap - ky * p.ks;
       const long long tap_off = ((long long)(ky * p.W + kx) * p.in_ld + ci0) * ES;
 #pragma unroll
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
         const char *src = ((a_taps[i] >> tap) & 1u) ? a_base[i] + tap_off : p.zero;
         a_reg[i] = *reinterpret_cast<const u32x4 *>(src);
       }
+      koff_k0 = ((long long)tap * p.Cin + ci0) * ES;
     } else {
       // per-chunk tap: Cin is only a multiple of the chunk width
       const int ke = kt * BKE + kc * CE;
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
         a_reg[i] = *reinterpret_cast<const u32x4 *>(src);
       }
     }
-    const long long koff = (long long)kt * 128;
+    const long long koff = GENERIC_K ? (long long)kt * 128 : koff_k0;
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) b_reg[i] = *reinterpret_cast<const u32x4 *>(b_base[i] + koff);
   };
@@ -400,8 +405,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
     int tap;
     bool in_k = true;
     if constexpr (KMODE == 0) {
-      tap = kt / p.ktiles_per_tap;
-      const int ci0 = (kt - tap * p.ktiles_per_tap) * BKE;
+      const int chunk = kt / p.n_taps;                 // chunk outermost, tap innermost: the halo kernels' K order
+      tap = kt - chunk * p.n_taps;
+      const int ci0 = chunk * BKE;
       const int ky = tap / p.ks, kx = tap - ky * p.ks;
       tap_off = ((long long)(ky * p.W + kx) * p.in_ld + ci0) * ES;
     } else if constexpr (KMODE == 2) {
@@ -431,7 +437,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
 #pragma unroll
     for (int i = 0; i < A_CH; ++i)
       __builtin_amdgcn_global_load_lds((gbl_void *)src[i], (lds_void *)(sA + wave * 1024 + i * (NT * 16)), 16, 0, 0);
-    const long long koff = (long long)kt * RB;
+    long long koff = (long long)kt * RB;
+    if constexpr (KMODE == 0) {
+      const int chunk = kt / p.n_taps;
+      koff = ((long long)(kt - chunk * p.n_taps) * p.Cin + chunk * BKE) * ES;
+    }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i)
       __builtin_amdgcn_global_load_lds((gbl_void *)(b_base[i] + koff), (lds_void *)(sB + wave * 1024 + i * (NT * 16)), 16, 0, 0);
@@ -709,11 +719,14 @@ void conv_igemm3_kernel(IgemmArgs p) {
       long long tap_off;
       int tap;
       bool in_k = true;
+      long long koff = (long long)kt * RB;
       if constexpr (KMODE == 0) {
-        tap = kt / p.ktiles_per_tap;
-        const int ci0 = (kt - tap * p.ktiles_per_tap) * BKE;
+        const int chunk = kt / p.n_taps;               // chunk outermost, tap innermost: the halo kernels' K order
+        tap = kt - chunk * p.n_taps;
+        const int ci0 = chunk * BKE;
         const int ky = tap / p.ks, kx = tap - ky * p.ks;
         tap_off = ((long long)(ky * p.W + kx) * p.in_ld + ci0) * ES;
+        koff = ((long long)tap * p.Cin + ci0) * ES;
       } else if constexpr (KMODE == 2) {
         tap = kt * tpt + tl;
         const int ky = tap / p.ks, kx = tap - ky * p.ks;
@@ -735,7 +748,6 @@ void conv_igemm3_kernel(IgemmArgs p) {
         const char *src = ok ? a_base[i] + tap_off : p.zero;
         __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(sA + lwave * 1024 + i * (NC * 16)), 16, 0, 0);
       }
-      const long long koff = (long long)kt * RB;
 #pragma unroll
       for (int i = 0; i < B_CH; ++i)
         __builtin_amdgcn_global_load_lds((gbl_void *)(b_base[i] + koff), (lds_void *)(sB + lwave * 1024 + i * (NC * 16)), 16, 0, 0);
@@ -997,6 +1009,7 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
   if (op.in_c % bke == 0) kmode = 0;
   else if (bke % op.in_c == 0) kmode = 2;
   a.ktiles_per_tap = kmode == 0 ? op.in_c / bke : 0;
+  a.n_taps = op.ksize * op.ksize;
   if (kmode == 0) a.n_ktiles = op.ksize * op.ksize * a.ktiles_per_tap;
   else if (kmode == 2) a.n_ktiles = y3_ceil_div(op.ksize * op.ksize, bke / op.in_c);
   else a.n_ktiles = y3_ceil_div(a.K, bke);
@@ -1015,7 +1028,7 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
   // CU resident).  Narrower tiles re-read the (small) activation tile more often and keep the weight bytes per FLOP.
   if (version == 2 && !(op.flags & Y3_F_OUT_F32) && !(y3_opt().auto_mask & 1024)) {
     const long long m_tiles = y3_ceil_div(a.M, 128);
-    while (bn > 32 && m_tiles * y3_ceil_div(op.out_c, bn) < 256) bn >>= 1;   // 362 / 368 workgroups at 128 measured faster than twice as many at 64
+    while (bn > 32 && m_tiles * y3_ceil_div(op.out_c, bn) < y3_device_cus()) bn >>= 1;   // 362 / 368 workgroups at 128 measured faster than twice as many at 64
   }
   // float32-output (detection head) convs: the direct epilogue of v1 measured faster
   if (version == 1 || (version == 2 && bf && (op.flags & Y3_F_OUT_F32))) {
@@ -1096,6 +1109,7 @@ int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d
   a.k_ld = op0.k_ld;
   a.K = op0.in_c;
   a.ktiles_per_tap = op0.in_c / 64;
+  a.n_taps = 1;
   a.n_ktiles = a.ktiles_per_tap;
   a.flags = op0.flags;
   igemm_fast_div((uint32_t)a.HoWo, a.mul_hw, a.sh_hw);

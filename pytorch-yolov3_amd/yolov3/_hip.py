@@ -46,9 +46,17 @@ class Y3Op(ctypes.Structure):
 class Y3Options(ctypes.Structure):
     """Mirror of ``struct y3_options`` (include/yolov3_hip.h): kernel-selection options of one plan."""
     _fields_ = [(name, ctypes.c_int32) for name in (
-        "auto_mask", "halo_persistent", "igemm_version", "igemm_ns", "igemm_bm", "use_graph", "fuse_stem", "fuse_head",
+        "auto_mask", "unused0", "igemm_version", "igemm_ns", "igemm_bm", "use_graph", "fuse_stem", "fuse_head",
         "fuse_spp", "decode_lanes")] + [("reserved", ctypes.c_int32 * 6)]
 
+
+# y3_options.auto_mask bits (include/yolov3_hip.h: Y3_AM_*)
+AM_HALO_WIDE, AM_IGEMM3_MID, AM_HALO_NARROW, AM_IGEMM3_1X1_DEEP = 0x0001, 0x0002, 0x0004, 0x0008
+AM_HALO_MID, AM_IGEMM3_NARROW, AM_IGEMM3_1X1_BM64, AM_PATCH_WIDE = 0x0010, 0x0020, 0x0040, 0x0080
+AM_HALO_TILE256, AM_NO_BN_SHRINK, AM_NO_SMALL_GRID, AM_NO_WRES, AM_WRES_ALWAYS = 0x0200, 0x0400, 0x0800, 0x1000, 0x2000
+AM_DEFAULT = AM_HALO_WIDE | AM_HALO_NARROW | AM_IGEMM3_1X1_DEEP | AM_HALO_MID | AM_PATCH_WIDE
+AM_IGEMM_ONLY = 0
+AM_HALO_ALL = AM_HALO_WIDE | AM_HALO_NARROW | AM_HALO_MID          # conv_bench: the halo kernel wherever it fits
 
 ABI_VERSION = 2
 _lib = None
@@ -127,7 +135,7 @@ def options(**overrides):
     opt = Y3Options()
     lib().y3_options_default(ctypes.byref(opt))
     for key, val in overrides.items():
-        if key not in dict(Y3Options._fields_) or key == "reserved":
+        if key not in dict(Y3Options._fields_) or key in ("reserved", "unused0"):
             raise KeyError("unknown plan option {!r}".format(key))
         setattr(opt, key, int(val))
     return opt

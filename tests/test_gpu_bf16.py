@@ -195,7 +195,8 @@ def test_bf16_every_block_teacher_forced_mini():
     assert checked >= 20
 
 
-HALO = {"auto_mask": 157 | 2048}     # round-1 selection: the halo kernel whatever the grid size (bit 11: no small-grid rerouting)
+from yolov3 import _hip as _H
+HALO = {"auto_mask": _H.AM_DEFAULT | _H.AM_NO_SMALL_GRID}     # round-1 selection: the halo kernel whatever the grid size
 
 
 @pytest.mark.parametrize("model,h,w,batch,options,kernels", [
@@ -214,13 +215,13 @@ HALO = {"auto_mask": 157 | 2048}     # round-1 selection: the halo kernel whatev
     ("yolov3-spp", 416, 416, 2, HALO, ("conv_halo_ws", "maxpool_spp", "head_decode")),
     # batch 8: 76^2 and 38^2 stay on the halo kernel by themselves, 19^2 goes to the implicit GEMM
     ("yolov3", 608, 608, 8, None, ("conv_halo_ws", "conv_igemm3", "head_decode")),
-    # the weights-resident persistent 1x1 kernel on every layer it supports (bit 13; by itself it starts at 512 tiles)
-    ("yolov3", 608, 608, 2, {"auto_mask": 157 | 8192}, ("conv1x1_wres_bf16_128x128", "conv1x1_wres_bf16_128x64")),
-    ("yolov3", 352, 480, 3, {"auto_mask": 157 | 8192}, ("conv1x1_wres_bf16_128x128", "conv1x1_wres_bf16_128x64")),
-    ("yolov3-spp", 416, 416, 1, {"auto_mask": 157 | 8192}, ("conv1x1_wres",)),
+    # the weights-resident persistent 1x1 kernel on every layer it supports (Y3_AM_WRES_ALWAYS; by itself it starts at 512 tiles)
+    ("yolov3", 608, 608, 2, {"auto_mask": _H.AM_DEFAULT | _H.AM_WRES_ALWAYS}, ("conv1x1_wres_bf16_128x128", "conv1x1_wres_bf16_128x64")),
+    ("yolov3", 352, 480, 3, {"auto_mask": _H.AM_DEFAULT | _H.AM_WRES_ALWAYS}, ("conv1x1_wres_bf16_128x128", "conv1x1_wres_bf16_128x64")),
+    ("yolov3-spp", 416, 416, 1, {"auto_mask": _H.AM_DEFAULT | _H.AM_WRES_ALWAYS}, ("conv1x1_wres",)),
     # THE BENCHMARKED CONFIGURATION, block by block: 16 frames of 608 x 608 with bench.py's plan options (256-pixel halo
     # tiles in several rounds of workgroups, the weights-resident 1x1 kernel by itself, the stride-2 layer on igemm3)
-    ("yolov3", 608, 608, 16, {"auto_mask": 157 | 512}, ("conv_halo_ws_bf16_256x128", "conv1x1_wres_bf16_128x128",
+    ("yolov3", 608, 608, 16, {"auto_mask": _H.AM_DEFAULT | _H.AM_HALO_TILE256}, ("conv_halo_ws_bf16_256x128", "conv1x1_wres_bf16_128x128",
                                                         "conv1x1_wres_bf16_128x64", "conv_igemm3", "conv_patch", "head_decode")),
 ])
 def test_bf16_every_block_teacher_forced(model, h, w, batch, options, kernels):
@@ -232,24 +233,12 @@ def test_bf16_every_block_teacher_forced(model, h, w, batch, options, kernels):
     assert checked >= (20 if model == "yolov3-tiny" else 75)      # 107 blocks, 23 convs checked with their shortcut, 3 yolo
 
 
-@pytest.mark.parametrize("model,h,w,batch", [("yolov3", 608, 608, 1), ("yolov3", 416, 416, 2), ("yolov3", 352, 480, 3),
-                                             ("yolov3-spp", 320, 320, 2), ("yolov3-tiny", 416, 416, 2)])
-def test_bf16_every_block_teacher_forced_two_per_cu_halo_kernel(model, h, w, batch):
-    """The same per-block gate with the two-workgroups-per-CU halo kernel (128 x 128 tiles, single halo buffer) on every
-    3x3 layer it fits: rows of 19 / 38 px at 608, 13 / 26 / 52 at 416, 11..60 at 352 x 480 (strips that wrap rows and
-    frames, one to sixteen channel chunks)."""
-    frames = synth_frames(2000 + h + w + batch, batch, h, w)
-    checked, frac, names = _teacher_forced(model, frames, ("conv_halo2",), options={"auto_mask": 157 | 256})
-    print("%s %dx%d b%d: %d blocks checked, worst mismatch share %.4f, %d launches of conv_halo2" % (
-        model, h, w, batch, checked, frac, sum("conv_halo2" in k for k in names)))
-
-
 @pytest.mark.parametrize("model,h,w,batch", [("yolov3", 608, 608, 1), ("yolov3", 320, 416, 2)])
 def test_bf16_every_block_teacher_forced_256_pixel_halo_tiles(model, h, w, batch):
     """The halo kernel picks 192- or 256-pixel tiles per layer from the tile count (192 at these small batches); the same
-    per-block gate with 256-pixel tiles forced (auto_mask bit 9), the choice the batch-16 benchmark makes at 76^2."""
+    per-block gate with 256-pixel tiles forced (Y3_AM_HALO_TILE256), the choice the batch-16 benchmark makes at 76^2."""
     frames = synth_frames(3000 + h + w + batch, batch, h, w)
-    checked, frac, names = _teacher_forced(model, frames, ("conv_halo_ws_bf16_256x128",), options={"auto_mask": 157 | 512 | 2048})
+    checked, frac, names = _teacher_forced(model, frames, ("conv_halo_ws_bf16_256x128",), options={"auto_mask": _H.AM_DEFAULT | _H.AM_HALO_TILE256 | _H.AM_NO_SMALL_GRID})
     assert not any("192x128" in k for k in names)
     print("%s %dx%d b%d: %d blocks checked, worst mismatch share %.4f" % (model, h, w, batch, checked, frac))
 

@@ -43,21 +43,20 @@ LAYERS = [
     ("s76_256-255_k1_head", 76, 256, 255, 1, 1, False, True),
 ]
 
-# knob sets (y3_set_tuning) compared per layer; auto_mask 0 = implicit GEMM everywhere, 21 = halo kernel where it fits,
-# +128 = 2-D patch kernel for rows wider than 128 px
-BASE = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 0, "halo_persistent": 0}   # auto_mask 0: no rerouting at all
+# knob sets (y3_set_tuning) compared per layer (auto_mask bits: include/yolov3_hip.h, Y3_AM_*)
+AM = _hip
+BASE = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": AM.AM_IGEMM_ONLY}   # no rerouting at all
 VARIANTS = [
     ("igemm_v2", dict(BASE)),
-    ("halo_ws", dict(BASE, auto_mask=21)),
-    ("halo_wsq", dict(BASE, auto_mask=21, halo_persistent=1)),      # persistent, epilogue handed to the loader waves
-    ("patch_8x32", dict(BASE, auto_mask=21 | 128)),
+    ("halo_ws", dict(BASE, auto_mask=AM.AM_HALO_ALL)),
+    ("patch_8x32", dict(BASE, auto_mask=AM.AM_HALO_ALL | AM.AM_PATCH_WIDE)),
     ("igemm_v3_ns3", dict(BASE, igemm_version=3, igemm_ns=3)),
     ("igemm_v3_ns4", dict(BASE, igemm_version=3, igemm_ns=4)),
     ("igemm_v3_bm64_ns4", dict(BASE, igemm_version=3, igemm_ns=4, igemm_bm=64)),
     ("igemm_v3_bm64_ns3", dict(BASE, igemm_version=3, igemm_ns=3, igemm_bm=64)),
-    ("halo_ws_256", dict(BASE, auto_mask=21 | 512)),
-    ("igemm_v2_bn128", dict(BASE, auto_mask=1024)),
-    ("wres_1x1", dict(BASE, auto_mask=8192)),           # weights-resident persistent 1x1 kernel wherever it is supported
+    ("halo_ws_256", dict(BASE, auto_mask=AM.AM_HALO_ALL | AM.AM_HALO_TILE256)),
+    ("igemm_v2_bn128", dict(BASE, auto_mask=AM.AM_NO_BN_SHRINK)),
+    ("wres_1x1", dict(BASE, auto_mask=AM.AM_WRES_ALWAYS)),           # weights-resident persistent 1x1 kernel wherever it is supported
 ]
 
 

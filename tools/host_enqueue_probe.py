@@ -19,7 +19,7 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 print("host cores granted: %d" % len(os.sched_getaffinity(0)))
 for graph in (0, 1, 0, 1):
-    opts = {"auto_mask": _hip.options().auto_mask | 512, "use_graph": graph}
+    opts = {"auto_mask": _hip.options().auto_mask | _hip.AM_HALO_TILE256, "use_graph": graph}
     wl = bench.Workload("yolov3", 608, 16, "bf16", params, dev, 0, 1, 512, 3, options=opts)
     for i in range(12):
         wl.step(wl.frames, i)
