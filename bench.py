@@ -32,6 +32,10 @@ import time
 # RCCL between processes on this driver stack needs dmabuf IPC (already exported on the pool's boxes; kept here so a
 # bare environment behaves the same)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share a queue run one after
+# the other: the PCIe-inclusive variant's copy stream was the fifth stream of the process, so two of its three batches in
+# flight serialised (profiles/r03c_pcie_inclusive.txt: 4.9 k against 6.3 k frames/s).  Read by the runtime at start-up.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pytorch-yolov3_amd"))
@@ -199,15 +203,25 @@ class Workload(object):
         self.rows = out["class_prob"].shape[1]
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
         self.dets = [Detector(batch, self.rows, dev) for _ in range(nstream)]
-        self.gathers = [DetectionGather(batch, self.rows, kmax, dev, world) for _ in range(nstream)]
+        # one side stream for all gathers of this rank: every HIP stream needs a hardware queue of its own to overlap
+        side = torch.cuda.Stream(device=dev) if (world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized())) else None
+        self.gathers = [DetectionGather(batch, self.rows, kmax, dev, world, side=side) for _ in range(nstream)]
         self.h2d = None
+        torch.cuda.synchronize()       # the set-up forward ran on the default stream; the steps run on side streams
 
     def enable_h2d(self, parts=3):
-        self.h2d = dict(parts=parts, host_frames=torch.from_numpy(self.frames_np).pin_memory(),
-                        dev_frames=[torch.empty_like(self.frames) for _ in range(self.nstream)],
+        # TWO device frame buffers per batch in flight: with one, the copy of step i could only start once the forward of
+        # step i - nstream (same stream, same buffer) had finished -- exactly when stream i % nstream was ready for its
+        # next forward, which then waited out the whole copy (0.43 ms of every step, on each stream in turn: measured
+        # 4.8-5.4 k against 6.2-6.5 k frames/s).  With two, the copy of step i only needs step i - 2 nstream to be done.
+        nbuf = 2 * self.nstream
+        self.h2d = dict(parts=parts, engine=os.environ.get("Y3_BENCH_H2D_ENGINE", "kernel"),
+                        blocks=int(os.environ.get("Y3_BENCH_H2D_BLOCKS", "8")),
+                        host_frames=torch.from_numpy(self.frames_np).pin_memory(),
+                        dev_frames=[torch.empty_like(self.frames) for _ in range(nbuf)],
                         copy_stream=torch.cuda.Stream(device=self.dev), host_rec=None,
-                        free_ev=[torch.cuda.Event() for _ in range(self.nstream)],
-                        ready_ev=[torch.cuda.Event() for _ in range(self.nstream)])
+                        free_ev=[torch.cuda.Event() for _ in range(nbuf)],
+                        ready_ev=[torch.cuda.Event() for _ in range(nbuf)])
         for e in self.h2d["free_ev"]:
             e.record()
 
@@ -216,16 +230,22 @@ class Workload(object):
         h = self.h2d if h2d else None
         with torch.cuda.stream(self.streams[k]):
             if h and (h["parts"] & 1):
-                # the copy runs on its own stream (one step ahead of the compute stream that consumes it)
+                # the copy runs on its own stream, into the buffer the forward of step i - 2 nstream read last
+                j = i % len(h["dev_frames"])
                 with torch.cuda.stream(h["copy_stream"]):
-                    h["copy_stream"].wait_event(h["free_ev"][k])
-                    h["dev_frames"][k].copy_(h["host_frames"], non_blocking=True)
-                    h["ready_ev"][k].record(h["copy_stream"])
-                self.streams[k].wait_event(h["ready_ev"][k])
-                fr = h["dev_frames"][k]
+                    h["copy_stream"].wait_event(h["free_ev"][j])
+                    if h["engine"] == "kernel":
+                        from yolov3 import _hip
+                        _hip.check(_hip.lib().y3_copy_bytes(h["host_frames"].data_ptr(), h["dev_frames"][j].data_ptr(),
+                                                            h["host_frames"].numel(), h["blocks"], _hip.stream_ptr()))
+                    else:
+                        h["dev_frames"][j].copy_(h["host_frames"], non_blocking=True)
+                    h["ready_ev"][j].record(h["copy_stream"])
+                self.streams[k].wait_event(h["ready_ev"][j])
+                fr = h["dev_frames"][j]
             o = self.net.forward_frames(fr, fresh=False, slot=k)
             if h and (h["parts"] & 1):
-                h["free_ev"][k].record(self.streams[k])
+                h["free_ev"][j].record(self.streams[k])
             self.dets[k].run(o, self.orig_hw, 0.05, 0.3)
             rec = self.gathers[k].run(self.dets[k])
             if h and (h["parts"] & 2):
@@ -234,7 +254,12 @@ class Workload(object):
                     self.streams[k].wait_event(g.done)
                 if h["host_rec"] is None:
                     h["host_rec"] = [torch.empty(rec.shape, dtype=rec.dtype).pin_memory() for _ in range(self.nstream)]
-                h["host_rec"][k].copy_(rec, non_blocking=True)
+                if h["engine"] == "kernel":
+                    from yolov3 import _hip
+                    _hip.check(_hip.lib().y3_copy_bytes(rec.data_ptr(), h["host_rec"][k].data_ptr(),
+                                                        rec.numel() * rec.element_size(), 4, _hip.stream_ptr()))
+                else:
+                    h["host_rec"][k].copy_(rec, non_blocking=True)
             return rec
 
     def timed(self, steps, warmup, distributed=False, h2d=False):
@@ -546,8 +571,10 @@ def main(argv=None):
         e2 = wl.timed(args.steps, min(args.warmup, 5), False, h2d=True)
         line["pcie_inclusive"] = {
             "value": round(args.batch * args.steps / e2, 2), "unit": "frames/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
-            "what": "same workload, frames start in pinned host memory: H2D copy of the uint8 batch (copy stream, one step "
-                    "ahead) and D2H of the packed detection records inside every step"}
+            "what": "same workload, frames start in pinned host memory and the packed detection records end there, inside every "
+                    "step: y3_copy_bytes on a copy stream (8 workgroups read the pinned frames over PCIe into one of six device "
+                    "buffers) and 4 workgroups writing the records back; GPU_MAX_HW_QUEUES=8 so that the copy stream does not share "
+                    "a hardware queue with a compute stream"}
         # ---- the other single-GPU configurations of BASELINE.json (parity cases; each with its own roofline) -----
         others = []
         for model, dim, batch, dtype in (("yolov3-tiny", 416, 8, "float32"), ("yolov3-spp", 608, 16, "bf16"),

@@ -223,8 +223,15 @@ int y3_cxywh_to_tlbr(const int64_t *d_xywh, int64_t *d_tlbr, int n, int cols, vo
 int y3_resize_bilinear_u8(const uint8_t *d_src, int src_h, int src_w, uint8_t *d_dst, int dst_h, int dst_w,
                           const int32_t *d_ytab, const int32_t *d_xtab, void *stream);
 
+/* frames in / detections out without a copy engine (replaces the `.to(device)` / `.cpu()` transfers around
+ * Darknet.forward, inference.py:335, :338-340): a small grid of `blocks` workgroups (<= 0: 32) moves `nbytes` bytes with
+ * 16-byte accesses.  `src` or `dst` may be PINNED HOST memory, which the GPU addresses directly over PCIe; both must be
+ * 16-byte aligned.  Unlike hipMemcpyAsync it needs no copy-engine hand-over on the stream, so batches in flight on other
+ * streams keep the chip (measured: profiles/r03c_pcie_inclusive.txt). */
+int y3_copy_bytes(const void *src, void *dst, size_t nbytes, int blocks, void *stream);
+
 /* padded fixed-size detection records for the multi-GPU all-gather (no reference counterpart:
- * the reference is single device).  Record = 8 x int32: x1,y1,x2,y2, score bits, class, row, and the
+ * the reference is single device).  Record = 8 x int32: x1,y1,x2,y2 (int64 corners saturated to int32), score bits, class, row, and the
  * frame's TRUE detection count (0 in padding records: the field doubles as the valid flag; a count
  * above kmax means the frame was truncated to its kmax best-ordered detections).
  * d_records (batch, kmax, 8) int32; d_rec_count (batch) int32 also receives the true counts, may be NULL. */

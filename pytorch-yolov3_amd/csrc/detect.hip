@@ -478,7 +478,13 @@ __global__ void pack_records_kernel(const int *cnt, const long long *tlbr, const
     int *o = rec + ((long long)b * kmax + k) * 8;
     if (k < n) {
       const long long *t = tlbr + ((long long)b * rows + k) * 4;
-      o[0] = (int)t[0]; o[1] = (int)t[1]; o[2] = (int)t[2]; o[3] = (int)t[3];
+      // pixel corners are int64 upstream (numpy's astype(int)); a record field is 32 bits: saturate instead of wrapping
+      // (only untrained / adversarial weights produce boxes beyond +-2^31 px: exp(tw) * anchor * width)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const long long v = t[j];
+        o[j] = v > 2147483647ll ? 2147483647 : (v < -2147483648ll ? (int)-2147483648ll : (int)v);
+      }
       o[4] = __float_as_int(prob[(long long)b * rows + k]);
       o[5] = (int)cls[(long long)b * rows + k];
       o[6] = row[(long long)b * rows + k];

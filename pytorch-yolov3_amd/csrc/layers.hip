@@ -380,7 +380,35 @@ __global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t *src, int 
     dst[(long long)idx * 3 + c] = (uint8_t)v;
   }
 }
+
+// Plain byte mover for buffers that a copy engine would otherwise carry: `blocks` workgroups stride over the buffer with
+// 16-byte accesses, four in flight per thread.  Either side may be pinned host memory (the GPU addresses it directly).
+__global__ __launch_bounds__(256) void copy_bytes_kernel(const char *__restrict__ src, char *__restrict__ dst, size_t n16, size_t tail0,
+                                                          size_t nbytes) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const u32x4 *s4 = reinterpret_cast<const u32x4 *>(src);
+  u32x4 *d4 = reinterpret_cast<u32x4 *>(dst);
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const u32x4 a = s4[i], b = s4[i + stride], c = s4[i + 2 * stride], d = s4[i + 3 * stride];
+    d4[i] = a; d4[i + stride] = b; d4[i + 2 * stride] = c; d4[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) d4[i] = s4[i];
+  if (blockIdx.x == 0) for (size_t t = tail0 + threadIdx.x; t < nbytes; t += 256) dst[t] = src[t];
+}
 }  // namespace
+
+extern "C" int y3_copy_bytes(const void *src, void *dst, size_t nbytes, int blocks, void *stream) {
+  Y3_REQUIRE(src && dst, "y3_copy_bytes: null pointer argument");
+  Y3_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "y3_copy_bytes: buffers must be 16-byte aligned");
+  if (nbytes == 0) return Y3_OK;
+  if (blocks < 1) blocks = 32;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(copy_bytes_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const char *>(src), static_cast<char *>(dst), nbytes / 16, nbytes / 16 * 16, nbytes);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
 
 extern "C" int y3_resize_bilinear_u8(const uint8_t *d_src, int src_h, int src_w, uint8_t *d_dst, int dst_h, int dst_w,
                                      const int32_t *d_ytab, const int32_t *d_xtab, void *stream) {

@@ -76,34 +76,48 @@ def unpack_records(records):
 class DetectionGather(object):
     """Device buffers + the per-batch gather of one rank.
 
-    ``run`` packs on the CURRENT (compute) stream, then issues the all-gather on this object's side stream
-    behind an event, and returns the gathered tensor; ``done`` is recorded on the side stream when the
-    gather has finished: consumers on other streams ``wait_event(done)`` (or synchronise the device) before
-    reading it.  Re-running the same object first waits for its previous gather, so the record buffer is
-    never overwritten while RCCL still reads it."""
+    ``run`` packs on the CURRENT (compute) stream of the buffers' device, then issues the all-gather on a side stream
+    behind an event, and returns the gathered tensor; ``done`` is recorded on the side stream when the gather has
+    finished: consumers on other streams ``wait_event(done)`` (or synchronise the device) before reading it.
+    Re-running the same object first waits for its previous gather, so the record buffer is never overwritten while
+    RCCL still reads it -- and for ``consumed`` (``mark_consumed()``), if the caller read the previous result on some
+    other stream, so that result is never overwritten under a reader either.
+    ``side``: a stream shared by several gathers of one rank (HIP maps streams onto a handful of hardware queues;
+    one side stream per batch in flight would make compute streams share queues and serialise them)."""
 
-    def __init__(self, batch, rows, kmax, device, world, group=None):
+    def __init__(self, batch, rows, kmax, device, world, group=None, side=None):
         self.batch, self.rows, self.kmax, self.world, self.group = batch, rows, kmax, world, group
+        self.device = torch.device(device)
         self.records = torch.zeros((batch, kmax, RECORD_INTS), dtype=torch.int32, device=device)
         self.gathered = self.records
         self.collective = world > 1 or (dist.is_available() and dist.is_initialized())
-        self.side = self.packed = self.done = None
-        if self.collective and torch.device(device).type == "cuda":
+        self.side = self.packed = self.done = self.consumed = None
+        if self.collective and self.device.type == "cuda":
             self.gathered = torch.empty((world * batch, kmax, RECORD_INTS), dtype=torch.int32, device=device)
-            self.side = torch.cuda.Stream(device=device)
+            self.side = side if side is not None else torch.cuda.Stream(device=device)
             self.packed = torch.cuda.Event()
             self.done = torch.cuda.Event()
             self.done.record(self.side)
 
+    def mark_consumed(self, stream=None):
+        """Call after enqueueing the last read of the gathered tensor on a stream OTHER than the one ``run`` is called
+        on (reads on that stream are ordered anyway): the next ``run`` waits for it before overwriting the result."""
+        if self.device.type == "cuda":
+            self.consumed = torch.cuda.Event()
+            self.consumed.record(stream if stream is not None else torch.cuda.current_stream(self.device))
+
     def run(self, det):
         """det: yolov3.inference.Detector after ``run``.  Returns the records of all ranks, (world*batch, kmax, 8)."""
         from . import _hip
-        cur = torch.cuda.current_stream()
+        cur = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         if self.side is not None:
             cur.wait_event(self.done)           # the previous gather of this buffer has been read by RCCL
+        if self.consumed is not None:
+            cur.wait_event(self.consumed)       # ... and its result by whoever took it to another stream
+            self.consumed = None
         _hip.check(_hip.lib().y3_pack_records(
             det.count.data_ptr(), det.tlbr.data_ptr(), det.prob.data_ptr(), det.cls.data_ptr(), det.row.data_ptr(),
-            self.batch, self.rows, self.kmax, self.records.data_ptr(), None, _hip.stream_ptr()))
+            self.batch, self.rows, self.kmax, self.records.data_ptr(), None, _hip.stream_ptr(cur)))
         if not self.collective:
             return self.records
         if self.side is None:
