@@ -42,12 +42,11 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-_PKG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pytorch-yolov3_amd")
-if _PKG not in sys.path:
-    sys.path.insert(0, _PKG)
-
-from yolov3.cfgparse import parse_config  # noqa: E402  host-side cfg reader (pinned by G2)
-from yolov3.weights import conv_layout, read_darknet_weights  # noqa: E402
+try:
+    from . import ref_io              # oracle-side cfg / .weights readers, independent of the product's
+except ImportError:                   # imported as a top-level module
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import ref_io
 
 BN_EPS = 1e-5          # torch.nn.BatchNorm2d default, reference darknet.py:252
 LEAKY_SLOPE = 0.1      # reference darknet.py:256
@@ -148,18 +147,18 @@ class OracleDarknet:
     """Functional restatement of reference ``Darknet`` (darknet.py:318-476)."""
 
     def __init__(self, config_fpath):
-        self.blocks, self.net_info = parse_config(config_fpath)
+        self.blocks, self.net_info = ref_io.read_cfg(config_fpath)
         # negative route indices -> absolute (darknet.py:338-343)
         for i, blk in enumerate(self.blocks):
             if blk["type"] == "route":
                 blk["layers"] = [j if j >= 0 else i + j for j in blk["layers"]]
-        _, convs = conv_layout(self.blocks, self.net_info)
-        self._conv_slot = {c["block_idx"]: n for n, c in enumerate(convs)}
+        conv_blocks = [i for i, blk in enumerate(self.blocks) if blk["type"] == "convolutional"]
+        self._conv_slot = {bi: n for n, bi in enumerate(conv_blocks)}
         self.params = None
         self.header = None
 
     def load_weights(self, path):
-        self.header, self.params = read_darknet_weights(path, self.blocks, self.net_info)
+        self.header, self.params = ref_io.read_weights(path, self.blocks, self.net_info["channels"])
         return self
 
     def set_params(self, params):

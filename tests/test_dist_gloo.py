@@ -124,7 +124,29 @@ def test_bench_self_launch_starts_n_ranks(world):
     line = json.loads(lines[0])
     assert line["n_gpus"] == world and line["config"]["global_batch"] == 16 * world
     assert line["plumbing_only"] is True and line["ranks_seen_by_collective"] == world
-    assert line["frames_gathered_per_step"] == 16 * world
+    assert line["frames_gathered_per_step"] == 16 * world and line["scaling"] == "weak"
+    pr = line["per_rank"]      # a slow or starved rank must be visible in the line, not only in the maximum
+    assert len(pr["ms_per_step_by_rank"]) == world == len(pr["host_enqueue_ms_per_step_by_rank"])
+    assert pr["ms_per_step_min"] <= pr["ms_per_step_max"] and pr["usable_cpus_per_rank"] >= 0
+
+
+def test_bench_strong_scaling_splits_128_frames_over_8_ranks():
+    """128 frames in total, split over the ranks (BASELINE.json configs[4] at N = 8: 16 per GPU) -- the
+    same launcher / shard / one-gather-per-step / max-over-ranks skeleton as the weak-scaling run."""
+    r = _run_bench(["--gpus", "8", "--scaling", "strong", "--total-frames", "128", "--steps", "3", "--warmup", "1",
+                    "--no-cpu-baseline"], {"Y3_BENCH_PLUMBING": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 8
+    assert line["config"]["global_batch"] == 128 and line["config"]["frames_per_gpu"] == [16] * 8
+    assert line["frames_gathered_per_step"] == 128
+    assert len(line["per_rank"]["ms_per_step_by_rank"]) == 8
+    r2 = _run_bench(["--gpus", "2", "--scaling", "strong", "--total-frames", "128", "--steps", "2", "--warmup", "0",
+                     "--no-cpu-baseline"], {"Y3_BENCH_PLUMBING": "gloo"})
+    line2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][0])
+    assert line2["config"]["frames_per_gpu"] == [64, 64] and line2["frames_gathered_per_step"] == 128
 
 
 def test_bench_self_launch_propagates_rank_failure():

@@ -17,6 +17,37 @@ from golden_util import (GOLDEN, MODELS, MODEL_DIMS, ROOT, golden_params, golden
                          compare_detections)
 
 
+@pytest.mark.parametrize("model", ["yolov3-tiny", "yolov3", "yolov3-spp", "mini"])
+def test_oracle_readers_are_pinned_and_independent(model, tmp_path):
+    """oracle/ref_io.py (the oracle's OWN cfg / .weights readers: no host code shared with the product) against the JSON
+    dump of the reference's parse_config output, and against the product's readers on the same files."""
+    import json
+    from oracle import ref_io
+    from yolov3 import weights as W
+    from yolov3.cfgparse import parse_config
+    with open(os.path.join(GOLDEN, "parse_config.json")) as fh:
+        want = json.load(fh)[model]
+    blocks, net_info = ref_io.read_cfg(MODELS[model])
+    assert blocks == want["blocks"] and net_info == want["net_info"]
+    src = open(os.path.join(ROOT, "oracle", "ref_io.py")).read() + open(os.path.join(ROOT, "oracle", "darknet_oracle.py")).read()
+    assert "yolov3" not in [ln.split()[1].split(".")[0] for ln in src.splitlines() if ln.startswith(("from ", "import "))]
+    # stream order of the .weights format: what the product's writer wrote, read back by both readers
+    pblocks, pnet = parse_config(MODELS[model])
+    params = W.synth_params(pblocks, pnet, seed=11)
+    path = str(tmp_path / "w.weights")
+    W.write_darknet_weights(path, params)
+    header, got = ref_io.read_weights(path, blocks, net_info["channels"])
+    assert len(got) == len(params) and header.shape == (5,)
+    for a, b in zip(got, params):
+        assert sorted(a) == sorted(k for k in b if k != "block_idx")
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    with open(path, "r+b") as fh:
+        fh.truncate(os.path.getsize(path) - 8)
+    with pytest.raises(RuntimeError):
+        ref_io.read_weights(path, blocks, net_info["channels"])
+
+
 def test_cxywh_to_tlbr_reference_known_answer():
     # /root/reference/tests/test_inference.py:12-23
     xywh = np.array([[5, 8, 10, 13, 10000], [100, 200, 30, 17, 19000]], dtype=np.int64)
