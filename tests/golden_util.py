@@ -28,26 +28,41 @@ def load_jpeg_bgr(name):
     return np.ascontiguousarray(np.asarray(im)[:, :, ::-1])
 
 
-def golden_params(model):
+# objectness bias of the "bench regime" goldens (tools/make_goldens.py: BENCH_OBJ_BIAS): a few hundred candidates per frame
+BENCH_REGIME_OBJ_BIAS = {"yolov3": -8.5, "yolov3-spp": -8.5, "yolov3-tiny": -5.0}
+SAMPLE_IMAGES = ["000000035279.jpg", "000000078170.jpg", "000000229358.jpg", "000000253835.jpg", "000000377368.jpg",
+                 "000000393569.jpg", "000000410880.jpg", "000000529762.jpg", "000000547336.jpg"]
+
+
+def golden_params(model, obj_bias=GOLDEN_OBJ_BIAS):
     """The procedural parameters the golden vectors were generated with."""
     blocks, net_info = parse_config(MODELS[model])
     calib = None if model == "mini" else W.load_calibration(model)
-    return W.synth_params(blocks, net_info, seed=GOLDEN_SEED, obj_bias=GOLDEN_OBJ_BIAS, calib=calib)
+    return W.synth_params(blocks, net_info, seed=GOLDEN_SEED, obj_bias=obj_bias, calib=calib)
 
 
-def golden_weights_path(model, tmp_path=None):
+def golden_weights_path(model, tmp_path=None, obj_bias=GOLDEN_OBJ_BIAS):
     """Write (once per machine) the Darknet-format file the golden run loaded, so tests exercise
     the ordinary ``load_weights`` path."""
     cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), "y3_golden_weights")
     os.makedirs(cache, exist_ok=True)
-    path = os.path.join(cache, "%s_seed%d.weights" % (model, GOLDEN_SEED))
+    tag = "" if obj_bias == GOLDEN_OBJ_BIAS else "_ob%g" % obj_bias
+    path = os.path.join(cache, "%s_seed%d%s.weights" % (model, GOLDEN_SEED, tag))
     blocks, net_info = parse_config(MODELS[model])
     want = 20 + 4 * W.stream_length(blocks, net_info)
     if not (os.path.exists(path) and os.path.getsize(path) == want):
         tmp = path + ".%d.tmp" % os.getpid()
-        W.write_darknet_weights(tmp, golden_params(model))
+        W.write_darknet_weights(tmp, golden_params(model, obj_bias))
         os.replace(tmp, path)
     return path
+
+
+def bench_regime_frame(name, dim):
+    """Frame of a bench-regime golden entry: one of the nine sample_dataset JPEGs (original size) or a procedural frame."""
+    from yolov3.synthdata import synth_frames
+    if name.startswith("img"):
+        return load_jpeg_bgr("000000%s.jpg" % name[3:])
+    return synth_frames(int(name[5:]), 1, dim, dim)[0]
 
 
 def product_candidates(bbox, prob, cls, orig_shape, prob_thresh):

@@ -311,3 +311,44 @@ def test_bf16_post_nms_agreement_vs_reference(model):
             else:           # a handful of scores: no percentiles, the bf16 score error as such (p99 ~ 2e-2 on these networks)
                 assert dp.max() <= 3e-2
             assert cls_same >= 0.99
+
+
+@pytest.mark.parametrize("model", ["yolov3-tiny", "yolov3", "yolov3-spp"])
+def test_bf16_post_nms_agreement_at_the_bench_regime(model):
+    """The same comparison at the objectness bias the throughput is measured at (tens of kept boxes per frame), on the nine
+    sample images and the procedural frames of inference_bench_regime_<model>.npz, one image per call.  Pooled keep-set
+    Jaccard against the reference's float32 lists, asserted against what the bf16-emulating oracle reaches
+    (bf16_agreement.json "bench_regime"); scores on common rows within the bf16 score error."""
+    from golden_util import BENCH_REGIME_OBJ_BIAS, bench_regime_frame
+    g = np.load(os.path.join(GOLDEN, "inference_bench_regime_%s.npz" % model))
+    fixture = bf16_agreement()["bench_regime"][model]
+    dim = MODEL_DIMS[model]
+    net = yolov3.Darknet(MODELS[model], device="cuda", dtype="bf16")
+    net.load_weights(golden_weights_path(model, obj_bias=BENCH_REGIME_OBJ_BIAS[model])).eval()
+    for tag in ("a", "b"):
+        pth, ith = g[tag + "_thresholds"]
+        common = union = 0
+        dps, cls_ok = [], []
+        for name in (str(n) for n in g["names"]):
+            frame = bench_regime_frame(name, dim)
+            res = yolov3.inference(net, frame, device="cuda", prob_thresh=float(pth), nms_iou_thresh=float(ith), return_rows=True)[0]
+            key = "%s_%s_" % (name, tag)
+            rows, want = set(int(r) for r in res[3]), set(g[key + "rows"].tolist())
+            common += len(rows & want)
+            union += len(rows | want)
+            gi = {int(r): k for k, r in enumerate(g[key + "rows"])}
+            for k, r in enumerate(res[3]):
+                if int(r) in gi:
+                    dps.append(abs(float(res[1][k]) - float(g[key + "prob"][gi[int(r)]])))
+                    cls_ok.append(int(res[2][k]) == int(g[key + "cls"][gi[int(r)]]))
+        jac = common / max(union, 1)
+        fl = fixture["all_" + tag]
+        dps = np.array(dps) if dps else np.zeros(1)
+        print("%s %s: pooled keep-set Jaccard %.3f (ideal bf16 %.3f; %d common of %d), score |d| median %.1e max %.1e, class agreement %.4f"
+              % (model, tag, jac, fl["jaccard"], common, union, np.median(dps), dps.max(), np.mean(cls_ok) if cls_ok else 1.0))
+        if fl["union"] >= 100:
+            assert jac >= fl["jaccard"] - 0.08
+        else:
+            assert (union - common) <= (fl["union"] - fl["common"]) + 4
+        assert np.median(dps) <= 1e-2 and dps.max() <= 6e-2
+        assert not cls_ok or np.mean(cls_ok) >= 0.98

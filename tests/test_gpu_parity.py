@@ -185,6 +185,46 @@ def test_inference_golden_fp32(model):
                   "keep-set diff", ndiff, "box diffs", nbad)
 
 
+@pytest.mark.parametrize("model", ["yolov3-tiny", "yolov3", "yolov3-spp"])
+def test_inference_bench_regime_all_sample_images_fp32(model):
+    """G7': the reference's ``inference()`` lists at the BENCHMARKED regime (a few hundred candidates, tens of kept boxes
+    per frame), one call per image like the reference's own test (/root/reference/tests/test_inference.py:51-59), on all
+    nine sample_dataset JPEGs and on procedural frames the generator audited.
+    AUDITED-CLEAN (frame, threshold) pairs -- every candidate >= 2e-3 px from an integer pixel, every score >= 1e-4 from
+    the threshold, every class margin >= 1e-4 -- must reproduce the reference EXACTLY: identical rows, classes and integer
+    boxes after NMS, no exemption path (``cand=None``).  The other pairs use the flip rule of compare_detections."""
+    from golden_util import BENCH_REGIME_OBJ_BIAS, bench_regime_frame, product_candidates
+    g = np.load(os.path.join(GOLDEN, "inference_bench_regime_%s.npz" % model))
+    dim = MODEL_DIMS[model]
+    net = yolov3.Darknet(MODELS[model], device="cuda", dtype="float32")
+    net.load_weights(golden_weights_path(model, obj_bias=BENCH_REGIME_OBJ_BIAS[model])).eval()
+    names = [str(n) for n in g["names"]]
+    assert sum(n.startswith("img") for n in names) == 9
+    n_clean = kept_clean = 0
+    for name in names:
+        frame = bench_regime_frame(name, dim)
+        fwd = {k: v.cpu().numpy() for k, v in net.forward_frames(resize_bilinear_u8(frame, dim, dim)[None]).items()}
+        for tag in ("a", "b"):
+            pth, ith = g[tag + "_thresholds"]
+            key = "%s_%s_" % (name, tag)
+            res = yolov3.inference(net, frame, device="cuda", prob_thresh=float(pth), nms_iou_thresh=float(ith), return_rows=True)[0]
+            clean = bool(g[key + "audit"][4])
+            if clean:
+                order = np.argsort(res[3])
+                gorder = np.argsort(g[key + "rows"])
+                assert np.array_equal(res[3][order], g[key + "rows"][gorder]), (model, name, tag, "kept rows differ")
+                assert np.array_equal(res[2][order], g[key + "cls"][gorder]), (model, name, tag, "classes differ")
+                assert np.array_equal(res[0][order], g[key + "tlbr"][gorder]), (model, name, tag, "boxes differ")
+                np.testing.assert_allclose(res[1][order], g[key + "prob"][gorder], atol=SCORE_ATOL)
+                n_clean += 1
+                kept_clean += len(res[1])
+            else:
+                cand = product_candidates(fwd["bbox_xywh"][0], fwd["class_prob"][0], fwd["class_idx"][0], frame.shape, pth)
+                compare_detections(g, key, res[:3], rows=res[3], prob_tol=SCORE_ATOL, cand=cand)
+    print(model, "audited-clean (frame, threshold) pairs reproduced exactly:", n_clean, "with", kept_clean, "kept boxes in all")
+    assert n_clean >= 4
+
+
 def test_device_resize_is_bit_identical_to_host_resize():
     from yolov3.preprocess import resize_on_device
     for name, (oh, ow) in (("000000229358.jpg", (608, 608)), ("000000393569.jpg", (416, 416)), ("000000035279.jpg", (320, 480))):

@@ -161,6 +161,29 @@ def test_inference_golden_tiny(tmp_path):
 # bf16 emulation mode of the oracle (checker of the product's bf16 path, tests/test_gpu_bf16.py)
 # ---------------------------------------------------------------------------------------------------
 
+@pytest.mark.parametrize("model", ["yolov3-tiny", "yolov3"])
+def test_inference_bench_regime_goldens(model, tmp_path):
+    """G7': the reference's inference() at the benchmarked regime on all nine sample_dataset images (one call per image,
+    like /root/reference/tests/test_inference.py:51-59) and on audited procedural frames: the oracle reproduces every
+    list exactly -- rows, classes, integer boxes, scores."""
+    from golden_util import BENCH_REGIME_OBJ_BIAS, bench_regime_frame, compare_detections
+    g = np.load(os.path.join(GOLDEN, "inference_bench_regime_%s.npz" % model))
+    assert float(g["obj_bias"]) == BENCH_REGIME_OBJ_BIAS[model]
+    net = orc.OracleDarknet(MODELS[model]).load_weights(golden_weights_path(model, tmp_path, obj_bias=BENCH_REGIME_OBJ_BIAS[model]))
+    names = [str(n) for n in g["names"]]
+    assert sum(n.startswith("img") for n in names) == 9
+    for name in names if model == "yolov3-tiny" else names[:3] + names[-2:]:      # (yolov3 on CPU: a subset keeps the suite short)
+        dim = MODEL_DIMS[model]
+        frame = bench_regime_frame(name, dim)
+        out = net.forward(torch.from_numpy(orc.frames_to_input([resize_bilinear_u8(frame, dim, dim)])))
+        for tag in ("a", "b"):
+            pth, ith = g[tag + "_thresholds"]
+            res = orc.postprocess(out["bbox_xywh"].numpy(), out["class_prob"].numpy(), out["class_idx"].numpy(),
+                                  [frame.shape], float(pth), float(ith), audit=True)
+            ndiff, nbad, _ = compare_detections(g, "%s_%s_" % (name, tag), res[0][:3], rows=res[0][3])
+            assert ndiff == 0 and nbad == 0        # same machine, same libraries as the golden run: exact
+
+
 def test_bf16_rounding_points():
     net = orc.OracleDarknet(MODELS["yolov3"])
     rounds = net.bf16_rounding_points()

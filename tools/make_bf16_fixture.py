@@ -20,7 +20,8 @@ for p in (os.path.join(ROOT, "pytorch-yolov3_amd"), ROOT, os.path.join(ROOT, "te
     sys.path.insert(0, p)
 
 from oracle import darknet_oracle as orc  # noqa: E402
-from golden_util import GOLDEN, MODELS, MODEL_DIMS, golden_params, load_jpeg_bgr  # noqa: E402
+from golden_util import (BENCH_REGIME_OBJ_BIAS, GOLDEN, MODELS, MODEL_DIMS, bench_regime_frame, golden_params,  # noqa: E402
+                         load_jpeg_bgr)
 from yolov3.preprocess import resize_bilinear_u8  # noqa: E402
 from yolov3.synthdata import synth_frames  # noqa: E402
 
@@ -34,6 +35,38 @@ def agreement(det, g, prefix):
     dp = np.array([abs(float(det[1][mine[r]]) - gp[r]) for r in common]) if common else np.zeros(1)
     return dict(jaccard=round(len(rows & want) / len(rows | want), 4) if rows | want else 1.0, kept=len(rows), ref_kept=len(want),
                 score_med=float(np.median(dp)), score_p99=float(np.percentile(dp, 99)), score_max=float(dp.max()))
+
+
+def bench_regime():
+    """The same floors at the BENCHMARKED regime (objectness bias -8.5 / -5.0: tens of kept boxes per frame, like trained
+    weights) on every frame of tests/golden/inference_bench_regime_<model>.npz: the nine sample images and the procedural
+    frames, one image per call.  ``all`` pools the frames: |intersection| / |union| of kept rows summed over frames."""
+    out = {}
+    for model in ("yolov3-tiny", "yolov3", "yolov3-spp"):
+        g = np.load(os.path.join(GOLDEN, "inference_bench_regime_%s.npz" % model))
+        dim = MODEL_DIMS[model]
+        net = orc.OracleDarknet(MODELS[model]).set_params(golden_params(model, BENCH_REGIME_OBJ_BIAS[model]))
+        entry = {}
+        pool = {t: [0, 0] for t in ("a", "b")}
+        for name in (str(n) for n in g["names"]):
+            frame = bench_regime_frame(name, dim)
+            x = torch.from_numpy(orc.frames_to_input([resize_bilinear_u8(frame, dim, dim)]))
+            o = net.forward(x, emulate_bf16=True, accumulate="f32")
+            for tag in ("a", "b"):
+                pth, ith = g[tag + "_thresholds"]
+                det = orc.postprocess(o["bbox_xywh"].numpy(), o["class_prob"].numpy(), o["class_idx"].numpy(), [frame.shape],
+                                      float(pth), float(ith), audit=True)[0]
+                key = "%s_%s" % (name, tag)
+                entry[key] = agreement(det, g, key + "_")
+                rows, want = set(int(r) for r in det[3]), set(g[key + "_rows"].tolist())
+                pool[tag][0] += len(rows & want)
+                pool[tag][1] += len(rows | want)
+                print(model, key, entry[key])
+        for tag in ("a", "b"):
+            entry["all_" + tag] = dict(jaccard=round(pool[tag][0] / max(pool[tag][1], 1), 4), common=pool[tag][0], union=pool[tag][1])
+            print(model, "all", tag, entry["all_" + tag])
+        out[model] = entry
+    return out
 
 
 def main():
@@ -60,6 +93,7 @@ def main():
                         entry[key]["jaccard_f64acc"] = a["jaccard"]
                     print(model, acc, key, a)
         table[model] = entry
+    table["bench_regime"] = bench_regime()
     with open(os.path.join(GOLDEN, "bf16_agreement.json"), "w") as fh:
         json.dump(table, fh, indent=1, sort_keys=True)
 
