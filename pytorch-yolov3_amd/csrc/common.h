@@ -81,6 +81,17 @@ __device__ __forceinline__ int y3_xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// Output-channel placement that makes a lane's accumulators of an MFMA fragment PAIR eight consecutive channels.
+// v_mfma_f32_16x16x32 leaves lane (fr, fq) with rows 4 fq .. 4 fq + 3 of each 16-row fragment for column (pixel) fr.  If,
+// inside every aligned block of 32 weight rows (fragments h = 0, 1), row h*16 + 4q + i carries channel 8q + 4h + i, the
+// lane holds channels 8 fq .. 8 fq + 7 of its pixel after both fragments: one 16-byte LDS write (8-lane groups, no
+// conflicts with the usual XOR swizzle or an odd multiple of 16 bytes as pixel pitch) instead of two 8-byte ones whose
+// 16-lane groups hit every 128-byte bank window twice or four times (tools/lds_conflicts.py).  Which row of a
+// fragment a channel occupies does not enter any sum: results are bit-identical.
+__host__ __device__ __forceinline__ constexpr int y3_pair_perm(int j) {
+  return (j & ~31) | (((j >> 2) & 3) << 3) | (((j >> 4) & 1) << 2) | (j & 3);
+}
+
 template <typename T>
 __device__ __forceinline__ float y3_to_float(T v);
 template <>

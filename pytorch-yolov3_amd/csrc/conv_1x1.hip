@@ -80,7 +80,10 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wres_kernel(WresArgs p) {
     const int kc = slot ^ (row0 & 7);
     // ---- weights: n_kt x BN rows of 128 bytes, K-tile major
     for (int r = row0; r < p.n_kt * BN; r += 32) {
-      const int kt = r / BN, co = r - kt * BN;
+      const int kt = r / BN, j = r - kt * BN;
+      // LDS row j holds output channel y3_pair_perm(j) (common.h): after the MFMAs a lane's accumulators of a fragment
+      // pair are eight consecutive channels of its pixel -- one 16-byte park write.  The K loop reads the same LDS rows.
+      const int co = y3_pair_perm(j);
       const char *src = p.wgt + ((long long)(n0 + co) * p.k_ld + kt * 64) * 2 + kc * 16;
       __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(sW + (r - row0) * 128 + lwave * 1024), 16, 0, 0);
     }
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wres_kernel(WresArgs p) {
   f32x4 sc[NI], bi[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
-    const int c = n0 + wn * TN + ni * 16 + fq * 4;
+    const int c = n0 + wn * TN + (ni >> 1) * 32 + fq * 8 + (ni & 1) * 4;   // channels of acc[.][ni] (row permutation above)
     sc[ni] = *reinterpret_cast<const f32x4 *>(p.scale + c);
     bi[ni] = *reinterpret_cast<const f32x4 *>(p.bias + c);
   }
@@ -170,17 +173,21 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wres_kernel(WresArgs p) {
     for (int mi = 0; mi < MI; ++mi) {
       const int pl = wm * 64 + mi * 16 + fr;
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int cl = wn * TN + ni * 16 + fq * 4;
-        const f32x2 t0 = f32x2{acc[mi][ni][0], acc[mi][ni][1]} * f32x2{sc[ni][0], sc[ni][1]} + f32x2{bi[ni][0], bi[ni][1]};
-        const f32x2 t1 = f32x2{acc[mi][ni][2], acc[mi][ni][3]} * f32x2{sc[ni][2], sc[ni][3]} + f32x2{bi[ni][2], bi[ni][3]};
-        const f32x2 s0 = t0 * slope, s1 = t1 * slope;
-        bf16x4 o;
-        o[0] = (bf16_t)y3_vmax(t0[0], s0[0]);
-        o[1] = (bf16_t)y3_vmax(t0[1], s0[1]);
-        o[2] = (bf16_t)y3_vmax(t1[0], s1[0]);
-        o[3] = (bf16_t)y3_vmax(t1[1], s1[1]);
-        *reinterpret_cast<bf16x4 *>(sP + pl * (BN * 2) + (((cl >> 3) ^ (pl & (OCT - 1))) << 4) + ((cl >> 2) & 1) * 8) = o;
+      for (int k = 0; k < NI / 2; ++k) {
+        bf16x8 o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ni = 2 * k + h;
+          const f32x2 t0 = f32x2{acc[mi][ni][0], acc[mi][ni][1]} * f32x2{sc[ni][0], sc[ni][1]} + f32x2{bi[ni][0], bi[ni][1]};
+          const f32x2 t1 = f32x2{acc[mi][ni][2], acc[mi][ni][3]} * f32x2{sc[ni][2], sc[ni][3]} + f32x2{bi[ni][2], bi[ni][3]};
+          const f32x2 s0 = t0 * slope, s1 = t1 * slope;
+          o[4 * h + 0] = (bf16_t)y3_vmax(t0[0], s0[0]);
+          o[4 * h + 1] = (bf16_t)y3_vmax(t0[1], s0[1]);
+          o[4 * h + 2] = (bf16_t)y3_vmax(t1[0], s1[0]);
+          o[4 * h + 3] = (bf16_t)y3_vmax(t1[1], s1[1]);
+        }
+        const int oc = wn * (TN / 8) + k * 4 + fq;                       // 16-byte chunk of the pixel's row
+        *reinterpret_cast<bf16x8 *>(sP + pl * (BN * 2) + ((oc ^ (pl & (OCT - 1))) << 4)) = o;
       }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);

@@ -352,13 +352,13 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  const int cq = fq * 4;
   const bool is_stem = wave >= NC;
 
   // ---- once per workgroup ----
   for (int i = tid; i < 64 * 36; i += NT) {                            // second conv's weights: 36 chunks of 16 bytes per channel
-    const int co = i / 36, ch = i - co * 36;
-    *reinterpret_cast<u32x4 *>(w1s + co * kW1Pitch + ch * 16) =
+    const int j = i / 36, ch = i - j * 36;
+    const int co = y3_pair_perm(j);                                     // LDS row j holds channel co (common.h)
+    *reinterpret_cast<u32x4 *>(w1s + j * kW1Pitch + ch * 16) =
         *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.w1) + ((long long)co * p.k_ld1) * 2 + ch * 16);
   }
   for (int i = tid; i < 2 * kPInBytes / 4; i += NT) reinterpret_cast<uint32_t *>(in_tile)[i] = 0u;
@@ -401,7 +401,8 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
         const int ky = k / 12, rem = k - ky * 12, kx = rem >> 2, c = rem & 3;
         const bool live = k < 36 && c < 3;
         const int kold = live ? ky * 9 + kx * 3 + c : 0;
-        const bf16_t za = p.w0[(0 + fr) * 32 + kold], zb = p.w0[(16 + fr) * 32 + kold];
+        // MFMA row fr of the first / second fragment is channel 8 (fr >> 2) + (fr & 3) (+ 4): y3_pair_perm
+        const bf16_t za = p.w0[y3_pair_perm(fr) * 32 + kold], zb = p.w0[y3_pair_perm(16 + fr) * 32 + kold];
         w0a[st][j] = live ? za : (bf16_t)0.f;
         w0b[st][j] = live ? zb : (bf16_t)0.f;
       }
@@ -415,8 +416,8 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
     f32x4 sc0[2], bi0[2];
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-      sc0[ni] = *reinterpret_cast<const f32x4 *>(p.sc0 + ni * 16 + cq);
-      bi0[ni] = *reinterpret_cast<const f32x4 *>(p.bi0 + ni * 16 + cq);
+      sc0[ni] = *reinterpret_cast<const f32x4 *>(p.sc0 + fq * 8 + ni * 4);
+      bi0[ni] = *reinterpret_cast<const f32x4 *>(p.bi0 + fq * 8 + ni * 4);
     }
     // fragments of this wave: f = sw + NS j; lane fr handles stem pixel q = 16 f + fr
     int fr_patch[kIters];                                               // byte offset of the pixel's patch element 0
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
       fr_patch[j] = (sy * kInPitch + sx * 4) * 2;
       fr_live |= (q < kPNStem ? 1u : 0u) << j;
     }
-    const int stem_wr = ((sw * 16 + fr) * kStemPitch) + cq * 2;        // + j * NS * 16 * kStemPitch + ni * 32
+    const int stem_wr = ((sw * 16 + fr) * kStemPitch) + fq * 16;       // + j * NS * 16 * kStemPitch; channels 8 fq .. 8 fq + 7
     // input patch as byte PAIRS (half the registers per tile in flight): pair k of patch row r = bytes 2k, 2k + 1.
     // pr_dst: LDS byte offset of the first byte's bf16 element | bit 0: the second byte skips the zero channel (its
     // element is two further, not one); the last pair of a row only has its first byte inside the patch.
@@ -528,8 +529,7 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
           }
           if ((fr_live >> (g + j)) & 1u) {
             char *dst = img + stem_wr + (g + j) * (NS * 16 * kStemPitch);
-            *reinterpret_cast<u32x2 *>(dst) = o0;
-            *reinterpret_cast<u32x2 *>(dst + 32) = o1;
+            *reinterpret_cast<u32x4 *>(dst) = u32x4{o0[0], o0[1], o1[0], o1[1]};   // one 16-byte write: no bank conflicts at 80-byte pitch
           }
         }
       };
@@ -609,8 +609,8 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
   f32x4 s1v[4], b1v[4];
 #pragma unroll
   for (int nf = 0; nf < 4; ++nf) {
-    s1v[nf] = *reinterpret_cast<const f32x4 *>(p.sc1 + nf * 16 + cq);
-    b1v[nf] = *reinterpret_cast<const f32x4 *>(p.bi1 + nf * 16 + cq);
+    s1v[nf] = *reinterpret_cast<const f32x4 *>(p.sc1 + (nf >> 1) * 32 + fq * 8 + (nf & 1) * 4);   // channels of acc[.][nf]
+    b1v[nf] = *reinterpret_cast<const f32x4 *>(p.bi1 + (nf >> 1) * 32 + fq * 8 + (nf & 1) * 4);
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();     // S1
@@ -652,10 +652,10 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
-        const int co = nf * 16 + cq;
-        *reinterpret_cast<u32x2 *>(my_stage + mr * 2048 + fr * 128 + (((co >> 3) ^ (fr & 7)) << 4) + (co & 7) * 2) =
-            bn_leaky_bf16x4(acc[mr][nf], s1v[nf], b1v[nf]);
+      for (int k = 0; k < 2; ++k) {                                      // fragment pair k: channels 32 k + 8 fq .. + 7
+        const u32x2 lo = bn_leaky_bf16x4(acc[mr][2 * k], s1v[2 * k], b1v[2 * k]);
+        const u32x2 hi = bn_leaky_bf16x4(acc[mr][2 * k + 1], s1v[2 * k + 1], b1v[2 * k + 1]);
+        *reinterpret_cast<u32x4 *>(my_stage + mr * 2048 + fr * 128 + (((k * 4 + fq) ^ (fr & 7)) << 4)) = u32x4{lo[0], lo[1], hi[0], hi[1]};
       }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -725,26 +725,27 @@ __global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs p
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fr = lane & 15, fq = lane >> 4, cq = fq * 4;
+  const int fr = lane & 15, fq = lane >> 4;
 
   for (int i = tid; i < 64 * 36; i += kThreads) {
-    const int co = i / 36, ch = i - co * 36;
-    *reinterpret_cast<u32x4 *>(w3s + co * kW1Pitch + ch * 16) =
+    const int j = i / 36, ch = i - j * 36;
+    const int co = y3_pair_perm(j);                                     // LDS row j holds channel co (common.h)
+    *reinterpret_cast<u32x4 *>(w3s + j * kW1Pitch + ch * 16) =
         *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.w3) + ((long long)co * p.k_ld3) * 2 + ch * 16);
   }
-  // 1x1 weights: A fragments [co-frag][K step], lane (co = fr, k = ks*32 + fq*8 ..)
+  // 1x1 weights: A fragments [co-frag][K step], lane (MFMA row fr = channel y3_pair_perm(ni*16 + fr), k = ks*32 + fq*8 ..)
   u32x4 w2f[2][2];
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
       w2f[ni][ks] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.w2) +
-                                                    ((long long)(ni * 16 + fr) * p.k_ld2 + ks * 32 + fq * 8) * 2);
+                                                    ((long long)y3_pair_perm(ni * 16 + fr) * p.k_ld2 + ks * 32 + fq * 8) * 2);
   f32x4 sc2[2], bi2[2];
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
-    sc2[ni] = *reinterpret_cast<const f32x4 *>(p.sc2 + ni * 16 + cq);
-    bi2[ni] = *reinterpret_cast<const f32x4 *>(p.bi2 + ni * 16 + cq);
+    sc2[ni] = *reinterpret_cast<const f32x4 *>(p.sc2 + fq * 8 + ni * 4);
+    bi2[ni] = *reinterpret_cast<const f32x4 *>(p.bi2 + fq * 8 + ni * 4);
   }
 
   auto tile_origin = [&](int tile, int &b, int &oy0, int &ox0) {
@@ -798,15 +799,17 @@ __global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs p
       const u32x4 xb = *reinterpret_cast<const u32x4 *>(xt + qc * 128 + (((4 + fq) ^ (qc & 7)) << 4));
       const int r = qc / kRP, cc = qc - r * kRP;
       const bool inside = (unsigned)(oy0 - 1 + r) < (unsigned)p.H && (unsigned)(ox0 - 1 + cc) < (unsigned)p.W;
+      u32x2 o[2];
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2f[ni][0]), __builtin_bit_cast(bf16x8, xa), a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2f[ni][1]), __builtin_bit_cast(bf16x8, xb), a, 0, 0, 0);
-        u32x2 o = bn_leaky_bf16x4(a, sc2[ni], bi2[ni]);
-        if (!inside) o = u32x2{0u, 0u};                                  // the 3x3's zero padding
-        if (q < kRNP) *reinterpret_cast<u32x2 *>(yt + q * kYPitch + (ni * 16 + cq) * 2) = o;
+        o[ni] = bn_leaky_bf16x4(a, sc2[ni], bi2[ni]);
+        if (!inside) o[ni] = u32x2{0u, 0u};                              // the 3x3's zero padding
       }
+      // channels 8 fq .. 8 fq + 7 of pixel q: one 16-byte write
+      if (q < kRNP) *reinterpret_cast<u32x4 *>(yt + q * kYPitch + fq * 16) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
     }
     const int next_tile = tile + gridDim.x;
     u32x4 pre[kXPre];
@@ -842,26 +845,32 @@ __global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs p
 
     // ---- phase C: bn + leaky, + shortcut operand from the x patch, -> bf16 -> staging ----------------------
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-      const f32x4 s3 = *reinterpret_cast<const f32x4 *>(p.sc3 + nf * 16 + cq);
-      const f32x4 b3 = *reinterpret_cast<const f32x4 *>(p.bi3 + nf * 16 + cq);
-      const int co = nf * 16 + cq;
+    for (int k = 0; k < 2; ++k) {                                        // fragment pair k: channels 32 k + 8 fq .. + 7
+      f32x4 s3[2], b3[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        s3[h] = *reinterpret_cast<const f32x4 *>(p.sc3 + k * 32 + fq * 8 + h * 4);
+        b3[h] = *reinterpret_cast<const f32x4 *>(p.bi3 + k * 32 + fq * 8 + h * 4);
+      }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         const int oyl = 2 * wave + mi;
         const int pp = (oyl + 1) * kRP + fr + 1;                          // this output pixel inside the patch
-        const u32x2 xr = *reinterpret_cast<const u32x2 *>(xt + pp * 128 + (((co >> 3) ^ (pp & 7)) << 4) + (co & 7) * 2);
-        const bf16x4 xv = __builtin_bit_cast(bf16x4, xr);
-        const f32x4 a = acc[mi][nf];
-        bf16x4 o;
+        const u32x4 xr = *reinterpret_cast<const u32x4 *>(xt + pp * 128 + (((k * 4 + fq) ^ (pp & 7)) << 4));
+        const bf16x8 xv = __builtin_bit_cast(bf16x8, xr);
+        bf16x8 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = a[r] * s3[r] + b3[r];
-          v = y3_vmax(v, Y3_LEAKY_SLOPE * v);
-          o[r] = (bf16_t)(v + (float)xv[r]);
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 a = acc[mi][2 * k + h];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = a[r] * s3[h][r] + b3[h][r];
+            v = y3_vmax(v, Y3_LEAKY_SLOPE * v);
+            o[4 * h + r] = (bf16_t)(v + (float)xv[4 * h + r]);
+          }
         }
         const int px = oyl * kRT + fr;
-        *reinterpret_cast<bf16x4 *>(yt + px * 128 + (((co >> 3) ^ (px & 7)) << 4) + (co & 7) * 2) = o;
+        *reinterpret_cast<bf16x8 *>(yt + px * 128 + (((k * 4 + fq) ^ (px & 7)) << 4)) = o;
       }
     }
     __syncthreads();   // B4: staging complete; the x patch is dead

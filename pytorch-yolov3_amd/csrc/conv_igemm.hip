@@ -333,7 +333,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
   static_assert(MI >= 1 && NI >= 1 && A_CH >= 1 && B_CH >= 1, "tile too small");
   // the fp32 output tile is written out in EP passes of RP pixel rows each (it must fit in the stages)
   // (the detection-head form parks its whole padded logit tile at once, so that the decode's passes are full)
-  constexpr int LDS_BYTES = DECODE && BM * (BN + 1) * 4 > 2 * STAGE ? BM * (BN + 1) * 4 : 2 * STAGE;
+  constexpr int LDL = BN + 4;                        // row stride of the parked logit tile (floats), detection-head form
+  constexpr int LDS_BYTES = DECODE && BM * LDL * 4 > 2 * STAGE ? BM * LDL * 4 : 2 * STAGE;
   constexpr int EP = (BM * BN * 4 + LDS_BYTES - 1) / LDS_BYTES <= 1 ? 1 : ((BM * BN * 4 + LDS_BYTES - 1) / LDS_BYTES <= 2 ? 2 : 4);
   constexpr int RP = BM / EP;
   static_assert(RP * BN * 4 <= LDS_BYTES && (RP % TM == 0 || TM % RP == 0), "epilogue tile must fit in the operand stages");
@@ -542,11 +543,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
         if (prow / RP == h) {
           const int pl = prow + fr - h * RP;
           if constexpr (DECODE) {
-            // logits = sum * scale + bias (the conv epilogue's single fused rounding), row stride BN + 1 floats
+            // logits = sum * scale + bias (the conv epilogue's single fused rounding).  Row stride BN + 4 floats: one
+            // 16-byte write per fragment whose 8-lane groups cover a 128-byte bank window exactly (1040 B = 65 x 16), and
+            // the decode's per-box reads collide 2-way instead of 3-way at BN + 1 (tools/lds_conflicts.py)
             const f32x4 hs = *reinterpret_cast<const f32x4 *>(p.scale + n0 + cl);
             const f32x4 hb = *reinterpret_cast<const f32x4 *>(p.bias + n0 + cl);
+            f32x4 lg;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sC[pl * (BN + 1) + cl + r] = __builtin_fmaf(acc[mi][ni][r], hs[r], hb[r]);
+            for (int r = 0; r < 4; ++r) lg[r] = __builtin_fmaf(acc[mi][ni][r], hs[r], hb[r]);
+            *reinterpret_cast<f32x4 *>(sC + pl * LDL + cl) = lg;
           } else {
             *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
           }
@@ -555,8 +560,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
     }
     __syncthreads();
     if constexpr (DECODE) {
-      static_assert(RP * (BN + 1) * 4 <= LDS_BYTES, "padded logit tile must fit in the operand stages");
-      head_decode_rows<NT, BN + 1>(p, sC, m0 + h * RP, RP, tid);
+      static_assert(RP * LDL * 4 <= LDS_BYTES, "padded logit tile must fit in the operand stages");
+      head_decode_rows<NT, LDL>(p, sC, m0 + h * RP, RP, tid);
       continue;
     }
     if (nvalid <= 0) continue;
@@ -1119,7 +1124,7 @@ int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d
   a.y_row_offset = op1.row_offset; a.y_rows_total = op1.rows_total;
   a.y_net_w = op1.net_w; a.y_net_h = op1.net_h;
   for (int i = 0; i < 8; ++i) { a.y_aw[i] = op1.anchor_w[i]; a.y_ah[i] = op1.anchor_h[i]; }
-  // 64 pixels x all 255 channels per workgroup: 80 KiB of LDS (two operand stages; the padded logit tile of 64 x 257 floats
+  // 64 pixels x all 255 channels per workgroup: 80 KiB of LDS (two operand stages; the padded logit tile of 64 x 260 floats
   // is parked in them), so two workgroups share a CU and one's decode runs under the other's loads (128-pixel tiles, one
   // per CU, measured equal in isolation: profiles/r02n_heads.txt)
   a.n_tiles = 1;
