@@ -430,7 +430,8 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
       fr_patch[j] = (sy * kInPitch + sx * 4) * 2;
       fr_live |= (q < kPNStem ? 1u : 0u) << j;
     }
-    const int stem_wr = ((sw * 16 + fr) * kStemPitch) + fq * 16;       // + j * NS * 16 * kStemPitch; channels 8 fq .. 8 fq + 7
+    int stem_wr = ((sw * 16 + fr) * kStemPitch) + fq * 16;             // + j * NS * 16 * kStemPitch; channels 8 fq .. 8 fq + 7
+    asm volatile("" : "+v"(stem_wr));                                   // one live register (kept as its two terms it spilled)
     // input patch as byte PAIRS (half the registers per tile in flight): pair k of patch row r = bytes 2k, 2k + 1.
     // pr_dst: LDS byte offset of the first byte's bf16 element | bit 0: the second byte skips the zero channel (its
     // element is two further, not one); the last pair of a row only has its first byte inside the patch.
