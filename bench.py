@@ -46,7 +46,7 @@ import torch  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "float32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA)
 MODEL_FLOPS_PER_FRAME = {("yolov3", 608): 140.692e9, ("yolov3-tiny", 416): 5.565e9, ("yolov3-spp", 608): 141.449e9}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 
 def parse_args(argv=None):
@@ -368,8 +368,10 @@ class Workload(object):
         achieved = dk["flops"] / (dk["ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[self.dtype]
         traffic = None
-        if traffic_table:
-            traffic = traffic_table.get("kernels", {}).get(report["dominant"], {}).get("traffic_bytes_per_launch")
+        if traffic_table:                                 # per workload: a kernel's mean traffic depends on the layers it runs
+            key = "%s_%d_b%d_%s" % (self.model, self.dim, self.batch, self.dtype)
+            kern = traffic_table.get("workloads", {}).get(key, {}).get("kernels", {})
+            traffic = kern.get(report["dominant"], {}).get("traffic_bytes_per_launch")
         return {"bound": "mfma", "kernel": report["dominant"], "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(dk["bytes"] / dk["launches"]),
@@ -417,7 +419,7 @@ def device_code_sha256(path=None):
 
 def load_traffic_table():
     """HBM-side traffic per launch comes from separate rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a
-    pass and counters cannot be read from inside this process): tools/traffic_pmc.sh -> profiles/r02_traffic.json,
+    pass and counters cannot be read from inside this process): tools/profile_gpu.sh -> profiles/r03_traffic.json,
     which records the sha256 of the library it measured and of its device code objects.  A table measured on other
     kernels is not used."""
     try:

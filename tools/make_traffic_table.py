@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM-side traffic per launch from the rocprofv3 PMC passes of tools/profile_gpu.sh -> profiles/r02_traffic.json.
+"""HBM-side traffic per launch from the rocprofv3 PMC passes of tools/profile_gpu.sh -> profiles/r03_traffic.json.
 
 FETCH_SIZE and WRITE_SIZE are collected in SEPARATE passes (TCC slots, MI355X_MICROARCH.md "rocprofv3 PMC slots"); both
 are reported in KiB.  gfx950 correction from the same guide (HBM section): FETCH_SIZE counts 64 B per 128-B request for
@@ -37,6 +37,29 @@ def plan_name(kernel):
     m = re.search(r"conv_halo2_kernelI(DF16b|f)", k)
     if m:
         return "conv_halo2_%s_128x128" % ("bf16" if m.group(1) == "DF16b" else "f32")
+    dt = lambda t: "bf16" if t in ("DF16b", "__bf16") else "f32"
+    m = re.search(r"conv_igemm2_kernelI(DF16b|f)Li64ELi256ELi1ELi4ELi0ELb1E", k)
+    if m:
+        return "conv_head_decode_bf16_64x256"
+    m = re.search(r"conv_igemm(2|3|)_kernelI(DF16b|f)Li(\d+)ELi(\d+)E", k)
+    if m:
+        return "conv_igemm%s_%s_%sx%s" % (m.group(1), dt(m.group(2)), m.group(3), m.group(4))
+    m = re.match(r"conv_igemm(2|3|)_kernel<(float|__bf16), (\d+), (\d+)", k)     # demangled form
+    if m:
+        return "conv_igemm%s_%s_%sx%s" % (m.group(1), dt(m.group(2)), m.group(3), m.group(4))
+    m = re.match(r"conv_patch_wsp_kernel<(float|__bf16)", k)
+    if m:
+        return "conv_patch_wsp_%s_8x32x128" % dt(m.group(1))
+    m = re.search(r"conv_patch_wsp_kernelI(DF16b|f)", k)
+    if m:
+        return "conv_patch_wsp_%s_8x32x128" % dt(m.group(1))
+    m = re.match(r"conv1x1_wres_kernel<(\d+)>", k)
+    if m:
+        return "conv1x1_wres_bf16_128x%s" % m.group(1)
+    if k.startswith("conv_stem_s2_ws_kernel") or k.startswith("conv_stem_s2_fused_kernel"):
+        return "conv_stem_s2_fused_u8_bf16"
+    if k.startswith("conv_resblock_fused_kernel"):
+        return "conv_resblock_fused_bf16_64_32_64"
     m = re.search(r"\d+(conv_[a-z0-9_]+_kernel|[a-z_]+_kernel)I", k)
     if m:
         return m.group(1) + k[k.index(m.group(1)) + len(m.group(1)):].split("EvN")[0]
@@ -55,13 +78,24 @@ def per_launch(path, counter):
     return {k: (acc[k] / n[k], n[k]) for k in acc}
 
 
+WORKLOADS = ["yolov3_608_b16_bf16", "yolov3-tiny_416_b8_float32", "yolov3-spp_608_b16_bf16", "yolov3_608_b16_float32"]
+
+
+def kernels_of(prof, suffix):
+    fetch = glob.glob(os.path.join(prof, "pmc_fetch" + suffix, "**", "*counter_collection.csv"), recursive=True)
+    write = glob.glob(os.path.join(prof, "pmc_write" + suffix, "**", "*counter_collection.csv"), recursive=True)
+    if not fetch or not write:
+        return None
+    f, w = per_launch(fetch[0], "FETCH_SIZE"), per_launch(write[0], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(f) & set(w)):
+        out[k] = {"fetch_size_kib": round(f[k][0], 1), "write_size_kib": round(w[k][0], 1), "launches": f[k][1],
+                  "traffic_bytes_per_launch": int(round((2.0 * f[k][0] + w[k][0]) * 1024.0))}
+    return out
+
+
 def main():
     prof, out = sys.argv[1], sys.argv[2]
-    fetch = glob.glob(os.path.join(prof, "pmc_fetch", "**", "*counter_collection.csv"), recursive=True)
-    write = glob.glob(os.path.join(prof, "pmc_write", "**", "*counter_collection.csv"), recursive=True)
-    if not fetch or not write:
-        raise SystemExit("no PMC csv under %s" % prof)
-    f, w = per_launch(fetch[0], "FETCH_SIZE"), per_launch(write[0], "WRITE_SIZE")
     with open(os.path.join(ROOT, "pytorch-yolov3_amd", "lib", "libyolov3_hip.so"), "rb") as fh:
         sha = hashlib.sha256(fh.read()).hexdigest()
     sys.path.insert(0, ROOT)
@@ -69,16 +103,25 @@ def main():
     table = {"lib_sha256": sha,
              "device_code_sha256": bench.device_code_sha256(os.path.join(ROOT, "pytorch-yolov3_amd", "lib", "libyolov3_hip.so")),
              "_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_gpu.sh) over "
-                        "bench.py --streams 1 with the benchmark's plan options; per-launch means; FETCH_SIZE x 2 (gfx950 counts "
-                        "64 B per 128-B request for 16-B-per-lane streams: MI355X_MICROARCH.md, HBM), WRITE_SIZE as read; KiB -> bytes",
-             "kernels": {}}
-    for k in sorted(set(f) & set(w)):
-        table["kernels"][k] = {"fetch_size_kib": round(f[k][0], 1), "write_size_kib": round(w[k][0], 1), "launches": f[k][1],
-                               "traffic_bytes_per_launch": int(round((2.0 * f[k][0] + w[k][0]) * 1024.0))}
+                        "bench.py --streams 1 with the benchmark's plan options, once per workload (a kernel's mean traffic "
+                        "depends on the layers it runs); per-launch means; FETCH_SIZE x 2 (gfx950 counts 64 B per 128-B request "
+                        "for 16-B-per-lane streams: MI355X_MICROARCH.md, HBM), WRITE_SIZE as read; KiB -> bytes",
+             "workloads": {}}
+    main_k = kernels_of(prof, "")
+    if main_k is None:
+        raise SystemExit("no PMC csv under %s" % prof)
+    table["workloads"][WORKLOADS[0]] = {"kernels": main_k}
+    table["kernels"] = main_k                            # the headline workload, also at the top level
+    for wk in WORKLOADS[1:]:
+        k = kernels_of(prof, "_" + wk)
+        if k is not None:
+            table["workloads"][wk] = {"kernels": k}
     with open(out, "w") as fh:
         json.dump(table, fh, indent=1, sort_keys=True)
-    for k, v in sorted(table["kernels"].items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"])[:12]:
-        print("%-48s launches %5d  traffic/launch %8.1f MB" % (k[:48], v["launches"], v["traffic_bytes_per_launch"] / 1e6))
+    for wk, t in table["workloads"].items():
+        print("==", wk)
+        for k, v in sorted(t["kernels"].items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"])[:8]:
+            print("%-48s launches %5d  traffic/launch %8.1f MB" % (k[:48], v["launches"], v["traffic_bytes_per_launch"] / 1e6))
 
 
 if __name__ == "__main__":

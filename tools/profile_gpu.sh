@@ -8,11 +8,22 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-extras $*"
+# serial steps (one stream) with the plan options of the default three-stream bench run (Y3_AM_DEFAULT | Y3_AM_HALO_TILE256 =
+# 669), so that every kernel runs the layers it runs in the headline measurement
+TUNE="--streams 1 --tuning auto_mask=669"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-extras $TUNE $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $ARGS > $OUT/pmc_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py $ARGS > $OUT/pmc_sq.log 2>&1
+# the other single-GPU workloads of BASELINE.json: traffic passes only (bench.py other_configs[*].roofline.traffic)
+for W in "yolov3-tiny 416 8 float32" "yolov3-spp 608 16 bf16" "yolov3 608 16 float32"; do
+  set -- $W
+  KEY=$1_$2_b$3_$4
+  WARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extras $TUNE --model $1 --dim $2 --batch $3 --dtype $4"
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$KEY -- python3 $REPO/bench.py $WARGS > $OUT/pmc_fetch_$KEY.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$KEY -- python3 $REPO/bench.py $WARGS > $OUT/pmc_write_$KEY.log 2>&1
+done
 find $OUT -name "*.csv" | head -50
 python3 $REPO/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 tail -60 $OUT/summary.txt
