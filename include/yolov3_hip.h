@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define Y3_ABI_VERSION 2
+#define Y3_ABI_VERSION 3
 
 /* error codes */
 #define Y3_OK 0

@@ -58,7 +58,7 @@ AM_DEFAULT = AM_HALO_WIDE | AM_HALO_NARROW | AM_IGEMM3_1X1_DEEP | AM_HALO_MID | 
 AM_IGEMM_ONLY = 0
 AM_HALO_ALL = AM_HALO_WIDE | AM_HALO_NARROW | AM_HALO_MID          # conv_bench: the halo kernel wherever it fits
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/yolov3_hip.h declares

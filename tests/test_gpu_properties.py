@@ -112,3 +112,35 @@ def test_streams_and_plan_slots_do_not_interfere():
         got = dets[k].fetch(return_rows=True)
         for a, b in zip(got, serial[k]):
             assert all(np.array_equal(x, y) for x, y in zip(a, b)), k
+
+
+@pytest.mark.parametrize("nbytes", [0, 16, 48, 4096 + 7, 17_743_872 + 5])
+def test_copy_bytes_kernel_moves_every_byte(nbytes):
+    """y3_copy_bytes (frames in / records out without a copy engine): device -> device, pinned host -> device and
+    device -> pinned host, whole 16-byte pieces and a byte tail, any grid size; misaligned pointers are refused."""
+    from yolov3 import _hip
+    lib = _hip.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(nbytes)
+    src_h = torch.randint(0, 256, (nbytes + 32,), dtype=torch.uint8, generator=g).pin_memory()
+    src_d = src_h.to(dev)
+    stream = _hip.stream_ptr()
+    for blocks in (0, 1, 8, 1024):
+        dst_d = torch.full((nbytes + 32,), 0xAB, dtype=torch.uint8, device=dev)
+        _hip.check(lib.y3_copy_bytes(src_d.data_ptr(), dst_d.data_ptr(), nbytes, blocks, stream))
+        torch.cuda.synchronize()
+        assert torch.equal(dst_d[:nbytes], src_d[:nbytes]) and bool((dst_d[nbytes:] == 0xAB).all()), (nbytes, blocks)
+    dst_d = torch.full((nbytes + 32,), 0xAB, dtype=torch.uint8, device=dev)
+    _hip.check(lib.y3_copy_bytes(src_h.data_ptr(), dst_d.data_ptr(), nbytes, 8, stream))          # pinned host -> device
+    torch.cuda.synchronize()
+    assert torch.equal(dst_d[:nbytes].cpu(), src_h[:nbytes]) and bool((dst_d[nbytes:] == 0xAB).all())
+    dst_h = torch.full((nbytes + 32,), 0xCD, dtype=torch.uint8).pin_memory()
+    _hip.check(lib.y3_copy_bytes(src_d.data_ptr(), dst_h.data_ptr(), nbytes, 4, stream))          # device -> pinned host
+    torch.cuda.synchronize()
+    assert torch.equal(dst_h[:nbytes], src_h[:nbytes]) and bool((dst_h[nbytes:] == 0xCD).all())
+    if nbytes >= 16:
+        rc = lib.y3_copy_bytes(src_d.data_ptr() + 4, dst_d.data_ptr(), 16, 8, stream)
+        assert rc != 0 and b"align" in lib.y3_last_error().lower()
+        _hip.check(lib.y3_copy_bytes(src_d.data_ptr(), dst_d.data_ptr(), nbytes, 4096, stream))    # grid clamped to 1024
+        torch.cuda.synchronize()
+        assert torch.equal(dst_d[:nbytes], src_d[:nbytes])
