@@ -27,16 +27,10 @@ def plan_name(kernel):
     m = re.match(r"conv_halo_ws_kernel<(__bf16|float), \d+, (\d+)>", k)
     if m:
         return "conv_halo_ws_%s_%dx128" % ("bf16" if m.group(1) == "__bf16" else "f32", 64 * int(m.group(2)))
-    m = re.match(r"conv_halo2_kernel<(__bf16|float)", k)
-    if m:
-        return "conv_halo2_%s_128x128" % ("bf16" if m.group(1) == "__bf16" else "f32")
     # rocprofv3 leaves the template kernels of anonymous namespaces mangled: ...conv_halo_ws_kernelIDF16bLi4ELi4EEEv...
     m = re.search(r"conv_halo_ws_kernelI(DF16b|f)Li\d+ELi(\d+)E", k)
     if m:
         return "conv_halo_ws_%s_%dx128" % ("bf16" if m.group(1) == "DF16b" else "f32", 64 * int(m.group(2)))
-    m = re.search(r"conv_halo2_kernelI(DF16b|f)", k)
-    if m:
-        return "conv_halo2_%s_128x128" % ("bf16" if m.group(1) == "DF16b" else "f32")
     dt = lambda t: "bf16" if t in ("DF16b", "__bf16") else "f32"
     m = re.search(r"conv_igemm2_kernelI(DF16b|f)Li64ELi256ELi1ELi4ELi0ELb1E", k)
     if m:
