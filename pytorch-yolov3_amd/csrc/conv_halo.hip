@@ -71,6 +71,9 @@ struct MmaH<float> {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
+template <int V>
+struct TapC { static constexpr int value = V; };
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -235,20 +238,30 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     // the younger MFMA wave of each SIMD loses every issue arbitration to its older partner (age order); a static
     // priority for that half evens the pair out (MI355X_MICROARCH.md, two waves per SIMD, item 4): +1-5 % measured
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    // Which border taps a lane's pixel lacks, as wave-wide LANE MASKS in scalar registers (one per fragment and border):
+    // a tap's select below then costs one v_cndmask on a scalar pair instead of shift / and / compare in every lane and
+    // step, and the centre tap needs no select at all.  Pixels beyond the tensor (m >= M) need no masking: their halo rows
+    // were loaded as zeros or are other frames' pixels, and their accumulators are never stored.
+    // (bf16 instantiations; float32 sits at the 168-VGPR / 102-SGPR caps and keeps the per-lane nine-bit mask)
+    constexpr bool TAP_REGS = sizeof(T) == 2;
+    unsigned long long mk_top[MI], mk_bot[MI], mk_left[MI], mk_right[MI];
     uint32_t tapmask[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const uint32_t m = (uint32_t)(m0 + wm * WM + mi * 16 + fr);
-      uint32_t mask = 0u;
-      if (m < (uint32_t)p.M) {
-        const uint32_t img = (__umulhi(m, p.mul_hw) + m) >> p.sh_hw;
-        const uint32_t rem = m - img * (uint32_t)p.HW;
-        const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
-        const uint32_t ox = rem - oy * (uint32_t)p.W;
+      const uint32_t img = (__umulhi(m, p.mul_hw) + m) >> p.sh_hw;
+      const uint32_t rem = m - img * (uint32_t)p.HW;
+      const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
+      const uint32_t ox = rem - oy * (uint32_t)p.W;
+      if constexpr (TAP_REGS) {
+        mk_top[mi] = __builtin_amdgcn_ballot_w64(oy >= 1u);
+        mk_bot[mi] = __builtin_amdgcn_ballot_w64(oy + 1u < (uint32_t)p.H);
+        mk_left[mi] = __builtin_amdgcn_ballot_w64(ox >= 1u);
+        mk_right[mi] = __builtin_amdgcn_ballot_w64(ox + 1u < (uint32_t)p.W);
+      } else {
         const uint32_t vx = (ox >= 1u ? 1u : 0u) | 2u | (ox + 1u < (uint32_t)p.W ? 4u : 0u);
-        mask = (oy >= 1u ? vx : 0u) | (vx << 3) | (oy + 1u < (uint32_t)p.H ? vx << 6 : 0u);
+        tapmask[mi] = (oy >= 1u ? vx : 0u) | (vx << 3) | (oy + 1u < (uint32_t)p.H ? vx << 6 : 0u);
       }
-      tapmask[mi] = mask;
     }
     const int a_lane_row = wm * WM + fr;
     const int b_lane_row = wn * 64 + fr;
@@ -275,7 +288,51 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     }
     int low8 = 255;
     asm volatile("" : "+s"(low8));                     // in an SGPR: no VOP3 literals on gfx9
-    auto read_frags0 = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], int a_off, const char *bBuf, int a_shift, int tap) {
+    // fragment addresses of the nine taps at halo buffer 0 (the XOR swizzle makes them more than base + shift): nine
+    // registers, computed once
+    // (bf16 only: the float32 instantiation recomputes them, five instructions a step)
+    int ap_tap[TAP_REGS ? 9 : 1];
+    if constexpr (TAP_REGS) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int r0 = a_lane_row + (t / 3) * p.W + (t % 3);
+        ap_tap[t] = ((r0 << 7) + sA_lds) + ((fq ^ (r0 & 7)) << 4);
+      }
+    }
+    auto read_frags0 = [&](auto tapc, u32x4 (&xf)[MI], u32x4 (&wf)[NI], int a_off, const char *bBuf) {
+      constexpr int tap = decltype(tapc)::value, ky = tap / 3, kx = tap % 3;
+      int ap;
+      if constexpr (TAP_REGS) {
+        ap = ap_tap[tap] + a_off;
+      } else {
+        const int r0 = a_lane_row + ky * p.W + kx;
+        ap = ((r0 << 7) + (a_off + sA_lds)) + ((fq ^ (r0 & 7)) << 4);
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        int off = ap;
+        if constexpr (tap != 4) {
+          int zoff;
+          asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(zoff) : "v"(ap), "s"(low8), "v"(zalt[mi]));
+          if constexpr (TAP_REGS) {
+            unsigned long long ok = ky == 0 ? mk_top[mi] : (ky == 2 ? mk_bot[mi] : ~0ull);
+            if constexpr (kx == 0) ok &= mk_left[mi];
+            if constexpr (kx == 2) ok &= mk_right[mi];
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(off) : "v"(zoff), "v"(ap), "s"(ok));
+          } else {
+            off = ((tapmask[mi] >> tap) & 1u) ? ap : zoff;
+          }
+        }
+        asm volatile("" : "+v"(off));                  // keeps `+ mi * 2048` in the ds_read's immediate offset
+        sel[mi] = off;
+        xf[mi] = *reinterpret_cast<lds_u32x4 *>(off + mi * 2048);
+      }
+      const char *bp = bBuf + b_off0;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const u32x4 *>(bp + ni * 2048);
+    };
+    // float32 instantiations: the tap is a run-time value (loop not unrolled, see below)
+    auto read_frags0_rt = [&](u32x4 (&xf)[MI], u32x4 (&wf)[NI], int a_off, const char *bBuf, int a_shift, int tap) {
       const int r0 = a_lane_row + a_shift;
       const int ap = ((r0 << 7) + (a_off + sA_lds)) + ((fq ^ (r0 & 7)) << 4);
 #pragma unroll
@@ -320,7 +377,56 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     Y3_STAMP(0);
     Y3_CLK_BEGIN();
     u32x4 xf0[MI], wf0[NI], xf1[MI], wf1[NI];
-    read_frags0(xf0, wf0, 0, sB, 0, 0);
+    if constexpr (TAP_REGS) {
+    read_frags0(TapC<0>{}, xf0, wf0, 0, sB);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    int ring = 0, it = 0;
+#if defined(Y3_STAMPS_FINE)
+    const bool w0 = wave == 0;
+#define Y3_W0(slot) do { if (w0) Y3_STAMP(slot); } while (0)
+#else
+#define Y3_W0(slot) do {} while (0)
+#endif
+    // one K-step; the tap is a compile-time constant (the chunk loop below is unrolled over its nine taps), so tap
+    // shifts, mask choices and the next tap's address register are fixed per copy of the body
+    auto kstep = [&](auto tapc, int chunk) {
+      constexpr int tap = decltype(tapc)::value, tap_n = tap == 8 ? 0 : tap + 1;
+      if (it) {
+        __builtin_amdgcn_s_barrier();                 // B(it): weights(it+1) landed; slot of weights(it-1) released
+        Y3_STAMP(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags1(xf1, wf1, sB + ring * B_BYTES);
+      mma_all(xf0, wf0);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      Y3_W0(2);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      Y3_W0(3);
+      const int chunk_n = tap == 8 ? chunk + 1 : chunk;
+      const int ring_n = ring + 1 == NSB ? 0 : ring + 1;
+      read_frags0(TapC<tap_n>{}, xf0, wf0, (chunk_n & 1) * p.a_bytes, sB + ring_n * B_BYTES);
+      mma_all(xf1, wf1);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      Y3_W0(4);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+#if defined(Y3_STAMPS_FINE)
+      if (w0) Y3_STAMP(5); else Y3_STAMP(1);
+#else
+      Y3_STAMP(1);
+#endif
+      ring = ring_n;
+      ++it;
+    };
+#pragma unroll 1
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+      kstep(TapC<0>{}, chunk); kstep(TapC<1>{}, chunk); kstep(TapC<2>{}, chunk);
+      kstep(TapC<3>{}, chunk); kstep(TapC<4>{}, chunk); kstep(TapC<5>{}, chunk);
+      kstep(TapC<6>{}, chunk); kstep(TapC<7>{}, chunk); kstep(TapC<8>{}, chunk);
+    }
+    } else {
+    read_frags0_rt(xf0, wf0, 0, sB, 0, 0);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     int tap = 0, chunk = 0, ring = 0;
 #pragma unroll 1
@@ -348,7 +454,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       const int ring_n = ring + 1 == NSB ? 0 : ring + 1;
       {
         const int ky_n = (tap_n * 11) >> 5, kx_n = tap_n - ky_n * 3;
-        read_frags0(xf0, wf0, (chunk_n & 1) * p.a_bytes, sB + ring_n * B_BYTES, ky_n * p.W + kx_n, tap_n);
+        read_frags0_rt(xf0, wf0, (chunk_n & 1) * p.a_bytes, sB + ring_n * B_BYTES, ky_n * p.W + kx_n, tap_n);
       }
       mma_all(xf1, wf1);
       interleave();
@@ -363,6 +469,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       tap = tap_n;
       chunk = chunk_n;
       ring = ring_n;
+    }
     }
     Y3_CLK_END();
 #if defined(Y3_STAMPS_CLOCK)
