@@ -152,11 +152,19 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     const int row0 = ltid >> 3;
     const int kc = slot ^ (row0 & 7);
     const long long q0 = (long long)m0 - p.W - 1;     // flattened input pixel of halo row 0
+    // Halo row of pass `pass`: row0 + 32 pass, input pixel q0 + that row.  The row is real (inside the halo image and the
+    // tensor) for a per-lane RANGE of passes, and its address is the lane's pass-0 address plus a wave-uniform step: the
+    // loop issues each slice with two compares, one 64-bit add and a select instead of recomputing row, pixel and product.
+    const long long qr = q0 + row0;
+    const int hi_rows = (p.hr - 1 - row0) >> 5;                                        // last pass with row < hr (-1: none)
+    const long long hi_px = qr < p.M ? (p.M - 1 - qr) >> 5 : -1;                        // last pass with pixel < M
+    const int pass_lo = qr >= 0 ? 0 : (int)((-qr + 31) >> 5);                           // first pass with pixel >= 0
+    const int pass_hi = hi_px < hi_rows ? (int)hi_px : hi_rows;
+    const char *hsrc0 = p.in + (qr * p.in_ld) * ES + kc * 16;                           // pass 0, chunk 0 (maybe out of range)
+    const long long pass_step = (long long)RPL * p.in_ld * ES;
     auto issue_halo_pass = [&](int chunk, int pass, bool live) {
-      const int row = row0 + pass * RPL;
-      const long long q = q0 + row;
-      const bool ok = live && row < p.hr && q >= 0 && q < p.M;   // rows >= hr stay zero: row hr is the consumers' zero row
-      const char *src = ok ? p.in + (q * p.in_ld + (long long)chunk * BKE) * ES + kc * 16 : p.zero;
+      const bool ok = live && pass >= pass_lo && pass <= pass_hi;   // other rows stay zero: row hr is the consumers' zero row
+      const char *src = ok ? hsrc0 + (pass * pass_step + (long long)chunk * (BKE * ES)) : p.zero;
       char *dst = sA + (chunk & 1) * p.a_bytes + pass * (NL * 16) + lwave * 1024;
       __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
     };
@@ -173,9 +181,11 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       char *dst = sA + (chunk & 1) * p.a_bytes + pass * (NL * 16) + lwave * 1024;
       __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
     };
-    const char *b_src[NBL];
-#pragma unroll
-    for (int i = 0; i < NBL; ++i) b_src[i] = p.wgt + ((long long)(n0 + row0 + i * RPL) * p.k_ld) * ES + kc * 16;
+    // weight rows: wave-uniform base (channel tile, pass, K offset) + this lane's 32-bit offset (row, chunk): the compiler
+    // picks the scalar-base addressing form, no vector arithmetic per piece
+    const uint32_t b_lane = (uint32_t)row0 * (uint32_t)p.k_ld * ES + kc * 16;
+    const char *b_tile = p.wgt + ((long long)n0 * p.k_ld) * ES;
+    const long long b_pass = (long long)RPL * p.k_ld * ES;
     auto issue_weights = [&](int it, int ring_slot) {  // it = chunk*9 + tap; K offset = tap*Cin + chunk*BKE elements
       char *dst = sB + ring_slot * B_BYTES + lwave * 1024;
       if (it < nit) {
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
         const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
-          __builtin_amdgcn_global_load_lds((gbl_void *)(b_src[i] + koff), (lds_void *)(dst + i * (NL * 16)), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_void *)(b_tile + (koff + i * b_pass) + b_lane), (lds_void *)(dst + i * (NL * 16)), 16, 0, 0);
       } else {
         // past the last K-step: the instruction count per step stays (counted waits) but the pieces read the zero page --
         // a real weight tile here is 16 KiB nobody uses, and the epilogue's barrier waits for it to land
