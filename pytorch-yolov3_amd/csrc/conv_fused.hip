@@ -756,29 +756,63 @@ __global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs p
     b = tile / p.tiles_y;
     ox0 = tx * kRT;
   };
+  // Patch chunk j of this thread: patch pixel (r, cc), 16-byte channel chunk c -- the same for every tile, so the patch
+  // row / column, the byte offset relative to the tile's first patch pixel and the LDS address are computed ONCE; per tile
+  // a chunk costs two range checks and a load from (wave-uniform tile base) + (32-bit lane offset).
+  int xrc[kXPre];                                                        // (r << 8) | cc, or -1 past the patch
+  uint32_t xoff[kXPre];                                                  // ((r * W + cc) * x_ld) * 2 + c * 16
+  int xlds[kXPre];
+#pragma unroll
+  for (int j = 0; j < kXPre; ++j) {
+    const int i = tid + j * kThreads;
+    const int px = i >> 3, c = i & 7;
+    const int r = px / kRP, cc = px - r * kRP;
+    xrc[j] = i < kRNP * 8 ? (r << 8) | cc : -1;
+    xoff[j] = ((uint32_t)(r * p.W + cc) * (uint32_t)p.x_ld) * 2u + (uint32_t)c * 16u;
+    xlds[j] = px * 128 + ((c ^ (px & 7)) << 4);
+  }
+  // phase-A fragments of this wave (f = wave, wave + 8, wave + 16): patch read address, patch (r, cc), image write address
+  constexpr int kAFr = (kRFrag + kThreads / 64 - 1) / (kThreads / 64);
+  int a_rd[kAFr], a_rc[kAFr], a_wr[kAFr];
+#pragma unroll
+  for (int fs = 0; fs < kAFr; ++fs) {
+    const int q = (wave + fs * (kThreads / 64)) * 16 + fr;
+    const int qc = q < kRNP ? q : kRNP - 1;
+    const int r = qc / kRP, cc = qc - r * kRP;
+    a_rd[fs] = qc * 128 + ((fq ^ (qc & 7)) << 4);
+    a_rc[fs] = (r << 8) | cc;
+    a_wr[fs] = q < kRNP ? q * kYPitch + fq * 16 : -1;
+  }
+  // write-out item j of this thread: tile pixel opx, byte offset from the tile's first output pixel, staging address
+  constexpr int kOutPer = kRT * kRT * 8 / kThreads;
+  int opx[kOutPer], olds[kOutPer];
+  uint32_t ooff[kOutPer];
+#pragma unroll
+  for (int j = 0; j < kOutPer; ++j) {
+    const int i = tid + j * kThreads;
+    const int px = i >> 3, ch = i & 7;
+    opx[j] = px;
+    ooff[j] = ((uint32_t)((px >> 4) * p.W + (px & 15)) * (uint32_t)p.out_ld + (uint32_t)ch * 8u) * 2u;
+    olds[j] = px * 128 + ((ch ^ (px & 7)) << 4);
+  }
   auto x_fetch = [&](int tile, u32x4 (&pre)[kXPre]) {
     int b, oy0, ox0;
     tile_origin(tile, b, oy0, ox0);
+    // first patch pixel (oy0 - 1, ox0 - 1) of frame b: may lie outside the frame (then only in-range chunks are loaded)
+    const char *base = reinterpret_cast<const char *>(p.x) + ((((long long)b * p.H + (oy0 - 1)) * p.W + (ox0 - 1)) * p.x_ld) * 2;
 #pragma unroll
     for (int j = 0; j < kXPre; ++j) {
-      const int i = tid + j * kThreads;
-      const int px = i >> 3, c = i & 7;
-      const int r = px / kRP, cc = px - r * kRP;
-      const int gy = oy0 - 1 + r, gx = ox0 - 1 + cc;
+      const int gy = oy0 - 1 + (xrc[j] >> 8), gx = ox0 - 1 + (xrc[j] & 255);
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (i < kRNP * 8 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-        v = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.x) +
-                                             ((((long long)b * p.H + gy) * p.W + gx) * p.x_ld) * 2 + c * 16);
+      if (xrc[j] >= 0 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+        v = *reinterpret_cast<const u32x4 *>(base + xoff[j]);
       pre[j] = v;
     }
   };
   auto x_store = [&](const u32x4 (&pre)[kXPre]) {
 #pragma unroll
-    for (int j = 0; j < kXPre; ++j) {
-      const int i = tid + j * kThreads;
-      const int px = i >> 3, c = i & 7;
-      if (i < kRNP * 8) *reinterpret_cast<u32x4 *>(xt + px * 128 + ((c ^ (px & 7)) << 4)) = pre[j];
-    }
+    for (int j = 0; j < kXPre; ++j)
+      if (xrc[j] >= 0) *reinterpret_cast<u32x4 *>(xt + xlds[j]) = pre[j];
   };
 
   int tile = blockIdx.x;
@@ -793,13 +827,12 @@ __global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs p
     __syncthreads();   // B1: x patch (and, first time, the weights) in LDS; image / staging region free
 
     // ---- phase A: 1x1 conv over the patch ------------------------------------------------------------
-    for (int f = wave; f < kRFrag; f += kThreads / 64) {
-      const int q = f * 16 + fr;
-      const int qc = q < kRNP ? q : kRNP - 1;
-      const u32x4 xa = *reinterpret_cast<const u32x4 *>(xt + qc * 128 + (((0 + fq) ^ (qc & 7)) << 4));
-      const u32x4 xb = *reinterpret_cast<const u32x4 *>(xt + qc * 128 + (((4 + fq) ^ (qc & 7)) << 4));
-      const int r = qc / kRP, cc = qc - r * kRP;
-      const bool inside = (unsigned)(oy0 - 1 + r) < (unsigned)p.H && (unsigned)(ox0 - 1 + cc) < (unsigned)p.W;
+#pragma unroll
+    for (int fs = 0; fs < kAFr; ++fs) {
+      if (wave + fs * (kThreads / 64) >= kRFrag) break;                   // wave-uniform
+      const u32x4 xa = *reinterpret_cast<const u32x4 *>(xt + a_rd[fs]);
+      const u32x4 xb = *reinterpret_cast<const u32x4 *>(xt + (a_rd[fs] ^ 64));   // K half 1: chunk index + 4 under the XOR swizzle
+      const bool inside = (unsigned)(oy0 - 1 + (a_rc[fs] >> 8)) < (unsigned)p.H && (unsigned)(ox0 - 1 + (a_rc[fs] & 255)) < (unsigned)p.W;
       u32x2 o[2];
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
@@ -810,7 +843,7 @@ __global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs p
         if (!inside) o[ni] = u32x2{0u, 0u};                              // the 3x3's zero padding
       }
       // channels 8 fq .. 8 fq + 7 of pixel q: one 16-byte write
-      if (q < kRNP) *reinterpret_cast<u32x4 *>(yt + q * kYPitch + fq * 16) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
+      if (a_wr[fs] >= 0) *reinterpret_cast<u32x4 *>(yt + a_wr[fs]) = u32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
     }
     const int next_tile = tile + gridDim.x;
     u32x4 pre[kXPre];
@@ -859,30 +892,22 @@ __global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs p
         const int pp = (oyl + 1) * kRP + fr + 1;                          // this output pixel inside the patch
         const u32x4 xr = *reinterpret_cast<const u32x4 *>(xt + pp * 128 + (((k * 4 + fq) ^ (pp & 7)) << 4));
         const bf16x8 xv = __builtin_bit_cast(bf16x8, xr);
+        float v[8];
+        y3_bn_leaky8(v, acc[mi][2 * k], acc[mi][2 * k + 1], s3[0], s3[1], b3[0], b3[1], true);   // packed arithmetic
         bf16x8 o;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const f32x4 a = acc[mi][2 * k + h];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = a[r] * s3[h][r] + b3[h][r];
-            v = y3_vmax(v, Y3_LEAKY_SLOPE * v);
-            o[4 * h + r] = (bf16_t)(v + (float)xv[4 * h + r]);
-          }
-        }
+        for (int r = 0; r < 8; ++r) o[r] = (bf16_t)(v[r] + (float)xv[r]);
         const int px = oyl * kRT + fr;
         *reinterpret_cast<bf16x8 *>(yt + px * 128 + (((k * 4 + fq) ^ (px & 7)) << 4)) = o;
       }
     }
     __syncthreads();   // B4: staging complete; the x patch is dead
+    {
+      char *obase = reinterpret_cast<char *>(p.out) + ((((long long)b * p.H + oy0) * p.W + ox0) * p.out_ld) * 2;   // uniform
 #pragma unroll
-    for (int j = 0; j < kRT * kRT * 8 / kThreads; ++j) {
-      const int i = tid + j * kThreads;
-      const int px = i >> 3, ch = i & 7;
-      const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
-      if (oy < p.H && ox < p.W) {
-        const u32x4 v = *reinterpret_cast<const u32x4 *>(yt + px * 128 + ((ch ^ (px & 7)) << 4));
-        *reinterpret_cast<u32x4 *>(p.out + (((long long)b * p.H + oy) * p.W + ox) * p.out_ld + ch * 8) = v;
+      for (int j = 0; j < kOutPer; ++j) {
+        const int oy = oy0 + (opx[j] >> 4), ox = ox0 + (opx[j] & 15);
+        if (oy < p.H && ox < p.W) *reinterpret_cast<u32x4 *>(obase + ooff[j]) = *reinterpret_cast<const u32x4 *>(yt + olds[j]);
       }
     }
     if (next_tile < p.n_tiles) x_store(pre);
