@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define Y3_ABI_VERSION 3
+#define Y3_ABI_VERSION 4
 
 /* error codes */
 #define Y3_OK 0
@@ -137,11 +137,17 @@ typedef struct y3_plan y3_plan;
  *   fuse_head        1 [default]: detection-head conv + YOLO decode in one launch (bf16 networks)
  *   fuse_spp         1 [default]: three stride-1 max-pools (5 / 9 / 13) of one tensor in one launch
  *   decode_lanes     4 [default]: four lanes per box in the bf16 decode; 1: sequential class loop everywhere
+ *   fuse_block       0 [default]: off.  1: a 1x1 conv (-> 128 channels) + the 3x3 conv that is its only reader (+ the
+ *                    shortcut add) run as ONE kernel with the 128-channel tensor kept in LDS (csrc/conv_block.hip), where map
+ *                    and batch give enough workgroups to fill the chip (yolov3@608: the 76^2 blocks from batch 12 on); 2:
+ *                    wherever the kernel supports the pair (tests).  Same bits either way; measured level with the two
+ *                    launches (profiles/r04_block_fused_AB.txt), which is why it is not the default.
  */
 typedef struct y3_options {
   int32_t auto_mask, unused0, igemm_version, igemm_ns, igemm_bm;
   int32_t use_graph, fuse_stem, fuse_head, fuse_spp, decode_lanes;
-  int32_t reserved[6];
+  int32_t fuse_block;
+  int32_t reserved[5];
 } y3_options;
 
 /* library / device ------------------------------------------------------------------- */
@@ -178,7 +184,7 @@ int y3_conv_path(const y3_op *op);
 
 /* A/B measurements only (tools/conv_bench.py, bench.py --tuning): changes ONE field of the process-wide DEFAULT
  * options by name ("auto_mask", "igemm_version", "igemm_ns", "igemm_bm", "use_graph", "fuse_stem",
- * "fuse_head", "fuse_spp", "decode_lanes").  Plans created afterwards without explicit options pick it up; existing
+ * "fuse_head", "fuse_spp", "decode_lanes", "fuse_block").  Plans created afterwards without explicit options pick it up; existing
  * plans keep the options they were created with.                                                                  */
 int y3_set_tuning(const char *key, int value);
 

@@ -17,7 +17,7 @@ thread_local char g_err[512] = "";
 // Default options (y3_options_default / y3_set_tuning); the auto_mask bits are named in include/yolov3_hip.h (Y3_AM_*).
 static y3_options g_y3_defaults = {/*auto_mask*/ (int32_t)Y3_AM_DEFAULT, /*unused0*/ 0, /*igemm_version*/ 2, /*igemm_ns*/ 2,
                                    /*igemm_bm*/ 0, /*use_graph*/ 0, /*fuse_stem*/ 1, /*fuse_head*/ 1, /*fuse_spp*/ 1,
-                                   /*decode_lanes*/ 4, {0, 0, 0, 0, 0, 0}};
+                                   /*decode_lanes*/ 4, /*fuse_block*/ 0, {0, 0, 0, 0, 0}};
 static thread_local const y3_options *tl_y3_opt = nullptr;
 const y3_options &y3_opt() { return tl_y3_opt ? *tl_y3_opt : g_y3_defaults; }
 static int g_y3_debug = 0;
@@ -54,9 +54,9 @@ struct y3_plan {
   std::vector<y3_op> ops;
   std::vector<const char *> kernel;
   const void *d_zero;
-  std::vector<char> fuse;   // per op: 0 = launch normally, 1 / 3 / 4 = launch fused with the next op (stem pair / residual
-                            // block / head conv + decode), 5 = SPP pyramid with the next TWO ops, 2 = nothing (fused
-                            // into a previous op)
+  std::vector<char> fuse;   // per op: 0 = launch normally, 1 / 3 / 4 / 6 = launch fused with the next op (stem pair /
+                            // 64-32-64 residual block / head conv + decode / 128-channel bottleneck block), 5 = SPP
+                            // pyramid with the next TWO ops, 2 = nothing (fused into a previous op)
   std::vector<hipEvent_t> events;
   // hipGraph replay (one graph launch per forward instead of ~80 kernel launches): executable graphs keyed by the
   // input pointer they were captured with; the first run of a plan is always eager (one-time function attributes)
@@ -155,6 +155,7 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
 int run_op(y3_plan *plan, size_t i, const void *d_input, hipStream_t s, const char **name) {
   if (plan->fuse[i] == 2) return Y3_OK;
   if (plan->fuse[i] == 3) return y3_launch_conv_fused_resblock(plan->ops[i], plan->ops[i + 1], s, name, false);
+  if (plan->fuse[i] == 6) return y3_launch_conv_block_fused(plan->ops[i], plan->ops[i + 1], s, name, false);
   if (plan->fuse[i] == 4) return y3_launch_conv_head_decode(plan->ops[i], plan->ops[i + 1], plan->d_zero, s, name, false);
   if (plan->fuse[i] == 5) return y3_launch_maxpool_spp(plan->ops[i], plan->ops[i + 1], plan->ops[i + 2], s, name, false);
   if (plan->fuse[i] == 1) {
@@ -225,6 +226,9 @@ int y3_plan_create_ex(const y3_op *ops, int n_ops, const void *d_zero, const y3_
     } else if ((p->ops[i].flags & Y3_F_FUSE_NEXT) && y3_conv_fused_resblock_supported(p->ops[i], p->ops[i + 1])) {
       p->fuse[i] = 3;           // whole residual block in one kernel
       p->fuse[i + 1] = 2;
+    } else if ((p->ops[i].flags & Y3_F_FUSE_NEXT) && y3_conv_block_fused_supported(p->ops[i], p->ops[i + 1])) {
+      p->fuse[i] = 6;           // 1x1 -> 3x3 (+ shortcut) with the 128-channel tensor in LDS
+      p->fuse[i + 1] = 2;
     } else if (y3_conv_head_decode_supported(p->ops[i], p->ops[i + 1])) {
       p->fuse[i] = 4;           // head conv + YOLO decode (the float32 logits never leave the CU)
       p->fuse[i + 1] = 2;
@@ -241,6 +245,10 @@ int y3_plan_create_ex(const y3_op *ops, int n_ops, const void *d_zero, const y3_
     }
     if (p->fuse[i] == 4) {
       (void)y3_launch_conv_head_decode(p->ops[i], p->ops[i + 1], d_zero, nullptr, &p->kernel[i], true);
+      continue;
+    }
+    if (p->fuse[i] == 6) {
+      (void)y3_launch_conv_block_fused(p->ops[i], p->ops[i + 1], nullptr, &p->kernel[i], true);
       continue;
     }
     if (p->fuse[i] == 5) {
@@ -347,7 +355,7 @@ double y3_plan_op_flops(const y3_plan *plan, int op_index) {
     return o.kind != Y3_OP_CONV ? 0.0 : 2.0 * o.ksize * o.ksize * o.in_c * (double)o.out_c * o.out_h * o.out_w * o.batch;
   };
   double f = conv_flops(plan->ops[op_index]);
-  if (plan->fuse[op_index] == 1 || plan->fuse[op_index] == 3) f += conv_flops(plan->ops[op_index + 1]);   // (4: the decode has no conv FLOPs)
+  if (plan->fuse[op_index] == 1 || plan->fuse[op_index] == 3 || plan->fuse[op_index] == 6) f += conv_flops(plan->ops[op_index + 1]);   // (4: the decode has no conv FLOPs)
   return f;
 }
 
@@ -368,7 +376,7 @@ double y3_plan_op_bytes(const y3_plan *plan, int op_index) {
     const y3_op &a = plan->ops[op_index];
     return 4.0 * a.batch * a.in_h * a.in_w * a.in_c * y3_elem_size(a.dtype);
   }
-  if (plan->fuse[op_index] == 3) {   // x in (once), z out, both weight sets
+  if (plan->fuse[op_index] == 3 || plan->fuse[op_index] == 6) {   // x in (once), z out, both weight sets
     const y3_op &a = plan->ops[op_index], &b = plan->ops[op_index + 1];
     return ((double)a.batch * a.in_h * a.in_w * a.in_c + (double)b.batch * b.out_h * b.out_w * b.out_c) * 2.0 +
            ((double)a.in_c * a.out_c + 9.0 * b.in_c * b.out_c) * 2.0;
@@ -399,7 +407,8 @@ int y3_set_tuning(const char *key, int value) {
       {"igemm_version", &g_y3_defaults.igemm_version}, {"igemm_ns", &g_y3_defaults.igemm_ns},
       {"igemm_bm", &g_y3_defaults.igemm_bm}, {"use_graph", &g_y3_defaults.use_graph},
       {"fuse_stem", &g_y3_defaults.fuse_stem}, {"fuse_head", &g_y3_defaults.fuse_head},
-      {"fuse_spp", &g_y3_defaults.fuse_spp}, {"decode_lanes", &g_y3_defaults.decode_lanes}};
+      {"fuse_spp", &g_y3_defaults.fuse_spp}, {"decode_lanes", &g_y3_defaults.decode_lanes},
+      {"fuse_block", &g_y3_defaults.fuse_block}};
   for (auto &f : fields)
     if (!strcmp(key, f.name)) { *f.field = value; return Y3_OK; }
   if (!strcmp(key, "debug")) { g_y3_debug = value; return Y3_OK; }   // read by diagnostic builds only

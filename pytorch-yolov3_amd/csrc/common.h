@@ -243,6 +243,9 @@ int y3_launch_conv_fused_stem_s2(const y3_op &op0, const y3_op &op1, const void 
 bool y3_conv_fused_resblock_supported(const y3_op &op0, const y3_op &op1);
 int y3_launch_conv_fused_resblock(const y3_op &op0, const y3_op &op1, hipStream_t s, const char **kernel_name,
                                   bool dry_run);
+// 1x1 (-> 128 channels) + 3x3 (+ shortcut) in one kernel, bottleneck tensor in LDS (conv_block.hip)
+bool y3_conv_block_fused_supported(const y3_op &op0, const y3_op &op1);
+int y3_launch_conv_block_fused(const y3_op &op0, const y3_op &op1, hipStream_t s, const char **kernel_name, bool dry_run);
 // detection head: 1x1 conv + YOLO decode in one launch (conv_igemm.hip)
 bool y3_conv_head_decode_supported(const y3_op &op0, const y3_op &op1);
 int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d_zero, hipStream_t s,

@@ -47,7 +47,7 @@ class Y3Options(ctypes.Structure):
     """Mirror of ``struct y3_options`` (include/yolov3_hip.h): kernel-selection options of one plan."""
     _fields_ = [(name, ctypes.c_int32) for name in (
         "auto_mask", "unused0", "igemm_version", "igemm_ns", "igemm_bm", "use_graph", "fuse_stem", "fuse_head",
-        "fuse_spp", "decode_lanes")] + [("reserved", ctypes.c_int32 * 6)]
+        "fuse_spp", "decode_lanes", "fuse_block")] + [("reserved", ctypes.c_int32 * 5)]
 
 
 # y3_options.auto_mask bits (include/yolov3_hip.h: Y3_AM_*)
@@ -58,7 +58,7 @@ AM_DEFAULT = AM_HALO_WIDE | AM_HALO_NARROW | AM_IGEMM3_1X1_DEEP | AM_HALO_MID | 
 AM_IGEMM_ONLY = 0
 AM_HALO_ALL = AM_HALO_WIDE | AM_HALO_NARROW | AM_HALO_MID          # conv_bench: the halo kernel wherever it fits
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/yolov3_hip.h declares
