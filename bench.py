@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X YOLOv3 hot path (BASELINE.json metric: frames/sec at 608x608).
 
-One "step" = one pass of the whole path over one batch of synthetic frames that are already
-resident in HBM: uint8 BGR frames -> fused preprocess + Darknet-53 convs (HIP MFMA kernels)
--> 3 YOLO heads decode -> threshold/scale/int/tlbr + per-class NMS on device -> padded
-detection records (and, for N > 1 ranks, ONE RCCL all-gather of those records per step, on a side stream).
+One "step" = one pass of the whole path over one batch of synthetic frames that start in PINNED HOST
+memory: upload of the uint8 BGR frames -> fused preprocess + Darknet-53 convs (HIP MFMA kernels) -> 3 YOLO heads decode ->
+threshold/scale/int/tlbr + per-class NMS on device -> padded detection records (for N > 1 ranks ONE RCCL all-gather of
+those records per step, on a side stream) -> records back in pinned host memory.  The loop that is timed is the package's
+own (yolov3/pipeline.py: Pipeline, three batches in flight), the one `yolov3 --video` and stream.detect_in_frames run.
 
   python bench.py --gpus N --steps K --warmup W
 
@@ -12,11 +13,11 @@ With N > 1 and no torchrun environment the process starts its N ranks itself (``
 one process per GPU, rendezvous on 127.0.0.1) before anything touches a GPU, relays rank 0's JSON line and exits
 non-zero if a rank fails or fewer than N GPUs are visible.  Launched under torchrun it is one rank of the job.
 
-Rank 0 prints ONE JSON line.  `value` = frames of all ranks / max-over-ranks wall time of exactly K steps.
+Rank 0 prints ONE JSON line.  `value` = frames of all ranks / max-over-ranks wall time of exactly K steps (PCIe inclusive).
 At N = 1 the same run also measures and reports, in that line:
+  resident        the same steps with the frames already in HBM and the records left there (the kernels alone; r01-r03's `value`)
   roofline        dominant kernel, HIP events around every launch on the launch stream (serial passes)
   cpu_baseline    the CPU oracle (the reference's "-d cpu" op sequence) on the host cores, SURVEY.md 8(d) protocol
-  pcie_inclusive  the same workload with frames starting in pinned host memory and records copied back every step
   other_configs   BASELINE.json's other single-GPU configurations (parity cases, each with its own roofline)
   bf16_agreement  bf16 detections against the reference's float32 detections on the golden frames (tests/golden)
 """
@@ -70,10 +71,10 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: step i runs on HIP stream i %% streams with its own arena, so "
                          "one batch's kernel tails overlap the next batch's ramp-up (1 = strictly serial steps)")
-    ap.add_argument("--h2d", action="store_true",
-                    help="make the PCIe-inclusive variant the timed region (never the headline value): frames start in "
-                         "pinned host memory and are copied to the GPU inside every step, the packed detection records "
-                         "are copied back")
+    ap.add_argument("--resident", action="store_true",
+                    help="A/B runs of kernels: time the steps with the frames already in HBM and the records left there "
+                         "(not the headline: `value` is PCIe inclusive, frames from pinned host memory, records back to it)")
+    ap.add_argument("--h2d", action="store_true", help="(accepted for old command lines: PCIe inclusive is the default now)")
     ap.add_argument("--tuning", default="", help="A/B runs: comma-separated y3_set_tuning knobs, e.g. auto_mask=15")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak [default]: --batch frames per GPU whatever N (BASELINE.json configs[4]: 16 per GPU); strong: "
@@ -81,7 +82,8 @@ def parse_args(argv=None):
     ap.add_argument("--total-frames", type=int, default=128, help="frames per step of the whole job with --scaling strong")
     ap.add_argument("--graph", default="auto", choices=["auto", "0", "1"],
                     help="replay each forward as one captured hipGraph (0.07 instead of ~0.75 ms of host time per step): auto = "
-                         "only when this rank has fewer than two usable CPUs")
+                         "eager on one GPU (the headline is always measured the same way); with N > 1 ranks only when a rank "
+                         "has fewer than two usable CPUs.  The line says which (`use_graph`)")
     return ap.parse_args(argv)
 
 
@@ -217,96 +219,41 @@ def plumbing_main(args, backend):
 # ------------------------------------------------------------------------------------------------
 
 class Workload(object):
-    """model x input size x batch x dtype on one GPU: net, resident frames, per-stream detector / gather buffers."""
+    """model x input size x batch x dtype on one GPU: net, the package's Pipeline, host (pinned) and resident frames."""
 
     def __init__(self, model, dim, batch, dtype, params, dev, rank, world, kmax, nstream, options=None):
         import yolov3
-        from yolov3.inference import Detector
+        from yolov3.pipeline import Pipeline
         from yolov3.synthdata import synth_frames
-        from yolov3.dist import DetectionGather
         self.model, self.dim, self.batch, self.dtype, self.dev, self.nstream = model, dim, batch, dtype, dev, nstream
         cfg = os.path.join(ROOT, "pytorch-yolov3_amd", "models", model + ".cfg")
         self.cfg = cfg
-        if options is None and nstream > 1:
-            # several batches in flight: the halo kernel's throughput tile choice (include/yolov3_hip.h: Y3_AM_HALO_TILE256)
-            from yolov3 import _hip
-            options = {"auto_mask": _hip.options().auto_mask | _hip.AM_HALO_TILE256}
-        self.options = options
-        self.net = yolov3.Darknet(cfg, device=str(dev), dtype=dtype, options=options).eval()
+        self.net = yolov3.Darknet(cfg, device=str(dev), dtype=dtype).eval()
         self.net.set_params(params)
+        # explicit options (hipGraph replay) replace the pipeline's own choice, which is the throughput tile choice
+        # (Y3_AM_HALO_TILE256) whenever more than one batch is in flight
+        self.pipe = Pipeline(self.net, batch, dim, dim, in_flight=nstream, prob_thresh=0.05, nms_iou_thresh=0.3, kmax=kmax,
+                             world=world, options=options)
+        self.options = self.pipe.options
+        self.rows = self.pipe.rows
         self.frames_np = synth_frames(123 + rank, batch, dim, dim)
-        # distinct frames per rank (data-parallel shards), resident in HBM before timing starts
+        # distinct frames per rank (data-parallel shards): in pinned host memory (the headline) and resident in HBM
+        self.host_frames = torch.from_numpy(self.frames_np).pin_memory()
+        self.host_warm = torch.from_numpy(synth_frames(1000 + rank, batch, dim, dim)).pin_memory()
         self.frames = torch.from_numpy(self.frames_np).to(dev)
-        self.warm_frames = torch.from_numpy(synth_frames(1000 + rank, batch, dim, dim)).to(dev)
-        self.orig_hw = torch.tensor([[dim, dim]] * batch, dtype=torch.int32, device=dev)
-        out = self.net.forward_frames(self.warm_frames, fresh=False)
-        self.rows = out["class_prob"].shape[1]
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
-        self.dets = [Detector(batch, self.rows, dev) for _ in range(nstream)]
-        # one side stream for all gathers of this rank: every HIP stream needs a hardware queue of its own to overlap
-        side = torch.cuda.Stream(device=dev) if (world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized())) else None
-        self.gathers = [DetectionGather(batch, self.rows, kmax, dev, world, side=side) for _ in range(nstream)]
-        self.h2d = None
-        torch.cuda.synchronize()       # the set-up forward ran on the default stream; the steps run on side streams
+        self.warm_frames = self.host_warm.to(dev)
+        torch.cuda.synchronize()
 
-    def enable_h2d(self, parts=3):
-        # TWO device frame buffers per batch in flight: with one, the copy of step i could only start once the forward of
-        # step i - nstream (same stream, same buffer) had finished -- exactly when stream i % nstream was ready for its
-        # next forward, which then waited out the whole copy (0.43 ms of every step, on each stream in turn: measured
-        # 4.8-5.4 k against 6.2-6.5 k frames/s).  With two, the copy of step i only needs step i - 2 nstream to be done.
-        nbuf = 2 * self.nstream
-        self.h2d = dict(parts=parts, engine=os.environ.get("Y3_BENCH_H2D_ENGINE", "kernel"),
-                        blocks=int(os.environ.get("Y3_BENCH_H2D_BLOCKS", "8")),
-                        host_frames=torch.from_numpy(self.frames_np).pin_memory(),
-                        dev_frames=[torch.empty_like(self.frames) for _ in range(nbuf)],
-                        copy_stream=torch.cuda.Stream(device=self.dev), host_rec=None,
-                        free_ev=[torch.cuda.Event() for _ in range(nbuf)],
-                        ready_ev=[torch.cuda.Event() for _ in range(nbuf)])
-        for e in self.h2d["free_ev"]:
-            e.record()
+    def step(self, i, resident=False, warm=False):
+        if resident:
+            return self.pipe.submit(self.warm_frames if warm else self.frames, to_host=False)
+        return self.pipe.submit(self.host_warm if warm else self.host_frames)
 
-    def step(self, fr, i=0, h2d=False):
-        k = i % self.nstream
-        h = self.h2d if h2d else None
-        with torch.cuda.stream(self.streams[k]):
-            if h and (h["parts"] & 1):
-                # the copy runs on its own stream, into the buffer the forward of step i - 2 nstream read last
-                j = i % len(h["dev_frames"])
-                with torch.cuda.stream(h["copy_stream"]):
-                    h["copy_stream"].wait_event(h["free_ev"][j])
-                    if h["engine"] == "kernel":
-                        from yolov3 import _hip
-                        _hip.check(_hip.lib().y3_copy_bytes(h["host_frames"].data_ptr(), h["dev_frames"][j].data_ptr(),
-                                                            h["host_frames"].numel(), h["blocks"], _hip.stream_ptr()))
-                    else:
-                        h["dev_frames"][j].copy_(h["host_frames"], non_blocking=True)
-                    h["ready_ev"][j].record(h["copy_stream"])
-                self.streams[k].wait_event(h["ready_ev"][j])
-                fr = h["dev_frames"][j]
-            o = self.net.forward_frames(fr, fresh=False, slot=k)
-            if h and (h["parts"] & 1):
-                h["free_ev"][j].record(self.streams[k])
-            self.dets[k].run(o, self.orig_hw, 0.05, 0.3)
-            rec = self.gathers[k].run(self.dets[k])
-            if h and (h["parts"] & 2):
-                g = self.gathers[k]
-                if g.done is not None:
-                    self.streams[k].wait_event(g.done)
-                if h["host_rec"] is None:
-                    h["host_rec"] = [torch.empty(rec.shape, dtype=rec.dtype).pin_memory() for _ in range(self.nstream)]
-                if h["engine"] == "kernel":
-                    from yolov3 import _hip
-                    _hip.check(_hip.lib().y3_copy_bytes(rec.data_ptr(), h["host_rec"][k].data_ptr(),
-                                                        rec.numel() * rec.element_size(), 4, _hip.stream_ptr()))
-                else:
-                    h["host_rec"][k].copy_(rec, non_blocking=True)
-            return rec
-
-    def timed(self, steps, warmup, distributed=False, h2d=False):
+    def timed(self, steps, warmup, distributed=False, resident=False):
         """`warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize; max over ranks."""
         import torch.distributed as dist
         for i in range(max(warmup, self.nstream)):
-            self.step(self.warm_frames, i, h2d)
+            self.step(i, resident, warm=True)
         torch.cuda.synchronize()
         if os.environ.get("Y3_BENCH_DEBUG_AFTER_WARMUP"):      # diagnostic libraries only (timing experiments)
             from yolov3 import _hip
@@ -316,7 +263,7 @@ class Workload(object):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            self.step(self.frames, i, h2d)
+            self.step(i, resident)
         self.host_enqueue_s = time.perf_counter() - t0       # host time to enqueue the K steps (the GPU runs behind it)
         torch.cuda.synchronize()
         self.rank_elapsed_s = time.perf_counter() - t0       # this rank alone, before the closing barrier
@@ -331,7 +278,7 @@ class Workload(object):
         return elapsed
 
     def kept_per_frame(self):
-        return int(self.dets[0].count.cpu().numpy().mean())
+        return int(self.pipe.dets[0].count.cpu().numpy().mean())
 
     def kernel_report(self, passes, dump_ops=None):
         """Per-kernel device time with HIP events around every launch, serial passes on the launch stream (inside the
@@ -339,7 +286,7 @@ class Workload(object):
         net = self.net
         per_op = None
         for _ in range(passes):
-            net._run(self.frames, "u8", timed=True, fresh=False)
+            net._run(self.frames, "u8", timed=True, fresh=False, options=self.options)   # the plan the timed steps ran
             ms = np.array(net.last_op_ms)
             per_op = ms if per_op is None else np.minimum(per_op, ms)
         plan = net.plan_report()
@@ -607,20 +554,18 @@ def main(argv=None):
         return 2
     # Host side: ~80 launches per forward cost ~0.75 ms of one core per step (profiles/r02l_host_enqueue_probe.txt); N ranks
     # on a box that grants fewer than two cores per rank replay each forward as one captured hipGraph instead (0.07 ms).
-    use_graph = {"auto": usable_cpus() < 2 * world, "0": False, "1": True}[args.graph]
-    options = None
-    if nstream > 1 or use_graph:
-        options = {"auto_mask": _hip.options().auto_mask | (_hip.AM_HALO_TILE256 if nstream > 1 else 0), "use_graph": int(use_graph)}
+    use_graph = {"auto": world > 1 and usable_cpus() < 2 * world, "0": False, "1": True}[args.graph]
+    options = None                    # the Pipeline's own choice (throughput tiles when several batches are in flight)
+    if use_graph:
+        options = {"auto_mask": _hip.options().auto_mask | (_hip.AM_HALO_TILE256 if nstream > 1 else 0), "use_graph": 1}
     wl = Workload(args.model, args.dim, my_frames, args.dtype, params, dev, rank, world, args.kmax, nstream, options=options)
-    if args.h2d:
-        wl.enable_h2d(int(os.environ.get("Y3_BENCH_H2D_PARTS", "3")))
-    elapsed = wl.timed(args.steps, args.warmup, distributed, h2d=args.h2d)
+    elapsed = wl.timed(args.steps, args.warmup, distributed, resident=args.resident)
     kept = wl.kept_per_frame()
     ranks_seen = dist.get_world_size() if distributed else 1
 
     per_rank = rank_stats(wl.rank_elapsed_s, wl.host_enqueue_s, args.steps, world, dev) if distributed else \
         rank_stats(wl.rank_elapsed_s, wl.host_enqueue_s, args.steps, 1, None)
-    extras = rank == 0 and world == 1 and not args.no_extras and not args.h2d and args.scaling == "weak"
+    extras = rank == 0 and world == 1 and not args.no_extras and not args.resident and args.scaling == "weak"
     line = None
     if rank == 0:
         traffic_table, traffic_note = load_traffic_table()
@@ -639,13 +584,16 @@ def main(argv=None):
             "config": {"workload": "%s %dx%d batch=%d/GPU %s, procedural weights, uint8 frames %s -> "
                                    "detections (thr 0.05, NMS IoU 0.3), ~%d kept/frame" % (
                                        args.model, dim, dim, b, args.dtype,
-                                       "in pinned host memory, H2D + records D2H inside the step (PCIe-inclusive, not "
-                                       "the headline)" if args.h2d else "resident in HBM", kept),
+                                       "resident in HBM, records left on the device (--resident: NOT the headline "
+                                       "configuration)" if args.resident else
+                                       "in pinned host memory, upload + records back to pinned host memory inside every step "
+                                       "(PCIe inclusive, SURVEY.md 8(d)), yolov3.pipeline.Pipeline", kept),
                        "frames_per_gpu": b, "global_batch": sum(all_frames), "parallelism": "dp%d" % world,
                        "batches_in_flight_per_gpu": nstream, "ranks_seen_by_collective": ranks_seen,
-                       "plan_options": wl.options or "library defaults",
+                       "plan_options": wl.options or "library defaults", "timed_loop": "yolov3.pipeline.Pipeline.submit",
                        "collective": ("1 x all_gather_into_tensor(%d x %d x 8 int32 records) per step, side stream" % (
                            b, args.kmax)) if distributed else "none"},
+            "use_graph": bool(use_graph),
             "roofline": roof,
             "per_rank": per_rank,
             "cpu_baseline": None,
@@ -661,15 +609,14 @@ def main(argv=None):
                            for k, v in report["by_kernel"].items()}
 
     if extras:
-        # ---- PCIe-inclusive rate of the same workload (never `value`) ---------------------------------------
-        wl.enable_h2d(3)
-        e2 = wl.timed(args.steps, min(args.warmup, 5), False, h2d=True)
-        line["pcie_inclusive"] = {
+        # ---- the same steps with the frames already in HBM and the records left there (the kernels alone) ----------
+        e2 = wl.timed(args.steps, min(args.warmup, 5), False, resident=True)
+        line["resident"] = {
             "value": round(my_frames * args.steps / e2, 2), "unit": "frames/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
-            "what": "same workload, frames start in pinned host memory and the packed detection records end there, inside every "
-                    "step: y3_copy_bytes on a copy stream (8 workgroups read the pinned frames over PCIe into one of six device "
-                    "buffers) and 4 workgroups writing the records back; GPU_MAX_HW_QUEUES=8 so that the copy stream does not share "
-                    "a hardware queue with a compute stream"}
+            "what": "same pipeline, frames resident in HBM and records left on the device (rounds 1-3 reported this as `value`); "
+                    "the headline adds, inside every step, y3_copy_bytes on a copy stream (8 workgroups read the pinned frames over "
+                    "PCIe into one of six device buffers) and 4 workgroups writing the records back; GPU_MAX_HW_QUEUES=8 so that "
+                    "the copy stream does not share a hardware queue with a compute stream"}
         # ---- the other single-GPU configurations of BASELINE.json (parity cases; each with its own roofline) -----
         others = []
         for model, dim, batch, dtype in (("yolov3-tiny", 416, 8, "float32"), ("yolov3-spp", 608, 16, "bf16"),

@@ -11,7 +11,13 @@ and ``torch.cuda`` streams are valid inside this library (same runtime instance)
 import ctypes
 import os
 
-import torch  # noqa: F401  (must be loaded before libyolov3_hip.so, see above)
+# HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share a queue run one after
+# the other: the pipeline's copy stream next to its three compute streams needs more (yolov3/pipeline.py;
+# profiles/r03c_pcie_inclusive.txt: 4.9 k against 6.3 k frames/s).  Read by the runtime when it initialises, i.e. at the first
+# GPU call of the process -- importing this package before that is enough.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: F401,E402  (must be loaded before libyolov3_hip.so, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # Y3_HIP_LIB: developer override (e.g. the diagnostic build with in-kernel phase stamps)

@@ -71,12 +71,13 @@ class _CompiledPlan(object):
 
 
 class Darknet(object):
-    def __init__(self, config_fpath, device="cuda", dtype="float32", keep_all=False, fuse=None, options=None):
+    def __init__(self, config_fpath, device="cpu", dtype="float32", keep_all=False, fuse=None, options=None):
         """
         Args:
             config_fpath (str): Darknet .cfg file.
-            device (str): "cuda", "cuda:N" (an MI355X) -- or "cpu" to only build the
-                description; ``forward`` needs a GPU device (call ``.cuda()``).
+            device (str): "cpu" [default, like the reference: darknet.py:319] only builds the description;
+                ``forward`` needs "cuda" / "cuda:N" (an MI355X): pass it here or call ``.cuda()`` as the
+                reference's command line does (__main__.py:119-120).
             dtype (str): "float32" (parity path, exact fp32 MFMA) or "bf16"
                 (bf16 activations/weights, fp32 accumulation; throughput path).
         """
@@ -238,7 +239,7 @@ class Darknet(object):
         _hip.require_gpu()
         return torch.device(self.device)
 
-    def _compile(self, batch, height, width, input_mode):
+    def _compile(self, batch, height, width, input_mode, options=None):
         if self._params is None:
             raise RuntimeError("call load_weights() / set_params() before forward()")
         dev = self._torch_device()
@@ -342,23 +343,26 @@ class Darknet(object):
                 ops[n].d_bbox, ops[n].d_prob, ops[n].d_cls = (
                     cp.bbox.data_ptr(), cp.prob.data_ptr(), cp.cls.data_ptr())
         handle = ctypes.c_void_p()
-        opt = _hip.options(**self.options) if self.options else None
+        options = options if options is not None else self.options
+        opt = _hip.options(**options) if options else None
         _hip.check(lib.y3_plan_create_ex(ops, cp.n_ops, self._zero.data_ptr(),
                                          ctypes.byref(opt) if opt is not None else None, ctypes.byref(handle)))
         cp.handle = handle
         return cp
 
-    def _get_plan(self, batch, height, width, input_mode, slot=0):
+    def _get_plan(self, batch, height, width, input_mode, slot=0, options=None):
         # `slot` selects an independent arena + output buffers (one per in-flight batch when the caller
-        # pipelines batches over several HIP streams)
-        key = (batch, height, width, input_mode, self.dtype, str(self.device), slot)
+        # pipelines batches over several HIP streams); `options` (a dict, see __init__) override the network's
+        # plan options for this plan only (yolov3/pipeline.py asks for the throughput tile choice)
+        okey = tuple(sorted(options.items())) if options else None
+        key = (batch, height, width, input_mode, self.dtype, str(self.device), slot, okey)
         cp = self._plans.get(key)
         if cp is None:
-            cp = self._compile(batch, height, width, input_mode)
+            cp = self._compile(batch, height, width, input_mode, options)
             self._plans[key] = cp
         return cp
 
-    def _run(self, x, input_mode, timed=False, fresh=True, slot=0):
+    def _run(self, x, input_mode, timed=False, fresh=True, slot=0, options=None):
         """Launch the plan on torch's current stream.  ``fresh=False`` returns the plan's own
         output buffers (overwritten by the next call with the same shape) -- used by
         ``inference()`` and the benchmark, which consume them immediately."""
@@ -370,7 +374,7 @@ class Darknet(object):
             batch, ch, height, width = x.shape
         if ch != self.net_info["channels"]:
             raise ValueError("input has {} channels, cfg says {}".format(ch, self.net_info["channels"]))
-        cp = self._get_plan(batch, height, width, input_mode, slot)
+        cp = self._get_plan(batch, height, width, input_mode, slot, options)
         with torch.cuda.device(dev):
             if timed:
                 ms = (ctypes.c_float * cp.n_ops)()
@@ -395,7 +399,7 @@ class Darknet(object):
         x = x.to(device=dev, dtype=torch.float32).contiguous()
         return self._run(x, "f32")
 
-    def forward_frames(self, frames_u8, fresh=True, slot=0):
+    def forward_frames(self, frames_u8, fresh=True, slot=0, options=None):
         """frames_u8: (B,H,W,3) uint8 BGR (numpy or torch).  Same outputs as ``forward`` on
         ``flip(frames)/255`` transposed to NCHW (inference.py:332-333), preprocessing fused
         into the first conv kernel."""
@@ -404,7 +408,7 @@ class Darknet(object):
             frames_u8 = torch.from_numpy(np.ascontiguousarray(frames_u8))
         if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4:
             raise ValueError("expected uint8 (B,H,W,3) frames")
-        return self._run(frames_u8.to(dev).contiguous(), "u8", fresh=fresh, slot=slot)
+        return self._run(frames_u8.to(dev).contiguous(), "u8", fresh=fresh, slot=slot, options=options)
 
     def block_output(self, i):
         """(B,C,H,W) float32 copy of block i's output from the last forward.  Needs

@@ -1,0 +1,183 @@
+"""``Pipeline``: several batches in flight between host frames and host detections.
+
+What the reference does per frame in ``inference()`` (/root/reference/yolov3/inference.py:335 ``torch.tensor(inp, device=..)``,
+:336 forward, :338-340 ``.detach().cpu().numpy()``, :342-366 threshold / NMS on the host) is here one pipelined pass per BATCH:
+
+    pinned host frames --y3_copy_bytes (copy stream)--> device frame buffer --forward (stream k, arena k)--> y3_detect
+        --> y3_pack_records [--all_gather_into_tensor on a side stream, N ranks--] --y3_copy_bytes--> pinned host records
+
+with ``in_flight`` batches (default 3) on their own HIP streams, each with its own activation arena, detector buffers and
+record buffers, so that one batch's kernel tails, its frame upload and its record download run under the other batches'
+kernels.  This is the loop ``bench.py`` times (its headline number is this class fed from pinned host memory) and the loop
+``stream.detect_in_frames`` / the command line run: the benchmarked configuration IS the package's.
+
+Results equal per-frame ``inference()`` bit for bit (frames are independent, kernel choice does not change a bit:
+tests/test_gpu_properties.py, tests/test_gpu_pipeline.py).
+"""
+import numpy as np
+import torch
+
+from . import _hip
+from .dist import DetectionGather, unpack_records
+from .inference import Detector
+
+
+class Pipeline(object):
+    """``submit(frames)`` enqueues one batch and returns a ticket; ``results(ticket)`` waits for that batch only.
+
+    frames: a (batch, H, W, 3) uint8 BGR batch -- a PINNED torch tensor (uploaded straight from where it lies; fill
+    ``host_frames(j)`` to get one), a device tensor (no upload), or anything else array-like (staged through a pinned buffer:
+    one extra host copy).  At most ``in_flight`` tickets are open at a time: submitting the ``in_flight + 1``-th reuses the
+    oldest ticket's buffers (its results must have been taken, or are dropped -- the benchmark does that on purpose).
+    """
+
+    def __init__(self, net, batch, height=None, width=None, in_flight=3, prob_thresh=0.05, nms_iou_thresh=0.3, kmax=512,
+                 world=1, group=None, options=None, copy_blocks=8):
+        _hip.require_gpu()
+        if batch < 1 or in_flight < 1:
+            raise ValueError("batch and in_flight must be positive")
+        if not str(net.device).startswith("cuda"):
+            net.cuda()
+        self.net, self.batch, self.in_flight, self.kmax = net, int(batch), int(in_flight), int(kmax)
+        self.height = int(height or net.net_info["height"])
+        self.width = int(width or net.net_info["width"])
+        self.prob_thresh, self.nms_iou_thresh = float(np.float32(prob_thresh)), float(nms_iou_thresh)
+        self.dev = dev = net._torch_device()
+        self.copy_blocks = int(copy_blocks)
+        # several batches in flight: CU time counts, not one launch's tail -> the strip kernel's 256-pixel tiles
+        # (include/yolov3_hip.h: Y3_AM_HALO_TILE256).  Explicit ``options`` win.
+        if options is None and self.in_flight > 1:
+            base = dict(net.options or {})
+            base["auto_mask"] = int(base.get("auto_mask", _hip.options().auto_mask)) | _hip.AM_HALO_TILE256
+            options = base
+        self.options = dict(options) if options else None
+        with torch.cuda.device(dev):
+            self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.in_flight)]
+            self.copy_stream = torch.cuda.Stream(device=dev)
+            plans = [net._get_plan(self.batch, self.height, self.width, "u8", slot=k, options=self.options)
+                     for k in range(self.in_flight)]
+            self.rows = plans[0].rows_total
+            self.dets = [Detector(self.batch, self.rows, dev) for _ in range(self.in_flight)]
+            distributed = world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized())
+            # one side stream for all gathers of this rank: every HIP stream needs a hardware queue of its own to overlap
+            side = torch.cuda.Stream(device=dev) if distributed else None
+            self.gathers = [DetectionGather(self.batch, self.rows, self.kmax, dev, world, group=group, side=side)
+                            for _ in range(self.in_flight)]
+            self.world = world
+            # TWO device frame buffers per batch in flight: with one, the upload of ticket i could only start when the
+            # forward of ticket i - in_flight (same stream, same buffer) had finished -- exactly when that stream was ready
+            # for its next forward, which then waited out the whole copy (profiles/r03c_pcie_inclusive.txt)
+            self.nbuf = 2 * self.in_flight
+            shape = (self.batch, self.height, self.width, 3)
+            self.dev_frames = [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(self.nbuf)]
+            self._host_frames = [None] * self.nbuf           # pinned staging / caller-fillable buffers, made on demand
+            self.free_ev = [torch.cuda.Event() for _ in range(self.nbuf)]
+            self.ready_ev = [torch.cuda.Event() for _ in range(self.nbuf)]
+            for e in self.free_ev + self.ready_ev:
+                e.record()
+            self.host_rec = [torch.empty((world * self.batch, self.kmax, 8), dtype=torch.int32).pin_memory()
+                             for _ in range(self.in_flight)]
+            self.done_ev = [torch.cuda.Event() for _ in range(self.in_flight)]
+            self.full_hw = torch.tensor([[self.height, self.width]] * self.batch, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize(dev)
+        self._n = 0                     # tickets issued
+        self._uploads = 0               # uploads issued (device frame buffer = uploads % nbuf)
+        self._fetched = [True] * self.in_flight
+        self._frames_in = [0] * self.in_flight
+
+    # ------------------------------------------------------------------ host buffers
+    def host_frames(self, j):
+        """Pinned (batch, H, W, 3) uint8 buffer number ``j`` (0 .. 2 * in_flight - 1) for the caller to decode frames into;
+        ``submit`` uploads from it without a staging copy.  Refill buffer j only after ``upload_done(j)``."""
+        j %= self.nbuf
+        if self._host_frames[j] is None:
+            self._host_frames[j] = torch.empty((self.batch, self.height, self.width, 3), dtype=torch.uint8).pin_memory()
+        return self._host_frames[j]
+
+    def upload_done(self, j, wait=True):
+        """Has the last upload that read ``host_frames(j)`` finished (``wait``: block until it has)?"""
+        ev = self.ready_ev[j % self.nbuf]
+        if wait:
+            ev.synchronize()
+            return True
+        return ev.query()
+
+    # ------------------------------------------------------------------ the pipelined step
+    def submit(self, frames, orig_hw=None, n_frames=None, to_host=True):
+        """Enqueue one batch.  ``orig_hw``: (batch, 2) original frame sizes when the frames were resized to the network's
+        size (default: they are net-sized).  ``n_frames``: how many leading frames of the batch are real (a short last
+        batch).  ``to_host=False`` leaves the records on the device (resident-rate measurements).  Returns the ticket."""
+        i = self._n
+        k = i % self.in_flight
+        lib = _hip.lib()
+        with torch.cuda.device(self.dev), torch.cuda.stream(self.streams[k]):
+            cur = self.streams[k]
+            if isinstance(frames, torch.Tensor) and frames.is_cuda:
+                fr, j = frames, None
+            else:
+                j = self._uploads % self.nbuf
+                self._uploads += 1
+                host = frames if (isinstance(frames, torch.Tensor) and frames.is_pinned()) else None
+                if host is None:
+                    # pageable input: stage it (the staging buffer is free once the upload that last read it has finished)
+                    self.ready_ev[j].synchronize()
+                    host = self.host_frames(j)
+                    src = frames if isinstance(frames, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frames))
+                    host[:src.shape[0]].copy_(src)
+                if tuple(host.shape[1:]) != (self.height, self.width, 3) or host.dtype != torch.uint8 or not host.is_contiguous():
+                    raise ValueError("expected contiguous uint8 frames of shape (<= {}, {}, {}, 3)".format(self.batch, self.height, self.width))
+                # the copy runs on its own stream, into the buffer the forward of upload (uploads - nbuf) read last
+                with torch.cuda.stream(self.copy_stream):
+                    self.copy_stream.wait_event(self.free_ev[j])
+                    _hip.check(lib.y3_copy_bytes(host.data_ptr(), self.dev_frames[j].data_ptr(),
+                                                 min(host.numel(), self.dev_frames[j].numel()), self.copy_blocks,
+                                                 _hip.stream_ptr(self.copy_stream)))
+                    self.ready_ev[j].record(self.copy_stream)
+                cur.wait_event(self.ready_ev[j])
+                fr = self.dev_frames[j]
+            if tuple(fr.shape) != (self.batch, self.height, self.width, 3):
+                raise ValueError("device frames must be ({}, {}, {}, 3) uint8".format(self.batch, self.height, self.width))
+            out = self.net.forward_frames(fr, fresh=False, slot=k, options=self.options)
+            if j is not None:
+                self.free_ev[j].record(cur)
+            det = self.dets[k]
+            det.run(out, self.full_hw if orig_hw is None else orig_hw, self.prob_thresh, self.nms_iou_thresh)
+            g = self.gathers[k]
+            rec = g.run(det)
+            if to_host:
+                if g.done is not None:
+                    cur.wait_event(g.done)
+                _hip.check(lib.y3_copy_bytes(rec.data_ptr(), self.host_rec[k].data_ptr(), rec.numel() * rec.element_size(), 4,
+                                             _hip.stream_ptr(cur)))
+            self.done_ev[k].record(cur)
+        self._fetched[k] = not to_host
+        self._frames_in[k] = self.batch if n_frames is None else int(n_frames)
+        self._n += 1
+        return i
+
+    def records(self, ticket):
+        """Host records of all ranks for ``ticket``: (world * batch, kmax, 8) int32 (a view of the pinned buffer, valid
+        until the ticket's slot is reused); waits for that batch only."""
+        if not (self._n - self.in_flight <= ticket < self._n):
+            raise ValueError("ticket {} is not open (open: {} .. {})".format(ticket, max(0, self._n - self.in_flight), self._n - 1))
+        k = ticket % self.in_flight
+        self.done_ev[k].synchronize()
+        return self.host_rec[k].numpy()
+
+    def results(self, ticket, return_rows=False):
+        """Per frame of THIS rank's batch: ``[bbox_tlbr int64 (K,4), class_prob f32 (K,), class_idx int64 (K,)]`` (+ prediction
+        rows), the contract of ``inference()``.  A frame that kept more than ``kmax`` boxes is fetched again in full."""
+        rec = self.records(ticket)
+        k = ticket % self.in_flight
+        mine = rec[:self.batch] if self.world == 1 else rec     # single rank: all frames are ours
+        if self.world == 1 and mine.size and int(mine[:, 0, 7].max()) > self.kmax:
+            with torch.cuda.device(self.dev), torch.cuda.stream(self.streams[k]):
+                full = self.dets[k].fetch(return_rows=return_rows, kmax=int(mine[:, 0, 7].max()))
+            return full[:self._frames_in[k]]
+        items = unpack_records(mine)
+        n = self._frames_in[k] if self.world == 1 else len(items)
+        return [item[:4] if return_rows else item[:3] for item in items[:n]]
+
+    def synchronize(self):
+        for s in self.streams + [self.copy_stream]:
+            s.synchronize()

@@ -3,8 +3,8 @@
 Reference counterparts: ``to_coco`` (/root/reference/yolov3/inference.py:371-432), ``draw_boxes``
 (:97-158), ``detect_in_video`` (:496-544), ``detect_in_cam`` (:435-493) and the ``--image`` loop
 of the CLI (/root/reference/yolov3/__main__.py:161-187, which runs one frame at a time and leaves
-batching as a TODO).  Here frames are grouped into batches and two batches are kept in flight on
-separate HIP streams (each with its own activation arena and detection buffers), because a GPU
+batching as a TODO).  Here frames are grouped into batches and three batches are kept in flight on
+separate HIP streams (each with its own activation arena and detection buffers; yolov3/pipeline.py), because a GPU
 only earns its throughput on batches; results are yielded in frame order and are identical to
 calling ``inference()`` on every frame by itself.
 
@@ -20,7 +20,6 @@ import numpy as np
 import torch
 
 from . import _hip
-from .inference import Detector
 from .preprocess import prepare_frames_device
 
 IMAGE_EXTENSIONS = (".jpg", ".jpeg", ".png", ".bmp", ".ppm", ".webp", ".tif", ".tiff")
@@ -66,14 +65,19 @@ def _batches(frames, batch_size):
 
 
 def detect_in_frames(net, frames, batch_size=16, prob_thresh=0.05, nms_iou_thresh=0.3, resize=True,
-                     in_flight=2):
+                     in_flight=3, kmax=512):
     """Generator over ``[bbox_tlbr, class_prob, class_idx]`` for every frame of the iterable
     ``frames`` (HxWx3 uint8 BGR arrays; sizes may differ when ``resize``), in order.
 
-    Batches of ``batch_size`` frames are launched round-robin on ``in_flight`` HIP streams; a
-    batch's detections are fetched only when its slot is needed again (or at the end), so
-    decoding / uploading batch k+1 overlaps the kernels of batch k.
+    The frames run through :class:`yolov3.pipeline.Pipeline` -- the loop ``bench.py`` times -- in batches of
+    ``batch_size`` with ``in_flight`` batches on their own HIP streams: a batch's detections are taken only when its
+    slot is needed again (or at the end), so decoding / uploading batch k+1 overlaps the kernels of batch k.
+    Net-sized frames are stacked straight into one of the pipeline's pinned host buffers and uploaded from there;
+    other sizes are uploaded one by one and resized on the GPU.  ``frames`` may also yield whole (B, H, W, 3) batches
+    of net-sized frames: a pinned torch tensor is then uploaded from where it lies (no host copy at all), which is how
+    a decoder that fills ``Pipeline.host_frames`` reaches the benchmark's rate.
     """
+    from .pipeline import Pipeline
     _hip.require_gpu()
     if batch_size < 1 or in_flight < 1:
         raise ValueError("batch_size and in_flight must be positive")
@@ -81,38 +85,69 @@ def detect_in_frames(net, frames, batch_size=16, prob_thresh=0.05, nms_iou_thres
         net.cuda()
     dev = net._torch_device()
     height, width = net.net_info["height"], net.net_info["width"]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(in_flight)]
-    pending = [None] * in_flight          # (detector, n_frames) launched on that stream
-    detectors = {}                        # (slot, batch, rows) -> Detector
+    state = {"pipe": None, "keep": {}, "filled": 0}
 
-    def drain(slot):
-        job, pending[slot] = pending[slot], None
-        if job is None:
-            return []
-        det, count = job
-        streams[slot].synchronize()
-        return det.fetch()[:count]
+    def pipeline(batch):
+        if state["pipe"] is None:
+            state["pipe"] = Pipeline(net, batch, height, width, in_flight=in_flight, prob_thresh=prob_thresh,
+                                     nms_iou_thresh=nms_iou_thresh, kmax=kmax)
+        return state["pipe"]
 
-    n_batches = 0
-    with torch.cuda.device(dev):
-        for batch in _batches(frames, batch_size):
-            slot = n_batches % in_flight
-            for result in drain(slot):
+    def submit(batch):
+        """batch: list of frames, or one (B, H, W, 3) array / tensor.  Returns the ticket."""
+        whole = not isinstance(batch, list)
+        n = int(batch.shape[0]) if whole else len(batch)
+        pipe = pipeline(n)
+        if n > pipe.batch:
+            raise ValueError("a batch of {} frames after the pipeline was sized for {}".format(n, pipe.batch))
+        if whole:
+            if tuple(batch.shape[1:]) != (height, width, 3):
+                raise ValueError("whole batches must be net-sized: (B, {}, {}, 3)".format(height, width))
+            if n == pipe.batch:
+                return pipe.submit(batch, n_frames=n)
+            batch = list(batch)                               # a short last batch: through the staging path below
+        if all(tuple(f.shape[:2]) == (height, width) for f in batch):
+            j = state["filled"] % pipe.nbuf
+            state["filled"] += 1
+            pipe.upload_done(j)                               # the upload that last read this pinned buffer is over
+            host = pipe.host_frames(j).numpy()
+            for i, f in enumerate(batch):
+                host[i] = f.numpy() if isinstance(f, torch.Tensor) else f
+            return pipe.submit(pipe.host_frames(j), n_frames=n)
+        # frames of other sizes: uploaded one by one and resized on the GPU, on the stream the pipeline will run the batch on
+        k = pipe._n % pipe.in_flight
+        pad = batch + [batch[-1]] * (pipe.batch - n)
+        with torch.cuda.device(dev), torch.cuda.stream(pipe.streams[k]):
+            dev_frames, shapes = prepare_frames_device(pad, height, width, dev, resize)
+        state["keep"][k] = dev_frames                         # alive until the slot is reused
+        orig_hw = np.array([[s[0], s[1]] for s in shapes], dtype=np.int32)
+        return pipe.submit(dev_frames, orig_hw=orig_hw, n_frames=n)
+
+    def batches():
+        group = []
+        for item in frames:
+            if getattr(item, "ndim", 3) == 4:
+                if group:
+                    yield group
+                    group = []
+                yield item
+                continue
+            group.append(item)
+            if len(group) == batch_size:
+                yield group
+                group = []
+        if group:
+            yield group
+
+    open_tickets = []
+    for batch in batches():
+        if len(open_tickets) == in_flight:                    # the slot this batch will take: its results first
+            for result in state["pipe"].results(open_tickets.pop(0)):
                 yield result
-            with torch.cuda.stream(streams[slot]):
-                dev_frames, shapes = prepare_frames_device(list(batch), height, width, dev, resize)
-                out = net.forward_frames(dev_frames, fresh=False, slot=slot)
-                nb, rows = out["class_prob"].shape
-                det = detectors.get((slot, nb, rows))
-                if det is None:
-                    det = detectors[(slot, nb, rows)] = Detector(nb, rows, dev)
-                orig_hw = np.array([[s[0], s[1]] for s in shapes], dtype=np.int32)
-                det.run(out, orig_hw, float(np.float32(prob_thresh)), float(nms_iou_thresh))
-            pending[slot] = (det, len(batch))
-            n_batches += 1
-        for j in range(max(0, n_batches - in_flight), n_batches):   # batches still in flight, oldest first
-            for result in drain(j % in_flight):
-                yield result
+        open_tickets.append(submit(batch))
+    for ticket in open_tickets:
+        for result in state["pipe"].results(ticket):
+            yield result
 
 
 def detect_in_images(net, path, batch_size=16, prob_thresh=0.05, nms_iou_thresh=0.3):
