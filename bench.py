@@ -80,6 +80,9 @@ def parse_args(argv=None):
                     help="weak [default]: --batch frames per GPU whatever N (BASELINE.json configs[4]: 16 per GPU); strong: "
                          "--total-frames frames per step split over the N GPUs (SURVEY.md 8(d): 128 total)")
     ap.add_argument("--total-frames", type=int, default=128, help="frames per step of the whole job with --scaling strong")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="wall-clock limit (s) of the N-rank child job that `--gpus N` starts; on expiry its process group is "
+                         "killed and the exit code is 124")
     ap.add_argument("--graph", default="auto", choices=["auto", "0", "1"],
                     help="replay each forward as one captured hipGraph (0.07 instead of ~0.75 ms of host time per step): auto = "
                          "eager on one GPU (the headline is always measured the same way); with N > 1 ranks only when a rank "
@@ -125,9 +128,23 @@ def cpu_model():
 # launcher: `python bench.py --gpus N` without torchrun
 # ------------------------------------------------------------------------------------------------
 
+def _tail(path, n=12):
+    try:
+        with open(path, errors="replace") as fh:
+            return fh.read().splitlines()[-n:]
+    except OSError:
+        return []
+
+
 def self_launch(args, argv):
     """Start N ranks as a child torch.distributed.run job.  Runs BEFORE this process has made any GPU call (a
-    process that has initialised the GPU must not exec / is not what gets replaced here: the job is a child)."""
+    process that has initialised the GPU must not exec / is not what gets replaced here: the job is a child).
+    The parent is the watchdog: the job runs in its own process group under a wall-clock limit (--launch-timeout); on
+    expiry the whole group is killed (a rank stuck in RCCL init would otherwise burn the caller's limit); on any failure
+    every rank's last stderr lines are printed and the exit code is non-zero.  It only starts and kills children."""
+    import shutil
+    import signal
+    import tempfile
     plumbing = os.environ.get("Y3_BENCH_PLUMBING")
     if not plumbing:
         visible = torch.cuda.device_count()        # counts devices without initialising the GPU runtime
@@ -138,19 +155,78 @@ def self_launch(args, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    logdir = tempfile.mkdtemp(prefix="y3_bench_ranks_")
+    # --tee 3: every rank's stdout / stderr goes to the console AND to <logdir>/.../<rank>/std{out,err}.log
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "--log-dir", logdir, "--tee", "3",
+           os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // args.gpus)))
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, universal_newlines=True)
-    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
-    if proc.returncode != 0 or len(lines) != 1:
-        sys.stderr.write(proc.stdout[-4000:])
-        sys.stderr.write("\nbench.py: the %d-rank job failed (exit code %d, %d JSON lines)\n" % (
-            args.gpus, proc.returncode, len(lines)))
-        return proc.returncode or 1
+    limit = float(os.environ.get("Y3_BENCH_LAUNCH_TIMEOUT", args.launch_timeout))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                            start_new_session=True)
+    timed_out = False
+    try:
+        out, err = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        for sig in (signal.SIGTERM, signal.SIGKILL):       # the whole process group: torchrun, its ranks, their children
+            try:
+                os.killpg(proc.pid, sig)
+            except (ProcessLookupError, PermissionError):
+                break
+            try:
+                out, err = proc.communicate(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        else:
+            out, err = proc.communicate()
+    # rank 0's JSON line arrives tee'd as "[default0]:{...}"
+    lines = []
+    for ln in out.splitlines():
+        i = ln.find("{")
+        if i >= 0 and ln[:i].strip() in ("", "[default0]:") and ln.rstrip().endswith("}"):
+            lines.append(ln[i:])
+    ok = (not timed_out) and proc.returncode == 0 and len(lines) == 1
+    if not ok:
+        sys.stderr.write(err[-4000:])
+        for root, _, files in sorted(os.walk(logdir)):
+            if "stderr.log" in files:
+                tail = _tail(os.path.join(root, "stderr.log"))
+                sys.stderr.write("\n---- rank %s, last stderr lines ----\n%s\n" % (os.path.basename(root), "\n".join(tail) or "(empty)"))
+        if timed_out:
+            sys.stderr.write("\nbench.py: the %d-rank job did not finish within %.0f s (--launch-timeout): process group killed\n" % (
+                args.gpus, limit))
+        else:
+            sys.stderr.write("\nbench.py: the %d-rank job failed (exit code %s, %d JSON lines)\n" % (
+                args.gpus, proc.returncode, len(lines)))
+    shutil.rmtree(logdir, ignore_errors=True)
+    if not ok:
+        return 124 if timed_out else (proc.returncode or 1)
     print(lines[0], flush=True)
     return 0
+
+
+def init_group(backend, dev=None):
+    """Process group with a BOUNDED rendezvous (a rank that never arrives must not hang the others for the default ten
+    minutes), then one real collective: every rank contributes its rank, and the job fails unless ranks 0 .. N-1 are seen."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    world = int(os.environ["WORLD_SIZE"])
+    timeout = datetime.timedelta(seconds=float(os.environ.get("Y3_BENCH_INIT_TIMEOUT", "180")))
+    if dev is not None:
+        dist.init_process_group(backend=backend, device_id=dev, timeout=timeout)
+    else:
+        dist.init_process_group(backend=backend, timeout=timeout)
+    mine = torch.tensor([dist.get_rank()], dtype=torch.int64, device=dev if dev is not None else "cpu")
+    seen = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(seen, mine)
+    seen = sorted(int(t.item()) for t in seen)
+    if seen != list(range(world)):
+        raise SystemExit("bench.py: the collective saw ranks %s, expected 0 .. %d" % (seen, world - 1))
+    return len(seen)
 
 
 def rank_stats(elapsed, host_enqueue, steps, world, dev):
@@ -180,8 +256,12 @@ def plumbing_main(args, backend):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     if os.environ.get("Y3_BENCH_FAIL_RANK") == str(rank):
         raise SystemExit(3)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend=backend)
+    if os.environ.get("Y3_BENCH_HANG_RANK") == str(rank):      # tests: a rank that never reaches the rendezvous
+        time.sleep(1e6)
+    ranks_seen = init_group(backend)
+    if os.environ.get("Y3_BENCH_DIE_AFTER_INIT") == str(rank):  # tests: a rank that dies once the group exists
+        sys.stderr.write("rank %d: dying after init (test hook)\n" % rank)
+        os._exit(5)
     b = frames_per_rank(args, rank, world)
     bmax = max(frames_per_rank(args, r, world) for r in range(world))
     rs = np.random.RandomState(rank)
@@ -205,7 +285,7 @@ def plumbing_main(args, backend):
         total = sum(frames_per_rank(args, r, world) for r in range(world))
         print(json.dumps({"metric": "frames/sec (608x608)", "value": None, "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "plumbing_only": True, "scaling": args.scaling,
-                          "ranks_seen_by_collective": dist.get_world_size(),
+                          "ranks_seen_by_collective": ranks_seen,
                           "frames_gathered_per_step": int(counts_of(out).shape[0]), "per_rank": stats,
                           "config": {"global_batch": total, "frames_per_gpu": [frames_per_rank(args, r, world) for r in range(world)],
                                      "parallelism": "dp%d" % world}}), flush=True)
@@ -530,9 +610,9 @@ def main(argv=None):
         return 2
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        ranks_seen = init_group("nccl", dev)
 
     from yolov3 import _hip, weights as W
     from yolov3.cfgparse import parse_config
@@ -561,7 +641,6 @@ def main(argv=None):
     wl = Workload(args.model, args.dim, my_frames, args.dtype, params, dev, rank, world, args.kmax, nstream, options=options)
     elapsed = wl.timed(args.steps, args.warmup, distributed, resident=args.resident)
     kept = wl.kept_per_frame()
-    ranks_seen = dist.get_world_size() if distributed else 1
 
     per_rank = rank_stats(wl.rank_elapsed_s, wl.host_enqueue_s, args.steps, world, dev) if distributed else \
         rank_stats(wl.rank_elapsed_s, wl.host_enqueue_s, args.steps, 1, None)

@@ -153,3 +153,31 @@ def test_bench_self_launch_propagates_rank_failure():
     r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"Y3_BENCH_PLUMBING": "gloo", "Y3_BENCH_FAIL_RANK": "1"})
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_launcher_kills_a_job_with_a_hanging_rank():
+    """A rank that never reaches the rendezvous: the others give up after the bounded init timeout or the watchdog kills the
+    whole process group at --launch-timeout -- either way non-zero, no JSON line, well inside a minute, nobody left behind."""
+    import time
+    t0 = time.time()
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--launch-timeout", "25"],
+                   {"Y3_BENCH_PLUMBING": "gloo", "Y3_BENCH_HANG_RANK": "1", "Y3_BENCH_INIT_TIMEOUT": "600"}, timeout=120)
+    assert r.returncode != 0 and time.time() - t0 < 60
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "did not finish within 25 s" in r.stderr and "process group killed" in r.stderr
+    # bounded init on its own: with a short init timeout the waiting rank fails by itself before the watchdog fires
+    t0 = time.time()
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--launch-timeout", "50"],
+                   {"Y3_BENCH_PLUMBING": "gloo", "Y3_BENCH_HANG_RANK": "1", "Y3_BENCH_INIT_TIMEOUT": "8"}, timeout=120)
+    assert r.returncode != 0 and time.time() - t0 < 60
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_launcher_reports_a_rank_that_dies_after_init():
+    import time
+    t0 = time.time()
+    r = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0", "--launch-timeout", "50"],
+                   {"Y3_BENCH_PLUMBING": "gloo", "Y3_BENCH_DIE_AFTER_INIT": "1"}, timeout=120)
+    assert r.returncode != 0 and time.time() - t0 < 60
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "dying after init" in r.stderr          # the dead rank's last stderr lines are in the report
