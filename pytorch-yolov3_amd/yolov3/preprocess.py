@@ -17,9 +17,12 @@ and the 8-bit specialisation of ``VResizeLinear``; IPP is not used for 8-bit lin
 * an exact 2:1 reduction, which OpenCV routes to its INTER_AREA fast path ``(s00 + s01 + s10 + s11 + 2) >> 2``,
   comes out of the formulas above unchanged (all four weights are 1024).
 
-PARITY UNPINNED for this function: without cv2 here it cannot be checked against OpenCV itself (INTEGRATION.md);
-host (:func:`resize_bilinear_u8`) and device (``y3_resize_bilinear_u8``) are bit-identical to each other, and
-net-sized frames -- the benchmark's case -- skip the resize exactly like the reference does (inference.py:322-326).
+PARITY against OpenCV ITSELF is unpinned for this function (no cv2 in this image: INTEGRATION.md).  What is pinned
+(tests/test_resize_pin.py): host (:func:`resize_bilinear_u8`) and device (``y3_resize_bilinear_u8``) are within 1 LSB on
+every byte -- 88-91 % of the bytes equal -- of an independent float bilinear with the same conventions
+(oracle/resize_oracle.py: ``torch.nn.functional.interpolate``) on the nine sample images, up- and down-scaling, and
+bit-identical to each other; net-sized frames -- the benchmark's case, and the crop goldens tests/golden/inference_crops_* --
+skip the resize exactly like the reference does (inference.py:322-326).
 Like the reference, ``dsize`` is passed as ``(net_h, net_w)`` although cv2 reads it as (width, height): for the
 square networks shipped here that is the same thing, and :func:`reference_dsize` keeps the quirk for others.
 """

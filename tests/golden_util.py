@@ -62,6 +62,10 @@ def bench_regime_frame(name, dim):
     from yolov3.synthdata import synth_frames
     if name.startswith("img"):
         return load_jpeg_bgr("000000%s.jpg" % name[3:])
+    if name.startswith("crop"):                     # net-sized centre crop (tools/make_goldens.py: center_crop): never resized
+        frame = load_jpeg_bgr("000000%s.jpg" % name[4:])
+        y0, x0 = (frame.shape[0] - dim) // 2, (frame.shape[1] - dim) // 2
+        return np.ascontiguousarray(frame[y0:y0 + dim, x0:x0 + dim])
     return synth_frames(int(name[5:]), 1, dim, dim)[0]
 
 

@@ -225,6 +225,40 @@ def test_inference_bench_regime_all_sample_images_fp32(model):
     assert n_clean >= 4
 
 
+@pytest.mark.parametrize("model", ["yolov3-tiny", "yolov3"])
+def test_inference_net_sized_crops_fp32(model):
+    """G7c: the reference's ``inference()`` lists on net-sized centre crops of the sample images (no resize anywhere between
+    the JPEG and the network, on either side).  Audited-clean (frame, threshold) pairs must match exactly, the others go
+    through the flip rule of compare_detections."""
+    from golden_util import bench_regime_frame, product_candidates
+    g = np.load(os.path.join(GOLDEN, "inference_crops_%s.npz" % model))
+    dim = MODEL_DIMS[model]
+    net = yolov3.Darknet(MODELS[model], device="cuda", dtype="float32")
+    net.load_weights(golden_weights_path(model, obj_bias=float(g["obj_bias"]))).eval()
+    n_clean = kept = 0
+    for name in (str(n) for n in g["names"]):
+        frame = bench_regime_frame(name, dim)
+        assert frame.shape == (dim, dim, 3)
+        fwd = {k: v.cpu().numpy() for k, v in net.forward_frames(frame[None]).items()}
+        for tag in ("a", "b"):
+            pth, ith = g[tag + "_thresholds"]
+            key = "%s_%s_" % (name, tag)
+            res = yolov3.inference(net, frame, device="cuda", prob_thresh=float(pth), nms_iou_thresh=float(ith), return_rows=True)[0]
+            kept += len(res[1])
+            if bool(g[key + "audit"][4]):
+                order, gorder = np.argsort(res[3]), np.argsort(g[key + "rows"])
+                assert np.array_equal(res[3][order], g[key + "rows"][gorder]), (model, name, tag, "kept rows differ")
+                assert np.array_equal(res[2][order], g[key + "cls"][gorder]), (model, name, tag, "classes differ")
+                assert np.array_equal(res[0][order], g[key + "tlbr"][gorder]), (model, name, tag, "boxes differ")
+                np.testing.assert_allclose(res[1][order], g[key + "prob"][gorder], atol=SCORE_ATOL)
+                n_clean += 1
+            else:
+                cand = product_candidates(fwd["bbox_xywh"][0], fwd["class_prob"][0], fwd["class_idx"][0], frame.shape, pth)
+                compare_detections(g, key, res[:3], rows=res[3], prob_tol=SCORE_ATOL, cand=cand)
+    print(model, "net-sized crops: clean pairs reproduced exactly:", n_clean, "kept boxes in all:", kept)
+    assert kept > 100 and (n_clean >= 4 or model == "yolov3")
+
+
 def test_device_resize_is_bit_identical_to_host_resize():
     from yolov3.preprocess import resize_on_device
     for name, (oh, ow) in (("000000229358.jpg", (608, 608)), ("000000393569.jpg", (416, 416)), ("000000035279.jpg", (320, 480))):

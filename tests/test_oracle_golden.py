@@ -245,3 +245,26 @@ def test_bf16_agreement_fixture_is_what_the_oracle_produces():
     for f in range(3):
         a = mod.agreement(dets[f], g, "a_f%d_" % f)
         assert a["jaccard"] == fixture["a_f%d" % f]["jaccard"] and a["kept"] == fixture["a_f%d" % f]["kept"]
+
+
+@pytest.mark.parametrize("model", ["yolov3-tiny", "yolov3"])
+def test_inference_net_sized_crop_goldens(model, tmp_path):
+    """G7c: the reference's inference() on NET-SIZED centre crops of the sample images -- eight at 416^2,
+    the one 640 x 640 image at 608^2 -- i.e. end-to-end fixtures in which nothing was resized, by OpenCV or by this build's
+    restatement of it (the generator makes the cv2.resize stand-in raise).  The oracle reproduces every list exactly."""
+    from golden_util import bench_regime_frame, compare_detections
+    g = np.load(os.path.join(GOLDEN, "inference_crops_%s.npz" % model))
+    dim = MODEL_DIMS[model]
+    net = orc.OracleDarknet(MODELS[model]).load_weights(golden_weights_path(model, tmp_path, obj_bias=float(g["obj_bias"])))
+    names = [str(n) for n in g["names"]]
+    assert names and all(n.startswith("crop") for n in names)
+    for name in names:
+        frame = bench_regime_frame(name, dim)
+        assert frame.shape == (dim, dim, 3)
+        out = net.forward(torch.from_numpy(orc.frames_to_input([frame])))
+        for tag in ("a", "b"):
+            pth, ith = g[tag + "_thresholds"]
+            res = orc.postprocess(out["bbox_xywh"].numpy(), out["class_prob"].numpy(), out["class_idx"].numpy(),
+                                  [frame.shape], float(pth), float(ith), audit=True)
+            ndiff, nbad, _ = compare_detections(g, "%s_%s_" % (name, tag), res[0][:3], rows=res[0][3])
+            assert ndiff == 0 and nbad == 0

@@ -24,6 +24,8 @@ Golden sets:
   G7 inference_<model>.npz    inference() end-to-end lists + fragility audit
   G7' inference_bench_regime_<model>.npz  inference() at the benchmarked regime (obj_bias -8.5) on all nine sample images
                                + audited-clean procedural frames (exact identity, no exemption)
+  G7c inference_crops_<model>.npz  the same records on NET-SIZED centre crops of the sample images (416^2: eight images;
+                               608^2: the one 640 x 640 image): end-to-end fixtures that pass through no resize at all
   G9 coco_export.json         to_coco() and devtools.coco_util.match_ids() on a small detection set
 """
 import hashlib
@@ -291,6 +293,7 @@ def g7_inference(model, net):
 # bench.py's regime: a few hundred candidates and tens of kept boxes per frame (the dense goldens above: ~10 k candidates);
 # yolov3-tiny's procedural weights reach that regime at -5.0 (at -8.5 nothing passes the threshold on these images)
 BENCH_OBJ_BIAS = {"yolov3": -8.5, "yolov3-spp": -8.5, "yolov3-tiny": -5.0}
+CROP_OBJ_BIAS = {"yolov3-tiny": -5.0, "yolov3": -6.5}     # G7c (at -8.5 the one 608^2 crop has no candidate at all)
 SAMPLE_IMAGES = ["000000035279.jpg", "000000078170.jpg", "000000229358.jpg", "000000253835.jpg", "000000377368.jpg",
                  "000000393569.jpg", "000000410880.jpg", "000000529762.jpg", "000000547336.jpg"]
 DIST_PX = 2e-3             # a candidate closer than this to an integer pixel may truncate differently under a 1-ulp forward difference
@@ -318,7 +321,17 @@ def nms_iou_margin(tlbr, prob, cls, thr):
     return best
 
 
-def g7p_bench_regime(model, n_synth_search=60, n_synth_keep=4):
+def center_crop(frame, dim):
+    """dim x dim centre crop of a frame at least that large (None otherwise): a NET-SIZED real image, so that the
+    reference's inference() skips cv2.resize (inference.py:322-326) and nothing of this build stands in for OpenCV."""
+    h, w = frame.shape[:2]
+    if h < dim or w < dim:
+        return None
+    y0, x0 = (h - dim) // 2, (w - dim) // 2
+    return np.ascontiguousarray(frame[y0:y0 + dim, x0:x0 + dim])
+
+
+def g7p_bench_regime(model, n_synth_search=60, n_synth_keep=4, crops=False):
     """The reference's inference() at the BENCHMARKED regime (obj_bias -8.5) on all nine sample_dataset images
     (/root/reference/tests/test_inference.py:51-59 runs them one at a time; here one call each as well), plus a search
     over procedural net-sized frames for AUDITED-CLEAN ones: every candidate at least DIST_PX from an integer pixel in all
@@ -326,7 +339,8 @@ def g7p_bench_regime(model, n_synth_search=60, n_synth_keep=4):
     CLS_MARGIN.  On a clean frame a correct float32 implementation must return the identical detections -- rows, classes,
     integer boxes -- with no exemption; the other frames carry the same candidate audit as G7."""
     dim = MODELS[model]["dim"]
-    net = make_net(model, obj_bias=BENCH_OBJ_BIAS[model])
+    obj_bias = CROP_OBJ_BIAS[model] if crops else BENCH_OBJ_BIAS[model]
+    net = make_net(model, obj_bias=obj_bias)
     arrays = {}
     names = []
     clean_names = []
@@ -374,11 +388,30 @@ def g7p_bench_regime(model, n_synth_search=60, n_synth_keep=4):
             all_clean = all_clean and clean
         return out, all_clean, resized
 
-    for jpg in SAMPLE_IMAGES:
-        name = "img" + jpg[6:12]
-        out, _, _ = record(name, load_jpeg_bgr(jpg))
-        arrays.update(out)
-        names.append(name)
+    if crops:
+        # G7c: the same records on net-sized centre crops of the sample images: no resize anywhere in the chain (the stub
+        # that stands in for cv2.resize raises if the reference calls it)
+        def no_resize(*a, **k):
+            raise AssertionError("cv2.resize called on a net-sized frame")
+        saved, cv2.resize = cv2.resize, no_resize
+        try:
+            for jpg in SAMPLE_IMAGES:
+                frame = center_crop(load_jpeg_bgr(jpg), dim)
+                if frame is None:
+                    continue
+                name = "crop" + jpg[6:12]
+                out, _, _ = record(name, frame)
+                arrays.update(out)
+                names.append(name)
+        finally:
+            cv2.resize = saved
+        n_synth_search = 0
+    else:
+        for jpg in SAMPLE_IMAGES:
+            name = "img" + jpg[6:12]
+            out, _, _ = record(name, load_jpeg_bgr(jpg))
+            arrays.update(out)
+            names.append(name)
     found = 0
     for seed in range(1000, 1000 + n_synth_search):
         frame = SD.synth_frames(seed, 1, dim, dim)[0]
@@ -395,8 +428,8 @@ def g7p_bench_regime(model, n_synth_search=60, n_synth_keep=4):
     arrays["names"] = np.array(names)
     arrays["a_thresholds"] = np.array([0.05, 0.3])
     arrays["b_thresholds"] = np.array([0.2, 0.3])
-    arrays["obj_bias"] = np.array(BENCH_OBJ_BIAS[model])
-    np.savez_compressed(os.path.join(GOLD, "inference_bench_regime_%s.npz" % model), **arrays)
+    arrays["obj_bias"] = np.array(obj_bias)
+    np.savez_compressed(os.path.join(GOLD, ("inference_crops_%s.npz" if crops else "inference_bench_regime_%s.npz") % model), **arrays)
     for row in summary:
         if row[0] in names:
             print("G7'", model, "%-10s %s candidates %4d kept %3d fragile %3d clean %s" % row)
@@ -486,6 +519,9 @@ if __name__ == "__main__":
     if "g7p" in which:
         for model in MODELS:
             g7p_bench_regime(model)
+    if "g7c" in which:
+        for model in ("yolov3-tiny", "yolov3"):
+            g7p_bench_regime(model, crops=True)
     if "g5" in which or "g7" in which:
         for model in MODELS:
             net = make_net(model)
