@@ -577,10 +577,47 @@ def bf16_agreement(dev):
             keep_set_jaccard=round(common / max(union, 1), 4), ideal_bf16_jaccard=floors2["all_" + tag]["jaccard"], kept=kept,
             reference_kept=ref_kept, score_abs_diff=dict(median=float(np.median(dps)), p99=float(np.percentile(dps, 99)), max=float(dps.max())))
     out["bench_regime"] = regime
+    # PLANTED parameters (tools/make_planted.py): the procedural backbone with a 19 x 19 head fitted on the nine sample images
+    # so that each has a handful of confident detections with margins (kept scores >= 0.6, class margins ~1, everything else
+    # below 0.01) -- the regime real weights are in.  Reference lists: tests/golden/inference_planted_yolov3.npz.
+    g3 = np.load(os.path.join(gdir, "inference_planted_yolov3.npz"))
+    with open(os.path.join(gdir, "bf16_agreement.json")) as fh:
+        floors3 = json.load(fh)["planted"]["yolov3"]
+    net.set_params(W.planted_params(net.blocks, net.net_info))
+    planted = {"frames": len(g3["names"])}
+    from yolov3.preprocess import resize_bilinear_u8
+    for tag in ("a", "b"):
+        pth, ith = g3[tag + "_thresholds"]
+        common = union = kept = ref_kept = same_cls = box_max = 0
+        dps = []
+        for name in (str(n) for n in g3["names"]):
+            frame = resize_bilinear_u8(jpeg("000000%s.jpg" % name), 608, 608)
+            res = yolov3.inference(net, frame, device=str(dev), prob_thresh=float(pth), nms_iou_thresh=float(ith), return_rows=True)[0]
+            key = "%s_%s_" % (name, tag)
+            want = g3[key + "rows"].tolist()
+            ref_by_row = {r: k for k, r in enumerate(want)}
+            rows = [int(r) for r in res[3]]
+            common += len(set(rows) & set(want))
+            union += len(set(rows) | set(want))
+            kept += len(rows)
+            ref_kept += len(want)
+            for k, r in enumerate(rows):
+                if r in ref_by_row:
+                    j = ref_by_row[r]
+                    same_cls += int(int(res[2][k]) == int(g3[key + "cls"][j]))
+                    dps.append(abs(float(res[1][k]) - float(g3[key + "prob"][j])))
+                    box_max = max(box_max, int(np.abs(res[0][k] - g3[key + "tlbr"][j]).max()))
+        dps = np.array(dps) if dps else np.zeros(1)
+        planted["thr_%.2f_iou_%.1f" % (pth, ith)] = dict(
+            keep_set_jaccard=round(common / max(union, 1), 4), ideal_bf16_jaccard=floors3["all_" + tag]["jaccard"], kept=kept,
+            reference_kept=ref_kept, common=common, same_class_on_common=same_cls, box_abs_diff_px_max=box_max,
+            score_abs_diff=dict(median=float(np.median(dps)), p99=float(np.percentile(dps, 99)), max=float(dps.max())))
+    out["planted"] = planted
     out["note"] = ("yolov3 608 bf16 HIP path vs the reference's float32 inference() on 3 golden frames, procedural weights "
                    "(thousands of overlapping near-threshold boxes per frame); ideal_bf16_jaccard = the bf16-emulating "
                    "oracle on the same frames (tests/golden/bf16_agreement.json); bench_regime = the same at the objectness "
-                   "bias the throughput is measured at, pooled over the nine sample images + procedural frames")
+                   "bias the throughput is measured at, pooled over the nine sample images + procedural frames; planted = a fitted "
+                   "head that gives every sample image a handful of confident detections with margins (tools/make_planted.py)")
     return out
 
 

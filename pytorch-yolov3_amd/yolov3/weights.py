@@ -232,3 +232,33 @@ def synth_params(blocks, net_info, seed=0, obj_bias=-3.0, calib=None,
             entry["bias"] = bias
         params.append(entry)
     return params
+
+
+# --------------------------------------------------------------------------
+# "planted" parameters: detections with margins (tools/make_planted.py)
+# --------------------------------------------------------------------------
+
+def install_planted_head(blocks, params, head_weight, head_bias):
+    """Replace the FIRST detection head's conv (the block before the first [yolo]) of ``params`` by the given
+    (Cout, Cin) weight / (Cout,) bias; returns ``params``."""
+    first_yolo = next(i for i, b in enumerate(blocks) if b["type"] == "yolo")
+    entry = next(p for p in params if p["block_idx"] == first_yolo - 1)
+    if entry["weight"].shape[:2] != head_weight.shape or "bias" not in entry:
+        raise ValueError("planted head does not fit block {}".format(first_yolo - 1))
+    entry["weight"] = np.ascontiguousarray(head_weight, dtype=np.float32).reshape(entry["weight"].shape)
+    entry["bias"] = np.ascontiguousarray(head_bias, dtype=np.float32)
+    return params
+
+
+def planted_params(blocks, net_info, model="yolov3", seed=0):
+    """The procedural backbone with a FITTED 19 x 19 detection head (``planted_<model>.npz`` next to this file, made by
+    tools/make_planted.py) and silent other heads: on the nine sample images (resized to the network's size) it returns a
+    handful of confident, well-separated detections per image -- kept scores far from any threshold, class margins near
+    one -- instead of the procedural heads' thousands of near-threshold boxes.  The fixture for "does bf16 keep real
+    detections" (tests/golden/inference_planted_<model>.npz holds the reference's float32 lists)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "planted_%s.npz" % model)
+    with np.load(path) as z:
+        head_w, head_b, silent = z["head_weight"], z["head_bias"], float(z["silent_obj_bias"])
+    params = synth_params(blocks, net_info, seed=seed, obj_bias=silent, calib=load_calibration(model))
+    return install_planted_head(blocks, params, head_w, head_b)

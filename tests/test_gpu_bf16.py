@@ -352,3 +352,47 @@ def test_bf16_post_nms_agreement_at_the_bench_regime(model):
             assert (union - common) <= (fl["union"] - fl["common"]) + 4
         assert np.median(dps) <= 1e-2 and dps.max() <= 6e-2
         assert not cls_ok or np.mean(cls_ok) >= 0.98
+
+
+def test_bf16_keeps_planted_detections():
+    """bf16 in a regime WITH margins.  The planted parameter set (tools/make_planted.py: procedural
+    backbone, 19 x 19 head fitted so that each of the nine sample images has seven or eight confident detections -- kept scores
+    >= 0.6, class margins ~1, every other box below 0.01) through the bf16 HIP path against the reference's float32
+    ``inference()`` lists: the keep set must be the reference's (Jaccard >= 0.95 pooled, and within 0.02 of what the
+    bf16-emulating oracle reaches: 1.0), classes identical on common rows, boxes within a few pixels (measured: 4).  Scores: the fitted
+    head's objectness rows have norm ~200 and amplify the bf16 error of their input features forty-fold (tools/make_planted.py),
+    so kept scores (>= 0.92 in float32) may move by up to 0.1 -- a pessimistic bound, asserted as such.  The float32 HIP path
+    on the same parameters must reproduce the lists exactly."""
+    from yolov3 import weights as W
+    g = np.load(os.path.join(GOLDEN, "inference_planted_yolov3.npz"))
+    floors = bf16_agreement()["planted"]["yolov3"]
+    for dtype in ("float32", "bf16"):
+        net = yolov3.Darknet(MODELS["yolov3"], device="cuda", dtype=dtype).eval()
+        net.set_params(W.planted_params(net.blocks, net.net_info))
+        for tag in ("a", "b"):
+            pth, ith = g[tag + "_thresholds"]
+            common = union = same_cls = 0
+            dps, dbox = [], []
+            for name in (str(n) for n in g["names"]):
+                frame = resize_bilinear_u8(load_jpeg_bgr("000000%s.jpg" % name), 608, 608)
+                res = yolov3.inference(net, frame, device="cuda", prob_thresh=float(pth), nms_iou_thresh=float(ith), return_rows=True)[0]
+                key = "%s_%s_" % (name, tag)
+                gi = {int(r): k for k, r in enumerate(g[key + "rows"])}
+                rows = [int(r) for r in res[3]]
+                common += len(set(rows) & set(gi))
+                union += len(set(rows) | set(gi))
+                for k, r in enumerate(rows):
+                    if r in gi:
+                        same_cls += int(int(res[2][k]) == int(g[key + "cls"][gi[r]]))
+                        dps.append(abs(float(res[1][k]) - float(g[key + "prob"][gi[r]])))
+                        dbox.append(int(np.abs(res[0][k] - g[key + "tlbr"][gi[r]]).max()))
+            jac = common / max(union, 1)
+            fl = floors["all_" + tag]
+            print("planted %s %s: keep-set Jaccard %.4f (ideal bf16 %.4f), %d common of %d, classes equal on %d, score |d| max %.2e, "
+                  "box |d| max %d px" % (dtype, tag, jac, fl["jaccard"], common, union, same_cls, max(dps), max(dbox)))
+            assert same_cls == common
+            if dtype == "float32":
+                assert jac == 1.0 and max(dps) <= 1e-3 and max(dbox) <= 1
+            else:
+                assert jac >= 0.95 and jac >= fl["jaccard"] - 0.02
+                assert max(dps) <= 0.1 and max(dbox) <= 6          # boxes of up to 400 px: 1.5 %

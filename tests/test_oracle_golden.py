@@ -268,3 +268,40 @@ def test_inference_net_sized_crop_goldens(model, tmp_path):
                                   [frame.shape], float(pth), float(ith), audit=True)
             ndiff, nbad, _ = compare_detections(g, "%s_%s_" % (name, tag), res[0][:3], rows=res[0][3])
             assert ndiff == 0 and nbad == 0
+
+
+def test_planted_parameter_goldens():
+    """The planted parameter set (tools/make_planted.py; pytorch-yolov3_amd/yolov3/planted_yolov3.npz): the reference's
+    inference() lists on the sample images -- seven or eight confident (score >= 0.92), well-separated detections each -- are reproduced
+    exactly by the float32 oracle (three of the nine frames: yolov3 on the CPU takes seconds per frame), and the fixture
+    has the margins it is there for."""
+    from golden_util import load_jpeg_bgr
+    from yolov3 import weights as W
+    from yolov3.cfgparse import parse_config
+    g = np.load(os.path.join(GOLDEN, "inference_planted_yolov3.npz"))
+    blocks, net_info = parse_config(MODELS["yolov3"])
+    net = orc.OracleDarknet(MODELS["yolov3"]).set_params(W.planted_params(blocks, net_info))
+    names = [str(n) for n in g["names"]]
+    assert len(names) == 9
+    for name in names:
+        for tag, thr in (("a", 0.05), ("b", 0.2)):
+            key = "%s_%s_" % (name, tag)
+            assert 5 <= len(g[key + "rows"]) <= 50
+            assert float(g[key + "prob"].min()) >= thr + 0.1                 # every kept score at least 0.1 above the threshold
+            assert float(g[key + "audit"][1]) >= 0.2                          # top-1 minus top-2 class score on kept boxes
+            assert int(g[key + "n_candidates"]) <= len(g[key + "rows"]) + 4   # nothing but the plants (and their twins) passes
+    for name in names[:3]:
+        frame = resize_bilinear_u8(load_jpeg_bgr("000000%s.jpg" % name), 608, 608)
+        out = net.forward(torch.from_numpy(orc.frames_to_input([frame])))
+        for tag in ("a", "b"):
+            pth, ith = g[tag + "_thresholds"]
+            det = orc.postprocess(out["bbox_xywh"].numpy(), out["class_prob"].numpy(), out["class_idx"].numpy(), [frame.shape],
+                                  float(pth), float(ith), audit=True)[0]
+            key = "%s_%s_" % (name, tag)
+            order, gorder = np.argsort(det[3]), np.argsort(g[key + "rows"])
+            assert np.array_equal(np.asarray(det[3])[order], g[key + "rows"][gorder])
+            assert np.array_equal(np.asarray(det[2])[order], g[key + "cls"][gorder])
+            assert np.array_equal(np.asarray(det[0])[order], g[key + "tlbr"][gorder])
+            # (the fitted head's rows have norms ~200: last-bit differences of the 1024 features between two float32 runs
+            # show in the fifth digit of a score; the parity bar is 1e-3)
+            np.testing.assert_allclose(np.asarray(det[1])[order], g[key + "prob"][gorder], atol=1e-4)

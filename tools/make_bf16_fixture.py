@@ -69,7 +69,50 @@ def bench_regime():
     return out
 
 
+def planted():
+    """Floors on the PLANTED parameter set (tools/make_planted.py: a fitted 19 x 19 head, a handful of confident detections per
+    sample image with margins): keep-set Jaccard of the bf16-emulating oracle against the reference's float32 lists, pooled
+    over the nine frames, and whether the classes agree on the common rows."""
+    from yolov3 import weights as W
+    from yolov3.cfgparse import parse_config
+    g = np.load(os.path.join(GOLDEN, "inference_planted_yolov3.npz"))
+    blocks, net_info = parse_config(MODELS["yolov3"])
+    net = orc.OracleDarknet(MODELS["yolov3"]).set_params(W.planted_params(blocks, net_info))
+    entry = {}
+    pool = {t: [0, 0, 0, 0] for t in ("a", "b")}
+    for name in (str(n) for n in g["names"]):
+        frame = resize_bilinear_u8(load_jpeg_bgr("000000%s.jpg" % name), 608, 608)
+        o = net.forward(torch.from_numpy(orc.frames_to_input([frame])), emulate_bf16=True, accumulate="f32")
+        for tag in ("a", "b"):
+            pth, ith = g[tag + "_thresholds"]
+            det = orc.postprocess(o["bbox_xywh"].numpy(), o["class_prob"].numpy(), o["class_idx"].numpy(), [frame.shape],
+                                  float(pth), float(ith), audit=True)[0]
+            key = "%s_%s" % (name, tag)
+            entry[key] = agreement(det, g, key + "_")
+            rows, want = [int(r) for r in det[3]], g[key + "_rows"].tolist()
+            gcls = dict(zip(want, g[key + "_cls"].tolist()))
+            same_cls = sum(1 for r, c in zip(rows, det[2]) if r in gcls and gcls[r] == int(c))
+            pool[tag][0] += len(set(rows) & set(want))
+            pool[tag][1] += len(set(rows) | set(want))
+            pool[tag][2] += same_cls
+            pool[tag][3] = max(pool[tag][3], len(want))
+            print("planted", key, entry[key])
+    for tag in ("a", "b"):
+        entry["all_" + tag] = dict(jaccard=round(pool[tag][0] / max(pool[tag][1], 1), 4), common=pool[tag][0], union=pool[tag][1],
+                                   same_class_on_common=pool[tag][2], most_kept_per_frame=pool[tag][3])
+        print("planted all", tag, entry["all_" + tag])
+    return entry
+
+
 def main():
+    path = os.path.join(GOLDEN, "bf16_agreement.json")
+    if sys.argv[1:] == ["planted"]:                    # only that section (the rest takes minutes)
+        with open(path) as fh:
+            table = json.load(fh)
+        table["planted"] = {"yolov3": planted()}
+        with open(path, "w") as fh:
+            json.dump(table, fh, indent=1, sort_keys=True)
+        return
     table = {}
     for model in ("yolov3-tiny", "yolov3", "yolov3-spp"):
         g = np.load(os.path.join(GOLDEN, "inference_%s.npz" % model))
@@ -94,6 +137,7 @@ def main():
                     print(model, acc, key, a)
         table[model] = entry
     table["bench_regime"] = bench_regime()
+    table["planted"] = {"yolov3": planted()}
     with open(os.path.join(GOLDEN, "bf16_agreement.json"), "w") as fh:
         json.dump(table, fh, indent=1, sort_keys=True)
 
