@@ -229,11 +229,12 @@ int y3_cxywh_to_tlbr(const int64_t *d_xywh, int64_t *d_tlbr, int n, int cols, vo
 int y3_resize_bilinear_u8(const uint8_t *d_src, int src_h, int src_w, uint8_t *d_dst, int dst_h, int dst_w,
                           const int32_t *d_ytab, const int32_t *d_xtab, void *stream);
 
-/* frames in / detections out without a copy engine (replaces the `.to(device)` / `.cpu()` transfers around
- * Darknet.forward, inference.py:335, :338-340): a small grid of `blocks` workgroups (<= 0: 32) moves `nbytes` bytes with
- * 16-byte accesses.  `src` or `dst` may be PINNED HOST memory, which the GPU addresses directly over PCIe; both must be
- * 16-byte aligned.  Unlike hipMemcpyAsync it needs no copy-engine hand-over on the stream, so batches in flight on other
- * streams keep the chip (measured: profiles/r03c_pcie_inclusive.txt). */
+/* frames in / detections out without a copy engine: what yolov3/pipeline.py (the loop bench.py times and detect_in_frames
+ * runs) uses in place of the `.to(device)` / `.cpu()` transfers around Darknet.forward (inference.py:335, :338-340).  A small
+ * grid of `blocks` workgroups (<= 0: 32) moves `nbytes` bytes with 16-byte accesses.  `src` or `dst` may be PINNED (registered)
+ * host memory, which the GPU addresses directly over PCIe; both must be 16-byte aligned, and a pointer the runtime does not
+ * know (pageable host memory) is rejected with Y3_ERR_INVALID.  Unlike hipMemcpyAsync it needs no copy-engine hand-over on
+ * the stream, so batches in flight on other streams keep the chip (measured: profiles/r03c_pcie_inclusive.txt). */
 int y3_copy_bytes(const void *src, void *dst, size_t nbytes, int blocks, void *stream);
 
 /* padded fixed-size detection records for the multi-GPU all-gather (no reference counterpart:

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -20,20 +21,27 @@ static y3_options g_y3_defaults = {/*auto_mask*/ (int32_t)Y3_AM_DEFAULT, /*unuse
                                    /*decode_lanes*/ 4, /*fuse_block*/ 0, {0, 0, 0, 0, 0}};
 static thread_local const y3_options *tl_y3_opt = nullptr;
 const y3_options &y3_opt() { return tl_y3_opt ? *tl_y3_opt : g_y3_defaults; }
+// y3_set_tuning("debug", v): exists in DIAGNOSTIC builds only (`make variant FLAGS=-DY3_X_...`, `make stamps`); the product
+// library rejects the key, so a benchmark line can never come from kernels that skip work
+#if defined(Y3_X_NOEPI) || defined(Y3_X_DEBUG) || defined(Y3_STAMPS)
+#define Y3_HAS_DEBUG_KEY 1
 static int g_y3_debug = 0;
 int y3_debug_flags() { return g_y3_debug; }
+#else
+int y3_debug_flags() { return 0; }
+#endif
 
 // CU count of the current device (256 on an MI355X; 256 as well when no device is visible: dry runs on a CPU box)
 int y3_device_cus() {
-  static int cus[32] = {};
+  static std::atomic<int> cus[32];                 // (zero-initialised; concurrent first calls store the same value)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) { (void)hipGetLastError(); return 256; }
-  if (cus[dev] == 0) {
-    int n = 0;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
-    cus[dev] = n;
+    cus[dev].store(n, std::memory_order_relaxed);
   }
-  return cus[dev];
+  return n;
 }
 namespace {
 struct OptScope {   // the launchers called below this frame see the plan's options
@@ -411,7 +419,9 @@ int y3_set_tuning(const char *key, int value) {
       {"fuse_block", &g_y3_defaults.fuse_block}};
   for (auto &f : fields)
     if (!strcmp(key, f.name)) { *f.field = value; return Y3_OK; }
-  if (!strcmp(key, "debug")) { g_y3_debug = value; return Y3_OK; }   // read by diagnostic builds only
+#ifdef Y3_HAS_DEBUG_KEY
+  if (!strcmp(key, "debug")) { g_y3_debug = value; return Y3_OK; }
+#endif
   y3_set_error("y3_set_tuning: unknown key %s", key);
   return Y3_ERR_INVALID;
 }

@@ -895,9 +895,9 @@ void fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
 // This is the LATENCY choice (one batch at a time: inference(), the video loop).  With several batches in flight on
 // their own streams (bench.py) the idle CUs of a short last round are filled by the other batches' kernels anyway and
 // what counts is CU time, which smaller tiles raise (the ~11 k cycles per tile are paid 248 instead of 184 times):
-// 2.3 % fewer frames/s end to end.  Such callers set auto_mask bit 9 (256-pixel tiles only) in their plan options.
+// 2.3 % fewer frames/s end to end.  Such callers set Y3_AM_HALO_TILE256 (256-pixel tiles only) in their plan options.
 static int halo_tile_fragments(int M, int n_tiles, int nchunks, int n_cu) {
-  if (y3_opt().auto_mask & 512) return 4;
+  if ((unsigned)y3_opt().auto_mask & Y3_AM_HALO_TILE256) return 4;
   double best = 0;
   int best_mi = 4;
   for (int mi = 4; mi >= 3; --mi) {

@@ -1031,7 +1031,7 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
   // ... and shrinks while the grid would leave most CUs without a workgroup (small maps / small batches: 13^2 x 8 frames
   // of yolov3-tiny has 11 pixel tiles; 128-channel tiles of its 512 -> 1024 layer are 88 workgroups on 256 CUs, two per
   // CU resident).  Narrower tiles re-read the (small) activation tile more often and keep the weight bytes per FLOP.
-  if (version == 2 && !(op.flags & Y3_F_OUT_F32) && !(y3_opt().auto_mask & 1024)) {
+  if (version == 2 && !(op.flags & Y3_F_OUT_F32) && !((unsigned)y3_opt().auto_mask & Y3_AM_NO_BN_SHRINK)) {
     const long long m_tiles = y3_ceil_div(a.M, 128);
     while (bn > 32 && m_tiles * y3_ceil_div(op.out_c, bn) < y3_device_cus()) bn >>= 1;   // 362 / 368 workgroups at 128 measured faster than twice as many at 64
   }

@@ -4,6 +4,7 @@
 // (in_ld / out_ld) so producers write straight into route-concat buffers
 // (/root/reference/yolov3/darknet.py:369-375) and no concat copy is needed on the usual path.
 #include "common.h"
+#include <initializer_list>
 
 namespace {
 
@@ -402,6 +403,17 @@ extern "C" int y3_copy_bytes(const void *src, void *dst, size_t nbytes, int bloc
   Y3_REQUIRE(src && dst, "y3_copy_bytes: null pointer argument");
   Y3_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "y3_copy_bytes: buffers must be 16-byte aligned");
   if (nbytes == 0) return Y3_OK;
+  // a pageable host pointer would be a GPU memory fault inside the kernel, not an error code: both ends must be device
+  // memory or pinned / registered host memory (what the runtime knows an address for)
+  for (const void *ptr : {src, static_cast<const void *>(dst)}) {
+    hipPointerAttribute_t attr;
+    const hipError_t e = hipPointerGetAttributes(&attr, ptr);
+    if (e != hipSuccess || attr.type == hipMemoryTypeUnregistered) {
+      (void)hipGetLastError();
+      y3_set_error("y3_copy_bytes: %p is neither device memory nor pinned (registered) host memory", ptr);
+      return Y3_ERR_INVALID;
+    }
+  }
   if (blocks < 1) blocks = 32;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(copy_bytes_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
