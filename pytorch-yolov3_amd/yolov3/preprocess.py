@@ -20,7 +20,7 @@ and the 8-bit specialisation of ``VResizeLinear``; IPP is not used for 8-bit lin
 PARITY against OpenCV ITSELF is unpinned for this function (no cv2 in this image: INTEGRATION.md).  What is pinned
 (tests/test_resize_pin.py): host (:func:`resize_bilinear_u8`) and device (``y3_resize_bilinear_u8``) are within 1 LSB on
 every byte -- 88-91 % of the bytes equal -- of an independent float bilinear with the same conventions
-(oracle/resize_oracle.py: ``torch.nn.functional.interpolate``) on the nine sample images, up- and down-scaling, and
+(``torch.nn.functional.interpolate``, kept with the test infrastructure) on the nine sample images, up- and down-scaling, and
 bit-identical to each other; net-sized frames -- the benchmark's case, and the crop goldens tests/golden/inference_crops_* --
 skip the resize exactly like the reference does (inference.py:322-326).
 Like the reference, ``dsize`` is passed as ``(net_h, net_w)`` although cv2 reads it as (width, height): for the
