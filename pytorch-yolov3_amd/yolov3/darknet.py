@@ -130,6 +130,7 @@ class Darknet(object):
         """Device weights and compiled plans hold addresses on the old device: drop them when the device changes
         (they are rebuilt lazily by the next forward)."""
         if str(device) != str(self.device):
+            self.__dict__.pop("_pipelines", None)
             self._dev_weights = {}
             for plan in self._plans.values():
                 plan.destroy()
@@ -168,6 +169,7 @@ class Darknet(object):
         if len(params) != len(self._convs):
             raise ValueError("expected {} conv parameter sets, got {}".format(len(self._convs), len(params)))
         self._params = params
+        self.__dict__.pop("_pipelines", None)      # (their plans hold the old weights' addresses)
         self._dev_weights = {}
         for plan in self._plans.values():
             plan.destroy()
@@ -237,7 +239,8 @@ class Darknet(object):
                 "Darknet.forward runs only on an MI355X GPU (device={!r}); call .cuda() -- this build "
                 "has no CPU execution path".format(self.device))
         _hip.require_gpu()
-        return torch.device(self.device)
+        dev = torch.device(self.device)
+        return dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
 
     def _compile(self, batch, height, width, input_mode, options=None):
         if self._params is None:
@@ -251,8 +254,14 @@ class Darknet(object):
         cp.batch = batch
         cp.rows_total = desc["rows_total"]
         cp.arena = torch.empty(desc["arena_bytes"], dtype=torch.uint8, device=dev)
-        if self._zero is None or self._zero.device != dev:
+        # The zero page (source of padding taps and tile tails in the conv kernels) must outlive every plan that holds its
+        # address: one per device index, and every plan keeps a reference.  (Until round 4 the test below compared
+        # ``cuda:0`` with ``cuda``, so EVERY compile made a new page and dropped the old one under the plans compiled before:
+        # once the allocator reused those 4 KiB, border pixels of the older plans read garbage.  Found by
+        # tests/test_gpu_pipeline.py, which is the first test to check outputs of several plans of one network.)
+        if self._zero is None or (self._zero.device.index or 0) != (dev.index if dev.index is not None else torch.cuda.current_device()):
             self._zero = torch.zeros(4096, dtype=torch.uint8, device=dev)
+        cp.keep.append(self._zero)
         base = cp.arena.data_ptr()
 
         def addr(t, elem):

@@ -27,8 +27,12 @@ class Pipeline(object):
 
     frames: a (batch, H, W, 3) uint8 BGR batch -- a PINNED torch tensor (uploaded straight from where it lies; fill
     ``host_frames(j)`` to get one), a device tensor (no upload), or anything else array-like (staged through a pinned buffer:
-    one extra host copy).  At most ``in_flight`` tickets are open at a time: submitting the ``in_flight + 1``-th reuses the
-    oldest ticket's buffers (its results must have been taken, or are dropped -- the benchmark does that on purpose).
+    one extra host copy).  ``in_flight`` batches run concurrently (streams, arenas); ``max_open`` = 2 x in_flight tickets may
+    be open, each with its own detector and record buffers, so that every stream always has its NEXT batch queued behind the
+    running one while the host is still reading an older batch's records (waiting for the oldest of only ``in_flight`` open
+    tickets before every submit costs 8-15 % of the rate: profiles/r04m_pipeline_depth.txt).  Submitting ticket
+    i + max_open reuses ticket i's buffers: its results must have been taken, or are dropped (the benchmark does that on
+    purpose).
     """
 
     def __init__(self, net, batch, height=None, width=None, in_flight=3, prob_thresh=0.05, nms_iou_thresh=0.3, kmax=512,
@@ -57,12 +61,13 @@ class Pipeline(object):
             plans = [net._get_plan(self.batch, self.height, self.width, "u8", slot=k, options=self.options)
                      for k in range(self.in_flight)]
             self.rows = plans[0].rows_total
-            self.dets = [Detector(self.batch, self.rows, dev) for _ in range(self.in_flight)]
+            self.max_open = 2 * self.in_flight
+            self.dets = [Detector(self.batch, self.rows, dev) for _ in range(self.max_open)]
             distributed = world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized())
             # one side stream for all gathers of this rank: every HIP stream needs a hardware queue of its own to overlap
             side = torch.cuda.Stream(device=dev) if distributed else None
             self.gathers = [DetectionGather(self.batch, self.rows, self.kmax, dev, world, group=group, side=side)
-                            for _ in range(self.in_flight)]
+                            for _ in range(self.max_open)]
             self.world = world
             # TWO device frame buffers per batch in flight: with one, the upload of ticket i could only start when the
             # forward of ticket i - in_flight (same stream, same buffer) had finished -- exactly when that stream was ready
@@ -76,14 +81,14 @@ class Pipeline(object):
             for e in self.free_ev + self.ready_ev:
                 e.record()
             self.host_rec = [torch.empty((world * self.batch, self.kmax, 8), dtype=torch.int32).pin_memory()
-                             for _ in range(self.in_flight)]
-            self.done_ev = [torch.cuda.Event() for _ in range(self.in_flight)]
+                             for _ in range(self.max_open)]
+            self.done_ev = [torch.cuda.Event() for _ in range(self.max_open)]
             self.full_hw = torch.tensor([[self.height, self.width]] * self.batch, dtype=torch.int32, device=dev)
             torch.cuda.synchronize(dev)
+        self.busy = False               # set by a caller that owns the pipeline for a while (stream.detect_in_frames)
         self._n = 0                     # tickets issued
         self._uploads = 0               # uploads issued (device frame buffer = uploads % nbuf)
-        self._fetched = [True] * self.in_flight
-        self._frames_in = [0] * self.in_flight
+        self._frames_in = [0] * self.max_open
 
     # ------------------------------------------------------------------ host buffers
     def host_frames(self, j):
@@ -108,7 +113,7 @@ class Pipeline(object):
         size (default: they are net-sized).  ``n_frames``: how many leading frames of the batch are real (a short last
         batch).  ``to_host=False`` leaves the records on the device (resident-rate measurements).  Returns the ticket."""
         i = self._n
-        k = i % self.in_flight
+        k, d = i % self.in_flight, i % self.max_open        # stream / arena of the batch; detector / record buffers of the ticket
         lib = _hip.lib()
         with torch.cuda.device(self.dev), torch.cuda.stream(self.streams[k]):
             cur = self.streams[k]
@@ -140,42 +145,42 @@ class Pipeline(object):
             out = self.net.forward_frames(fr, fresh=False, slot=k, options=self.options)
             if j is not None:
                 self.free_ev[j].record(cur)
-            det = self.dets[k]
+            det = self.dets[d]
             det.run(out, self.full_hw if orig_hw is None else orig_hw, self.prob_thresh, self.nms_iou_thresh)
-            g = self.gathers[k]
+            g = self.gathers[d]
             rec = g.run(det)
             if to_host:
                 if g.done is not None:
                     cur.wait_event(g.done)
-                _hip.check(lib.y3_copy_bytes(rec.data_ptr(), self.host_rec[k].data_ptr(), rec.numel() * rec.element_size(), 4,
+                _hip.check(lib.y3_copy_bytes(rec.data_ptr(), self.host_rec[d].data_ptr(), rec.numel() * rec.element_size(), 4,
                                              _hip.stream_ptr(cur)))
-            self.done_ev[k].record(cur)
-        self._fetched[k] = not to_host
-        self._frames_in[k] = self.batch if n_frames is None else int(n_frames)
+            self.done_ev[d].record(cur)
+        self._frames_in[d] = self.batch if n_frames is None else int(n_frames)
         self._n += 1
         return i
 
     def records(self, ticket):
         """Host records of all ranks for ``ticket``: (world * batch, kmax, 8) int32 (a view of the pinned buffer, valid
         until the ticket's slot is reused); waits for that batch only."""
-        if not (self._n - self.in_flight <= ticket < self._n):
-            raise ValueError("ticket {} is not open (open: {} .. {})".format(ticket, max(0, self._n - self.in_flight), self._n - 1))
-        k = ticket % self.in_flight
-        self.done_ev[k].synchronize()
-        return self.host_rec[k].numpy()
+        if not (self._n - self.max_open <= ticket < self._n):
+            raise ValueError("ticket {} is not open (open: {} .. {})".format(ticket, max(0, self._n - self.max_open), self._n - 1))
+        d = ticket % self.max_open
+        self.done_ev[d].synchronize()
+        return self.host_rec[d].numpy()
 
     def results(self, ticket, return_rows=False):
         """Per frame of THIS rank's batch: ``[bbox_tlbr int64 (K,4), class_prob f32 (K,), class_idx int64 (K,)]`` (+ prediction
         rows), the contract of ``inference()``.  A frame that kept more than ``kmax`` boxes is fetched again in full."""
         rec = self.records(ticket)
-        k = ticket % self.in_flight
+        k, d = ticket % self.in_flight, ticket % self.max_open
         mine = rec[:self.batch] if self.world == 1 else rec     # single rank: all frames are ours
         if self.world == 1 and mine.size and int(mine[:, 0, 7].max()) > self.kmax:
+            # (the ticket's detector buffers still hold the whole batch: they are reused max_open tickets later)
             with torch.cuda.device(self.dev), torch.cuda.stream(self.streams[k]):
-                full = self.dets[k].fetch(return_rows=return_rows, kmax=int(mine[:, 0, 7].max()))
-            return full[:self._frames_in[k]]
+                full = self.dets[d].fetch(return_rows=return_rows, kmax=int(mine[:, 0, 7].max()))
+            return full[:self._frames_in[d]]
         items = unpack_records(mine)
-        n = self._frames_in[k] if self.world == 1 else len(items)
+        n = self._frames_in[d] if self.world == 1 else len(items)
         return [item[:4] if return_rows else item[:3] for item in items[:n]]
 
     def synchronize(self):

@@ -88,9 +88,19 @@ def detect_in_frames(net, frames, batch_size=16, prob_thresh=0.05, nms_iou_thres
     state = {"pipe": None, "keep": {}, "filled": 0}
 
     def pipeline(batch):
+        # Pipelines are kept on the network (streams, pinned and device buffers, detector workspaces: ~50 ms to set up, half a
+        # second of video at the rate they run at) and handed to one generator at a time
         if state["pipe"] is None:
-            state["pipe"] = Pipeline(net, batch, height, width, in_flight=in_flight, prob_thresh=prob_thresh,
-                                     nms_iou_thresh=nms_iou_thresh, kmax=kmax)
+            cache = net.__dict__.setdefault("_pipelines", {})
+            key = (batch, height, width, in_flight, kmax, str(net.device), net.dtype)
+            pipe = cache.get(key)
+            if pipe is None or pipe.busy:
+                pipe = Pipeline(net, batch, height, width, in_flight=in_flight, kmax=kmax)
+                if key not in cache or not cache[key].busy:
+                    cache[key] = pipe
+            pipe.busy = True
+            pipe.prob_thresh, pipe.nms_iou_thresh = float(np.float32(prob_thresh)), float(nms_iou_thresh)
+            state["pipe"] = pipe
         return state["pipe"]
 
     def submit(batch):
@@ -119,7 +129,7 @@ def detect_in_frames(net, frames, batch_size=16, prob_thresh=0.05, nms_iou_thres
         pad = batch + [batch[-1]] * (pipe.batch - n)
         with torch.cuda.device(dev), torch.cuda.stream(pipe.streams[k]):
             dev_frames, shapes = prepare_frames_device(pad, height, width, dev, resize)
-        state["keep"][k] = dev_frames                         # alive until the slot is reused
+        state["keep"][pipe._n % pipe.max_open] = dev_frames    # alive until the ticket's buffers are reused
         orig_hw = np.array([[s[0], s[1]] for s in shapes], dtype=np.int32)
         return pipe.submit(dev_frames, orig_hw=orig_hw, n_frames=n)
 
@@ -140,14 +150,19 @@ def detect_in_frames(net, frames, batch_size=16, prob_thresh=0.05, nms_iou_thres
             yield group
 
     open_tickets = []
-    for batch in batches():
-        if len(open_tickets) == in_flight:                    # the slot this batch will take: its results first
-            for result in state["pipe"].results(open_tickets.pop(0)):
+    try:
+        for batch in batches():
+            if state["pipe"] is not None and len(open_tickets) == state["pipe"].max_open:   # the buffers this ticket will take
+                for result in state["pipe"].results(open_tickets.pop(0)):
+                    yield result
+            open_tickets.append(submit(batch))
+        for ticket in open_tickets:
+            for result in state["pipe"].results(ticket):
                 yield result
-        open_tickets.append(submit(batch))
-    for ticket in open_tickets:
-        for result in state["pipe"].results(ticket):
-            yield result
+    finally:
+        if state["pipe"] is not None:
+            state["pipe"].synchronize()                       # (a generator abandoned half way leaves nothing in flight)
+            state["pipe"].busy = False
 
 
 def detect_in_images(net, path, batch_size=16, prob_thresh=0.05, nms_iou_thresh=0.3):
