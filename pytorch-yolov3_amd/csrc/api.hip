@@ -23,7 +23,7 @@ static thread_local const y3_options *tl_y3_opt = nullptr;
 const y3_options &y3_opt() { return tl_y3_opt ? *tl_y3_opt : g_y3_defaults; }
 // y3_set_tuning("debug", v): exists in DIAGNOSTIC builds only (`make variant FLAGS=-DY3_X_...`, `make stamps`); the product
 // library rejects the key, so a benchmark line can never come from kernels that skip work
-#if defined(Y3_X_NOEPI) || defined(Y3_X_DEBUG) || defined(Y3_STAMPS)
+#if defined(Y3_X_NOEPI) || defined(Y3_X_S2BOUND) || defined(Y3_X_DEBUG) || defined(Y3_STAMPS)
 #define Y3_HAS_DEBUG_KEY 1
 static int g_y3_debug = 0;
 int y3_debug_flags() { return g_y3_debug; }

@@ -39,6 +39,8 @@ struct IgemmArgs {
   int k_ld, K;
   int n_ktiles, ktiles_per_tap, n_taps;
   int m_tiles, n_tiles;
+  int n_major;         // tile order: 0 = channel tiles innermost (an XCD walks all weight panels for a few pixel tiles),
+                       // 1 = pixel tiles innermost (an XCD owns a few weight panels): see igemm_tile_origin
   uint32_t mul_hw, sh_hw, mul_w, sh_w;   // n / d == (umulhi(n, mul) + n) >> sh  for n < 2^31 (d = HoWo, Wo)
   uint32_t flags;
   // detection-head fusion (conv_igemm2_kernel<..., DECODE = true>): the YOLO decode of yolo_decode.hip runs on the
@@ -111,8 +113,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / p.n_tiles) * BM;
-  const int n0 = (tile % p.n_tiles) * BN;
+  const int m0 = (p.n_major ? tile % p.m_tiles : tile / p.n_tiles) * BM;
+  const int n0 = (p.n_major ? tile / p.m_tiles : tile % p.n_tiles) * BN;
 
   // ---- loader set-up: thread owns LDS chunk slot (tid&7) of rows (tid>>3) + 32*i ------------
   const int slot = tid & 7;
@@ -178,7 +180,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
       const bool in_k = ke < p.K;
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
-        const bool ok = in_k && ((a_taps[i] >> tap) & 1u);
+        bool ok = in_k && ((a_taps[i] >> tap) & 1u);
+#ifdef Y3_X_S2BOUND
+        // timing-only bound for a staged-once stride-2 kernel (`make variant NAME=s2bound FLAGS=-DY3_X_S2BOUND`, debug = 1):
+        // only tap 0 of a stride-2 layer fetches pixels, the other eight read the zero page (results wrong)
+        if ((p.flags & 0x40000000u) && p.stride == 2 && tap != 0) ok = false;
+#endif
         const char *src = ok ? a_base[i] + tap_off : p.zero;
         a_reg[i] = *reinterpret_cast<const u32x4 *>(src);
       }
@@ -349,8 +356,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / p.n_tiles) * BM;
-  const int n0 = (tile % p.n_tiles) * BN;
+  const int m0 = (p.n_major ? tile % p.m_tiles : tile / p.n_tiles) * BM;
+  const int n0 = (p.n_major ? tile / p.m_tiles : tile % p.n_tiles) * BN;
 
   const int slot = tid % CPRW;
   const int row0 = tid / CPRW;
@@ -435,6 +442,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
     char *sB = sA + BM * RB;
     const char *src[A_CH];
     a_sources(kt, src);
+#ifdef Y3_X_S2BOUND
+    // debug = 2: the pixel loads of taps 1..8 are not even issued (this kernel waits vmcnt(0) per K-tile: any count is safe)
+    const bool skip_a = (p.flags & 0x80000000u) && p.stride == 2 && KMODE == 0 && (kt % p.n_taps) != 0;
+    if (!skip_a)
+#endif
 #pragma unroll
     for (int i = 0; i < A_CH; ++i)
       __builtin_amdgcn_global_load_lds((gbl_void *)src[i], (lds_void *)(sA + wave * 1024 + i * (NT * 16)), 16, 0, 0);
@@ -662,8 +674,8 @@ void conv_igemm3_kernel(IgemmArgs p) {
   Y3_STAMP_DECL
 
   const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / p.n_tiles) * BM;
-  const int n0 = (tile % p.n_tiles) * BN;
+  const int m0 = (p.n_major ? tile % p.m_tiles : tile / p.n_tiles) * BM;
+  const int n0 = (p.n_major ? tile / p.m_tiles : tile % p.n_tiles) * BN;
   const int n_kt = p.n_ktiles;
 
   typedef __attribute__((address_space(3))) void lds_void;
@@ -749,7 +761,12 @@ void conv_igemm3_kernel(IgemmArgs p) {
       char *sB = sA + BM * RB;
 #pragma unroll
       for (int i = 0; i < A_CH; ++i) {
-        const bool ok = in_k && ((a_taps[i] >> tap) & 1u);
+        bool ok = in_k && ((a_taps[i] >> tap) & 1u);
+#ifdef Y3_X_S2BOUND
+        // timing-only bound for a staged-once stride-2 kernel (`make variant NAME=s2bound FLAGS=-DY3_X_S2BOUND`, debug = 1):
+        // only tap 0 of a stride-2 layer fetches pixels, the other eight read the zero page (results wrong)
+        if ((p.flags & 0x40000000u) && p.stride == 2 && tap != 0) ok = false;
+#endif
         const char *src = ok ? a_base[i] + tap_off : p.zero;
         __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(sA + lwave * 1024 + i * (NC * 16)), 16, 0, 0);
       }
@@ -1020,7 +1037,13 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
   else a.n_ktiles = y3_ceil_div(a.K, bke);
   Y3_REQUIRE(a.n_ktiles * bke <= op.k_ld, "conv block %d: k_ld %d too small for %d K-tiles", op.block_idx, op.k_ld, a.n_ktiles);
   a.m_tiles = a.n_tiles = 0;
-  a.flags = op.flags;
+  // Each XCD gets one contiguous run of tile ids (y3_xcd_remap) and has its own L2.  Channel tiles innermost: the run covers a
+  // few pixel tiles x ALL channel tiles, so every XCD fetches the whole weight matrix and 1/8 of the activations; pixel
+  // tiles innermost: every XCD fetches all activations and 1/8 of the weights.  Whichever operand is bigger is the one to
+  // split (yolov3-tiny's 13^2 layers at batch 8: 18.9 MB of float32 weights against 2.8 MB of input -- 45 MB of traffic per
+  // launch for 16 MB algorithmic before this, profiles/r03_traffic.json).  Placement only: results do not change.
+  a.n_major = (double)op.out_c * a.K > (double)op.batch * op.in_h * op.in_w * op.in_c ? 1 : 0;
+  a.flags = op.flags | (y3_debug_flags() ? 0x40000000u : 0u) | (y3_debug_flags() == 2 ? 0x80000000u : 0u);
   Y3_REQUIRE((long long)op.batch * a.HoWo < (1ll << 31), "conv block %d: too many output pixels for the 32-bit tile index", op.block_idx);
   igemm_fast_div((uint32_t)a.HoWo, a.mul_hw, a.sh_hw);
   igemm_fast_div((uint32_t)a.Wo, a.mul_w, a.sh_w);
@@ -1128,6 +1151,7 @@ int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d
   // is parked in them), so two workgroups share a CU and one's decode runs under the other's loads (128-pixel tiles, one
   // per CU, measured equal in isolation: profiles/r02n_heads.txt)
   a.n_tiles = 1;
+  a.n_major = 0;
   a.m_tiles = y3_ceil_div(a.M, 64);
   hipLaunchKernelGGL((conv_igemm2_kernel<bf16_t, 64, 256, 1, 4, 0, true>), dim3(a.m_tiles), dim3(256), 0, s, a);
   Y3_HIP_CHECK(hipGetLastError());
