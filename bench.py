@@ -47,7 +47,7 @@ import torch  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "float32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA)
 MODEL_FLOPS_PER_FRAME = {("yolov3", 608): 140.692e9, ("yolov3-tiny", 416): 5.565e9, ("yolov3-spp", 608): 141.449e9}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
 
 
 def parse_args(argv=None):
