@@ -755,12 +755,13 @@ def main(argv=None):
             w2 = Workload(model, dim, batch, dtype, p, dev, 0, 1, args.kmax, nstream)
             steps = max(6, min(args.steps, 20 if dtype == "float32" else args.steps))
             e = w2.timed(steps, 3, False)
+            e_res = w2.timed(steps, 2, False, resident=True)      # rounds 1-3 reported this one
             rep = w2.kernel_report(2)
             f = batch * steps / e
             ff = MODEL_FLOPS_PER_FRAME.get((model, dim))
             others.append({"workload": "%s %dx%d batch=%d %s" % (model, dim, dim, batch, dtype), "value": round(f, 2),
                            "unit": "frames/s", "steps": steps, "ms_per_step": round(e / steps * 1e3, 4),
-                           "kept_per_frame": w2.kept_per_frame(),
+                           "resident": round(batch * steps / e_res, 2), "kept_per_frame": w2.kept_per_frame(),
                            "end_to_end_frac_of_peak": round(f * ff / 1e12 / PEAK_TFLOPS[dtype], 4) if ff else None,
                            "roofline": w2.roofline(rep, traffic_table)})
             del w2
