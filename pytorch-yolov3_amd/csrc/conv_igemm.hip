@@ -1085,6 +1085,21 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
     if (dry_run) return Y3_OK;
     return bf ? launch_cfg3<bf16_t, 128, 128, 2, 2>(a, kmode, ns, s) : launch_cfg3<float, 128, 128, 2, 2>(a, kmode, ns, s);
   }
+  // 96 x 64 tiles where they fit the chip in ONE round of equal workgroups and the tile above does not: yolov3-tiny's big
+  // float32 layers at batch 8 are 352 / 344 tiles of 128 x 32 on 256 CUs (the CUs that get two take twice as long: 39 % of
+  // the float32 MFMA peak) against 240 / 228 of 96 x 64, with twice the weight bytes reused per pixel fragment.  Same K order,
+  // same bits.  igemm_bm = 96 forces them (A/B), igemm_bm = 128 forbids them.
+  if (version == 2 && !(op.flags & Y3_F_OUT_F32) && op.out_c % 64 == 0 && bm_knob != 128 && bm_knob != 64) {
+    const int n_cu = y3_device_cus();
+    const long long t96 = (long long)y3_ceil_div(a.M, 96) * (op.out_c / 64);
+    const long long tcur = (long long)y3_ceil_div(a.M, 128) * y3_ceil_div(op.out_c, bn);
+    const bool pays = t96 <= n_cu && t96 * 4 >= n_cu * 3 && tcur > n_cu && tcur < 2 * n_cu && a.n_ktiles >= 32;
+    if (bm_knob == 96 || pays) {
+      *kernel_name = bf ? "conv_igemm2_bf16_96x64" : "conv_igemm2_f32_96x64";
+      if (dry_run) return Y3_OK;
+      return bf ? launch_cfg2<bf16_t, 96, 64, 2, 2>(a, kmode, s) : launch_cfg2<float, 96, 64, 2, 2>(a, kmode, s);
+    }
+  }
   if (bn == 128) {
     *kernel_name = bf ? "conv_igemm2_bf16_128x128" : "conv_igemm2_f32_128x128";
     if (dry_run) return Y3_OK;

@@ -442,12 +442,31 @@ def test_kernel_choice_does_not_change_a_bit(dtype):
     halo = _hip.AM_HALO_ALL | _hip.AM_NO_SMALL_GRID
     outs = []
     for opts in ({"auto_mask": _hip.AM_IGEMM_ONLY}, {"auto_mask": halo | _hip.AM_PATCH_WIDE}, {"auto_mask": halo | _hip.AM_HALO_TILE256},
-                 {"auto_mask": _hip.AM_IGEMM_ONLY, "igemm_version": 3, "igemm_ns": 3}, None):
+                 {"auto_mask": _hip.AM_IGEMM_ONLY, "igemm_version": 3, "igemm_ns": 3},
+                 {"auto_mask": _hip.AM_IGEMM_ONLY, "igemm_bm": 96},           # 96 x 64 tiles wherever Cout is a multiple of 64
+                 None):
         net = _net("yolov3", dtype=dtype, options=opts)
         outs.append({k: v.clone() for k, v in net.forward_frames(frames).items()})
     for o in outs[1:]:
         for k in ("bbox_xywh", "class_prob", "class_idx"):
             assert torch.equal(o[k], outs[0][k]), k
+
+
+@pytest.mark.parametrize("dtype", ["float32"])
+def test_96x64_tiles_are_chosen_for_yolov3_tiny_batch8_and_change_no_bit(dtype):
+    """BASELINE configs[1] (yolov3-tiny 416 batch 8): the two big layers (13^2 512 -> 1024, 26^2 384 -> 256) are 352 / 344 tiles of
+    128 x 32 on 256 CUs; the launcher picks 96 x 64 tiles (240 / 228, one round) for them -- and forbidding that choice
+    (igemm_bm = 128) gives the same bits."""
+    frames = synth_frames(41, 8, 416, 416)
+    a = _net("yolov3-tiny", dtype=dtype)
+    oa = {k: v.clone() for k, v in a.forward_frames(frames).items()}
+    names = [r["kernel"] for r in a.plan_report()]
+    assert sum("96x64" in n for n in names) >= 2, names
+    b = _net("yolov3-tiny", dtype=dtype, options={"igemm_bm": 128})
+    ob = b.forward_frames(frames)
+    assert not any("96x64" in r["kernel"] for r in b.plan_report())
+    for k in ("bbox_xywh", "class_prob", "class_idx"):
+        assert torch.equal(oa[k], ob[k]), k
 
 
 @pytest.mark.parametrize("dim,dtype", [(672, "float32"), (672, "bf16"), (1024, "bf16")])
