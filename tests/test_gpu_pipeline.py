@@ -142,3 +142,18 @@ def test_plans_compiled_back_to_back_keep_their_zero_page():
     for k in range(1, 4):
         for key in ("bbox_xywh", "class_prob", "class_idx"):
             assert torch.equal(outs[k][key], outs[0][key]), (k, key)
+
+
+def test_copy_bytes_rejects_pageable_host_memory():
+    """a pageable host pointer would be a GPU memory fault inside the copy kernel; y3_copy_bytes checks what the
+    runtime knows about both ends and returns Y3_ERR_INVALID instead."""
+    from yolov3 import _hip
+    lib = _hip.lib()
+    dst = torch.empty(4096, dtype=torch.uint8, device="cuda")
+    pageable = torch.zeros(4096, dtype=torch.uint8)
+    pinned = torch.arange(4096, dtype=torch.int32).to(torch.uint8).pin_memory()
+    assert lib.y3_copy_bytes(pageable.data_ptr(), dst.data_ptr(), 4096, 1, _hip.stream_ptr()) != 0
+    assert b"pinned" in lib.y3_last_error()
+    _hip.check(lib.y3_copy_bytes(pinned.data_ptr(), dst.data_ptr(), 4096, 1, _hip.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(dst.cpu(), pinned)
