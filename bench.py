@@ -635,7 +635,9 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # (Y3_BENCH_FORCE_LAUNCH=1: go through the launcher with one rank as well -- the only way to exercise it, RCCL included, on
+    # a box with one GPU: tests/test_callers.py)
+    if (args.gpus > 1 or os.environ.get("Y3_BENCH_FORCE_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
         return self_launch(args, argv)
     plumbing = os.environ.get("Y3_BENCH_PLUMBING")
     if plumbing and "WORLD_SIZE" in os.environ:
@@ -650,7 +652,7 @@ def main(argv=None):
     import torch.distributed as dist
     # Y3_BENCH_FORCE_DIST=1 (under torchrun with one process): run the RCCL plumbing -- init, barrier, all-gather,
     # all-reduce -- with a single rank, so the multi-GPU code path can be exercised on a one-GPU box
-    distributed = world > 1 or os.environ.get("Y3_BENCH_FORCE_DIST") == "1"
+    distributed = world > 1 or os.environ.get("Y3_BENCH_FORCE_DIST") == "1" or os.environ.get("Y3_BENCH_FORCE_LAUNCH") == "1"
     if torch.cuda.device_count() <= local_rank:
         sys.stderr.write("bench.py: rank %d needs GPU %d, %d visible\n" % (rank, local_rank, torch.cuda.device_count()))
         return 2

@@ -300,3 +300,25 @@ def test_cli_video_file_round_trip(tmp_path):
     with open(out_json) as fh:
         ds = json.load(fh)
     assert len(ds["images"]) == 5 and len(ds["annotations"]) == sum(len(r[1]) for r in want)
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_on_a_real_gpu():
+    """`python bench.py --gpus N` as the driver calls it, with the one GPU this box has (Y3_BENCH_FORCE_LAUNCH=1): the parent
+    counts devices without touching the GPU, starts the torchrun child job under its watchdog, the rank initialises RCCL, verifies
+    the ranks with a real all-gather, runs the pipelined steps with one all-gather per step, and the parent relays exactly one
+    JSON line (it arrives tee'd through torchrun's per-rank prefix: a 10-KiB line must survive that)."""
+    import subprocess
+    import sys
+    from golden_util import ROOT
+    env = dict(os.environ, Y3_BENCH_FORCE_LAUNCH="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--model", "yolov3-tiny", "--dim", "416",
+                           "--batch", "4", "--steps", "8", "--warmup", "3", "--no-cpu-baseline", "--launch-timeout", "400"],
+                          capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0, (proc.stdout[-1500:], proc.stderr[-2500:])
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["ranks_seen_by_collective"] == 1
+    assert "all_gather_into_tensor" in d["config"]["collective"] and len(d["per_rank"]["ms_per_step_by_rank"]) == 1
