@@ -89,6 +89,7 @@ class Pipeline(object):
         self._n = 0                     # tickets issued
         self._uploads = 0               # uploads issued (device frame buffer = uploads % nbuf)
         self._frames_in = [0] * self.max_open
+        self._on_host = [False] * self.max_open
 
     # ------------------------------------------------------------------ host buffers
     def host_frames(self, j):
@@ -128,6 +129,9 @@ class Pipeline(object):
                     self.ready_ev[j].synchronize()
                     host = self.host_frames(j)
                     src = frames if isinstance(frames, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frames))
+                    if src.dim() != 4 or src.shape[0] > self.batch:
+                        raise ValueError("expected at most {} frames of shape ({}, {}, 3), got {}".format(
+                            self.batch, self.height, self.width, tuple(src.shape)))
                     host[:src.shape[0]].copy_(src)
                 if tuple(host.shape[1:]) != (self.height, self.width, 3) or host.dtype != torch.uint8 or not host.is_contiguous():
                     raise ValueError("expected contiguous uint8 frames of shape (<= {}, {}, {}, 3)".format(self.batch, self.height, self.width))
@@ -156,6 +160,7 @@ class Pipeline(object):
                                              _hip.stream_ptr(cur)))
             self.done_ev[d].record(cur)
         self._frames_in[d] = self.batch if n_frames is None else int(n_frames)
+        self._on_host[d] = bool(to_host)
         self._n += 1
         return i
 
@@ -165,6 +170,8 @@ class Pipeline(object):
         if not (self._n - self.max_open <= ticket < self._n):
             raise ValueError("ticket {} is not open (open: {} .. {})".format(ticket, max(0, self._n - self.max_open), self._n - 1))
         d = ticket % self.max_open
+        if not self._on_host[d]:
+            raise ValueError("ticket {} was submitted with to_host=False: its records stayed on the device".format(ticket))
         self.done_ev[d].synchronize()
         return self.host_rec[d].numpy()
 
