@@ -157,3 +157,33 @@ def test_copy_bytes_rejects_pageable_host_memory():
     _hip.check(lib.y3_copy_bytes(pinned.data_ptr(), dst.data_ptr(), 4096, 1, _hip.stream_ptr()))
     torch.cuda.synchronize()
     assert torch.equal(dst.cpu(), pinned)
+
+
+def test_pipeline_is_deterministic_over_many_submits():
+    """Soak: 72 batches through three streams / six tickets, three different inputs in rotation, the host reading results as it
+    goes -- every occurrence of an input must give byte-identical records (a race between upload, forward, detection tail and
+    record download, or a plan reading memory it does not own, shows up as a difference between occurrences)."""
+    net = _net("yolov3-tiny", "bf16")
+    pipe = Pipeline(net, 8, in_flight=3, prob_thresh=0.05, nms_iou_thresh=0.3)
+    inputs = []
+    for j in range(3):
+        buf = pipe.host_frames(j)
+        buf.copy_(torch.from_numpy(synth_frames(500 + j, 8, 416, 416)))
+        inputs.append(buf)
+    first = {}
+    tickets = []
+
+    def take(t, j):
+        rec = pipe.records(t).copy()
+        if j in first:
+            assert np.array_equal(rec, first[j]), (t, j)
+        else:
+            first[j] = rec
+            assert int(rec[:, 0, 7].max()) > 0          # there are detections to compare
+    for i in range(72):
+        if len(tickets) == pipe.max_open:
+            take(*tickets.pop(0))
+        tickets.append((pipe.submit(inputs[i % 3]), i % 3))
+    for t, j in tickets:
+        take(t, j)
+    assert len(first) == 3 and not np.array_equal(first[0], first[1])
