@@ -22,6 +22,25 @@ from .dist import DetectionGather, unpack_records
 from .inference import Detector
 
 
+# HIP deals streams onto its hardware queues (GPU_MAX_HW_QUEUES, 8 here) in creation order and two streams on one queue run one
+# after the other, so streams are a per-device resource: every Pipeline of a device uses the SAME compute / copy / gather
+# streams (a second Pipeline with four streams of its own cost the first one 15 % -- and yolov3-tiny, whose kernels are short,
+# 20 %: profiles/r04m_pipeline_depth.txt).  Pipelines that are active at the same time then share streams: still correct
+# (everything is ordered by streams and events), just not concurrent with each other.
+_STREAMS = {}
+
+
+def _device_streams(dev, n_compute, want_side):
+    pool = _STREAMS.setdefault((dev.type, dev.index), {"compute": [], "copy": None, "side": None})
+    while len(pool["compute"]) < n_compute:
+        pool["compute"].append(torch.cuda.Stream(device=dev))
+    if pool["copy"] is None:
+        pool["copy"] = torch.cuda.Stream(device=dev)
+    if want_side and pool["side"] is None:
+        pool["side"] = torch.cuda.Stream(device=dev)
+    return pool["compute"][:n_compute], pool["copy"], pool["side"] if want_side else None
+
+
 class Pipeline(object):
     """``submit(frames)`` enqueues one batch and returns a ticket; ``results(ticket)`` waits for that batch only.
 
@@ -56,16 +75,14 @@ class Pipeline(object):
             options = base
         self.options = dict(options) if options else None
         with torch.cuda.device(dev):
-            self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.in_flight)]
-            self.copy_stream = torch.cuda.Stream(device=dev)
+            distributed = world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized())
+            # one side stream for all gathers of this rank: every HIP stream needs a hardware queue of its own to overlap
+            self.streams, self.copy_stream, side = _device_streams(dev, self.in_flight, distributed)
             plans = [net._get_plan(self.batch, self.height, self.width, "u8", slot=k, options=self.options)
                      for k in range(self.in_flight)]
             self.rows = plans[0].rows_total
             self.max_open = 2 * self.in_flight
             self.dets = [Detector(self.batch, self.rows, dev) for _ in range(self.max_open)]
-            distributed = world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized())
-            # one side stream for all gathers of this rank: every HIP stream needs a hardware queue of its own to overlap
-            side = torch.cuda.Stream(device=dev) if distributed else None
             self.gathers = [DetectionGather(self.batch, self.rows, self.kmax, dev, world, group=group, side=side)
                             for _ in range(self.max_open)]
             self.world = world
