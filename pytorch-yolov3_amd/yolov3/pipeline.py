@@ -125,6 +125,11 @@ class Pipeline(object):
             return True
         return ev.query()
 
+    def next_slot(self):
+        """(stream, ticket buffer index) the NEXT ``submit`` will use: callers that prepare device frames themselves (resize on the
+        GPU) do it on that stream and keep their tensor alive under that index until the buffers come round again."""
+        return self.streams[self._n % self.in_flight], self._n % self.max_open
+
     # ------------------------------------------------------------------ the pipelined step
     def submit(self, frames, orig_hw=None, n_frames=None, to_host=True):
         """Enqueue one batch.  ``orig_hw``: (batch, 2) original frame sizes when the frames were resized to the network's

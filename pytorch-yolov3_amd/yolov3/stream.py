@@ -125,11 +125,11 @@ def detect_in_frames(net, frames, batch_size=16, prob_thresh=0.05, nms_iou_thres
                 host[i] = f.numpy() if isinstance(f, torch.Tensor) else f
             return pipe.submit(pipe.host_frames(j), n_frames=n)
         # frames of other sizes: uploaded one by one and resized on the GPU, on the stream the pipeline will run the batch on
-        k = pipe._n % pipe.in_flight
+        stream, slot = pipe.next_slot()
         pad = batch + [batch[-1]] * (pipe.batch - n)
-        with torch.cuda.device(dev), torch.cuda.stream(pipe.streams[k]):
+        with torch.cuda.device(dev), torch.cuda.stream(stream):
             dev_frames, shapes = prepare_frames_device(pad, height, width, dev, resize)
-        state["keep"][pipe._n % pipe.max_open] = dev_frames    # alive until the ticket's buffers are reused
+        state["keep"][slot] = dev_frames                      # alive until the ticket's buffers are reused
         orig_hw = np.array([[s[0], s[1]] for s in shapes], dtype=np.int32)
         return pipe.submit(dev_frames, orig_hw=orig_hw, n_frames=n)
 
