@@ -42,6 +42,7 @@ struct HaloArgs {
   int k_ld;
   int nchunks;         // Cin / BKE
   int n_tiles;
+  int ngrp_w, m_tiles; // strip kernel's tile order: channel tiles in groups of ngrp_w, pixel tiles inside a group (see launch_halo_ws)
   int hr;              // halo rows that hold pixels (256 + 2W + 2); strip kernel: row `hr` of each buffer is all zero
   int hr_pad;          // halo rows, padded to a multiple of the loader's rows-per-pass
   int na;              // loader passes per halo (= glds per thread per halo)
@@ -129,8 +130,10 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
   const bool loader = wave >= NC / 64;
 
   const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / p.n_tiles) * BM;
-  const int n0 = (tile % p.n_tiles) * BN;
+  // linear order: channel-tile group (ngrp_w wide) outermost, then pixel tile, then channel tile inside the group
+  const int grp = tile / (p.m_tiles * p.ngrp_w), rem = tile - grp * (p.m_tiles * p.ngrp_w);
+  const int m0 = (rem / p.ngrp_w) * BM;
+  const int n0 = (grp * p.ngrp_w + rem % p.ngrp_w) * BN;
   const int nit = p.nchunks * 9;
 
   const int wm = (wave & 7) / WAVES_N, wn = (wave & 7) % WAVES_N;
@@ -945,7 +948,25 @@ int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
     if (lds <= 160 * 1024) { nsb = c; break; }
   }
   Y3_REQUIRE(nsb != 0, "wave-specialised halo kernel: row width %d does not fit", a.W);
-  const dim3 grid(y3_ceil_div(a.M, bm) * a.n_tiles);
+  a.m_tiles = y3_ceil_div(a.M, bm);
+  // Tile order and HBM traffic.  Each XCD (own L2) gets one contiguous run of tile ids.  With all channel tiles innermost
+  // (ngrp_w = n_tiles) a run covers a few pixel tiles x ALL weight panels: every XCD fetches the whole weight matrix -- fine
+  // while the input outweighs it (76^2, 38^2), 75 MB of extra fetches per launch at 19^2 (9.4 MB of weights, 5.9 MB of
+  // input).  With channel tiles in pn groups the XCDs split into pn sets of 8 / pn, each set owning one group's panels and
+  // all pixels: extra fetches ~ pn x input + (8 / pn) x weights; pick the pn (1, 2, 4, 8 dividing n_tiles) that minimises
+  // it.  Placement only: results and per-tile time do not change.
+  {
+    const double in_b = (double)a.M * a.Cin, w_b = 9.0 * a.Cin * a.Cout;
+    int best = 1;
+    double best_cost = 0;
+    for (int pn = 1; pn <= 8; pn <<= 1) {
+      if (a.n_tiles % pn) break;
+      const double cost = pn * in_b + (8.0 / pn) * w_b;
+      if (pn == 1 || cost < 0.9 * best_cost) { best = pn; best_cost = cost; }
+    }
+    a.ngrp_w = a.n_tiles / best;
+  }
+  const dim3 grid(a.m_tiles * a.n_tiles);
   if (mi == 3) {
     if (nsb == 4) hipLaunchKernelGGL((conv_halo_ws_kernel<T, 4, 3>), grid, dim3(768), lds, s, a);
     else hipLaunchKernelGGL((conv_halo_ws_kernel<T, 3, 3>), grid, dim3(768), lds, s, a);
@@ -1039,6 +1060,7 @@ int y3_launch_conv_patch(const y3_op &op, const void *d_in, const void *d_zero, 
   a.nchunks = op.in_c / (128 / es);
   a.n_tiles = op.out_c / 128;
   a.hr_pad = a.na = a.a_bytes = 0;
+  a.ngrp_w = a.n_tiles; a.m_tiles = 0;
   a.mul_hw = a.sh_hw = a.mul_w = a.sh_w = 0;
   a.flags = op.flags | (y3_debug_flags() ? 0x40000000u : 0u);
   return bf ? launch_patch_wsp<bf16_t>(a, s) : launch_patch_wsp<float>(a, s);
@@ -1068,6 +1090,7 @@ int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, h
   a.nchunks = op.in_c / (128 / es);
   a.n_tiles = op.out_c / 128;
   a.hr_pad = a.na = a.a_bytes = 0;
+  a.ngrp_w = a.n_tiles; a.m_tiles = 0;
   fast_div((uint32_t)a.HW, a.mul_hw, a.sh_hw);
   fast_div((uint32_t)a.W, a.mul_w, a.sh_w);
   a.flags = op.flags | (y3_debug_flags() ? 0x40000000u : 0u);
