@@ -191,7 +191,7 @@ __device__ __forceinline__ unsigned long long y3_now_real() {
 }
 #define Y3_CLK_BEGIN() unsigned long long _clk_r0 = 0; do { const unsigned long long _n = y3_now(); _st_acc[2] = _n - _st_prev; _st_prev = _n; _clk_r0 = y3_now_real(); } while (0)
 #define Y3_CLK_END() do { const unsigned long long _n = y3_now(); _st_acc[0] = _n - _st_prev; _st_prev = _n; _st_acc[1] = y3_now_real() - _clk_r0; } while (0)
-#define Y3_CLK_TAIL() do { if (threadIdx.x == 0) { _st_acc[3] = y3_now() - _st_prev; for (int _i = 0; _i < 4; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]); atomicAdd(&g_y3_stamps[7], 1ull); } } while (0)
+#define Y3_CLK_TAIL() do { if (threadIdx.x == 0) { _st_acc[3] = y3_now() - _st_prev; for (int _i = 0; _i < 4; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]); if (blockIdx.x < 256) { atomicAdd(&g_y3_stamps[4], _st_acc[2]); atomicAdd(&g_y3_stamps[5], 1000ull); atomicAdd(&g_y3_stamps[6], _st_acc[3]); } atomicAdd(&g_y3_stamps[7], 1ull); } } while (0)
 #else
 #define Y3_CLK_BEGIN() do {} while (0)
 #define Y3_CLK_END() do {} while (0)

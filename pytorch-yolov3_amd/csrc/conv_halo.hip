@@ -123,6 +123,13 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
   char *sB = smem;                                    // [NSB][BN][128]
   char *sA = smem + NSB * B_BYTES;                    // [2][hr_pad][128]
 
+#ifdef Y3_X_STAGGER
+  // timing experiment: every other first-round workgroup of an XCD starts half a tile period late, so that the CUs' prologues
+  // and epilogues (bursts of memory traffic) no longer coincide
+  if ((p.flags & 0x40000000u) && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+    __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   Y3_STAMP_DECL
   const int tid = threadIdx.x;
   const int lane = tid & 63;
