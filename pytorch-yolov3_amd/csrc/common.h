@@ -191,11 +191,20 @@ __device__ __forceinline__ unsigned long long y3_now_real() {
 }
 #define Y3_CLK_BEGIN() unsigned long long _clk_r0 = 0; do { const unsigned long long _n = y3_now(); _st_acc[2] = _n - _st_prev; _st_prev = _n; _clk_r0 = y3_now_real(); } while (0)
 #define Y3_CLK_END() do { const unsigned long long _n = y3_now(); _st_acc[0] = _n - _st_prev; _st_prev = _n; _st_acc[1] = y3_now_real() - _clk_r0; } while (0)
+#ifdef Y3_STAMPS_EPI
+// ... and the pieces of the epilogue in slots 4-6 (thread 0: K loop end -> first barrier -> tile parked -> written out)
+#define Y3_EPI(slot) do { const unsigned long long _n = y3_now(); _st_acc[slot] = _n - _st_prev; _st_prev = _n; } while (0)
+#define Y3_CLK_TAIL() do { if (threadIdx.x == 0) { _st_acc[3] = y3_now() - _st_prev; for (int _i = 0; _i < 7; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]); atomicAdd(&g_y3_stamps[7], 1ull); } } while (0)
+#else
+// slots 4-6: the first round of workgroups (blockIdx < 256) on its own: cycles before the loop, count x 1000, cycles after it
+#define Y3_EPI(slot) do {} while (0)
 #define Y3_CLK_TAIL() do { if (threadIdx.x == 0) { _st_acc[3] = y3_now() - _st_prev; for (int _i = 0; _i < 4; ++_i) atomicAdd(&g_y3_stamps[_i], _st_acc[_i]); if (blockIdx.x < 256) { atomicAdd(&g_y3_stamps[4], _st_acc[2]); atomicAdd(&g_y3_stamps[5], 1000ull); atomicAdd(&g_y3_stamps[6], _st_acc[3]); } atomicAdd(&g_y3_stamps[7], 1ull); } } while (0)
+#endif
 #else
 #define Y3_CLK_BEGIN() do {} while (0)
 #define Y3_CLK_END() do {} while (0)
 #define Y3_CLK_TAIL() do {} while (0)
+#define Y3_EPI(slot) do {} while (0)
 #endif
 
 // Y3_STAMPS_FINE (diagnostic): the ping-pong kernel stamps the pieces of its K-step instead of its phases

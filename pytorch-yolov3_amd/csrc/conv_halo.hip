@@ -520,9 +520,23 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
   const int co = n0 + oc_mine * 8;
   f32x4 sc_lo, sc_hi, bi_lo, bi_hi;
   u32x4 resv[WR];
-  // the epilogue's global reads go out first; a raw barrier (LDS reads drained, no vmcnt drain -- the loaders waited
-  // for their LDS-DMA themselves) lets them fly while the accumulators are parked
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();   // all operand reads and all LDS-DMA done: LDS can hold the output tile
+  Y3_EPI(4);
   if (!loader) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int cl = wn * 64 + ni * 16 + fq * 4;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int pl = wm * WM + mi * 16 + fr;
+        *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
+      }
+    }
+    // the epilogue's global reads go out AFTER the accumulators are on their way to LDS: eight waves x (4 + 8) 1-KiB loads
+    // keep the CU's address unit busy for ~1.5 k cycles, and issued before the barrier above (rounds 1-3: "so that they fly
+    // while the tile is parked") they held every wave back from it for that long (stamps: 1740 cycles from the end of the K
+    // loop to the barrier with a shortcut, 590 without); here the address unit and the LDS writes drain side by side
     sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
     sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
     bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
@@ -538,20 +552,8 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       }
     }
   }
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_s_barrier();   // all operand reads and all LDS-DMA done: LDS can hold the output tile
-  if (!loader) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int cl = wn * 64 + ni * 16 + fq * 4;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int pl = wm * WM + mi * 16 + fr;
-        *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
-      }
-    }
-  }
   __syncthreads();
+  Y3_EPI(5);
   if (loader) return;
 #pragma unroll
   for (int j = 0; j < WR; ++j) {

@@ -35,10 +35,12 @@ __global__ __launch_bounds__(256) void k(const char *src, size_t region, size_t 
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+static int g_blocks = 256;   // argv[1]: fewer blocks = only some CUs stream (8 per XCD with 64)
+
 template <int DEPTH>
 void run(const char *what, const char *src, size_t region, size_t xcd_stride, size_t blk_stride, int rowb, int pieces,
          unsigned long long *cyc, int reps) {
-  const int blocks = 256;
+  const int blocks = g_blocks;
   hipFuncSetAttribute(reinterpret_cast<const void *>(k<DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float ms = 0;
@@ -48,7 +50,7 @@ void run(const char *what, const char *src, size_t region, size_t xcd_stride, si
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
   }
-  unsigned long long h[256]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+  unsigned long long h[256]; hipMemcpy(h, cyc, blocks * 8, hipMemcpyDeviceToHost);
   double avg = 0; for (int i = 0; i < blocks; ++i) avg += h[i]; avg /= blocks;
   const double bytes_blk = (double)pieces * 4096.0;
   printf("%-34s depth %2d rowb %5d: %6.1f B/clk/CU (%5.0f cycles per 4-KiB piece), %6.2f TB/s aggregate (last of %d launches)\n",
@@ -67,7 +69,9 @@ void suite(const char *src, unsigned long long *cyc) {
   run<DEPTH>("HBM (2 GiB span, own 8 MiB)", src, 256 * MiB, 256 * MiB, 8 * MiB, 256, 1024, cyc, 2);
 }
 
-int main() {
+int main(int argc, char **argv) {
+  if (argc > 1) g_blocks = atoi(argv[1]);
+  printf("%d blocks\n", g_blocks);
   char *src; unsigned long long *cyc;
   const size_t total = (size_t)2 << 30;
   if (hipMalloc(&src, total + (1 << 20)) != hipSuccess) { printf("alloc failed\n"); return 1; }
