@@ -1,6 +1,6 @@
 # Same-box A/B of lib/libyolov3_hip_old.so (a build of an earlier tree) against the current library: parity subset, per-layer
 # conv_bench, clock stamps, end-to-end bench.py (three interleaved pairs).
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bf16.py -x -q 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_bf16.py -x -q 2>&1 | grep -E "^(FAILED|ERROR|E  )|passed|failed" | head -20
 bash tools/ab_lib.sh pytorch-yolov3_amd/lib/libyolov3_hip_old.so pytorch-yolov3_amd/lib/libyolov3_hip.so --only s76_128-256_k3,s38_256-512_k3,s19_512 --variants halo_ws_256 --rounds 5
 Y3_HIP_LIB=pytorch-yolov3_amd/lib/libyolov3_hip_stamps.so python tools/conv_bench.py --only s76_128-256_k3,s38_256-512_k3,s19_512 --variants halo_ws_256 --stamps 2>&1 | grep -v amdgpu
 for rep in 1 2 3; do for L in old new; do
