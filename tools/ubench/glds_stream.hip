@@ -35,18 +35,52 @@ __global__ __launch_bounds__(256) void k(const char *src, size_t region, size_t 
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-static int g_blocks = 256;   // argv[1]: fewer blocks = only some CUs stream (8 per XCD with 64)
+static int g_blocks = 256;
+static int g_vgpr = 0;      // argv[2] = 1: the register path (kv) instead of LDS-DMA (k)   // argv[1]: fewer blocks = only some CUs stream (8 per XCD with 64)
+
+// The same stream through the ordinary vector-memory path: global_load_dwordx4 into registers, DEPTH loads in flight per wave,
+// each followed by a ds_write_b128 (what a loader without LDS-DMA would do).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int DEPTH>
+__global__ __launch_bounds__(256) void kv(const char *src, size_t region, size_t xcd_stride, size_t blk_stride, int rowb,
+                                           int pieces, unsigned long long *cyc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const char *base = src + (size_t)xcd * xcd_stride;
+  const size_t lane_off = (size_t)(tid >> 3) * rowb + (tid & 7) * 16;
+  const size_t piece_b = (size_t)32 * rowb;
+  size_t off = ((size_t)idx * blk_stride) % region;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  u32x4 v[DEPTH];
+  for (int i = 0; i < pieces; i += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      v[d] = *reinterpret_cast<const u32x4 *>(base + off + lane_off);
+      off += piece_b;
+      if (off + piece_b > region) off = 0;
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) *reinterpret_cast<u32x4 *>(smem + tid * 16 + ((i + d) & 15) * 4096) = v[d];
+  }
+  __syncthreads();
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
 
 template <int DEPTH>
 void run(const char *what, const char *src, size_t region, size_t xcd_stride, size_t blk_stride, int rowb, int pieces,
          unsigned long long *cyc, int reps) {
   const int blocks = g_blocks;
   hipFuncSetAttribute(reinterpret_cast<const void *>(k<DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(kv<DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float ms = 0;
   for (int rep = 0; rep < reps; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<DEPTH>), dim3(blocks), dim3(256), 65536, 0, src, region, xcd_stride, blk_stride, rowb, pieces, cyc);
+    if (g_vgpr) hipLaunchKernelGGL((kv<DEPTH>), dim3(blocks), dim3(256), 65536, 0, src, region, xcd_stride, blk_stride, rowb, pieces, cyc);
+    else hipLaunchKernelGGL((k<DEPTH>), dim3(blocks), dim3(256), 65536, 0, src, region, xcd_stride, blk_stride, rowb, pieces, cyc);
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
   }
@@ -71,7 +105,8 @@ void suite(const char *src, unsigned long long *cyc) {
 
 int main(int argc, char **argv) {
   if (argc > 1) g_blocks = atoi(argv[1]);
-  printf("%d blocks\n", g_blocks);
+  if (argc > 2) g_vgpr = atoi(argv[2]);
+  printf("%d blocks, %s\n", g_blocks, g_vgpr ? "global_load_dwordx4 -> VGPR -> ds_write_b128" : "global_load_lds_dwordx4");
   char *src; unsigned long long *cyc;
   const size_t total = (size_t)2 << 30;
   if (hipMalloc(&src, total + (1 << 20)) != hipSuccess) { printf("alloc failed\n"); return 1; }
