@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k(const char *src, size_t region, size_t 
 }
 
 static int g_blocks = 256;
-static int g_vgpr = 0;      // argv[2] = 1: the register path (kv) instead of LDS-DMA (k)   // argv[1]: fewer blocks = only some CUs stream (8 per XCD with 64)
+static int g_vgpr = 0;      // argv[2] = 1: the register path (kv) instead of LDS-DMA (k); 2: both at once (kmix)   // argv[1]: fewer blocks = only some CUs stream (8 per XCD with 64)
 
 // The same stream through the ordinary vector-memory path: global_load_dwordx4 into registers, DEPTH loads in flight per wave,
 // each followed by a ds_write_b128 (what a loader without LDS-DMA would do).
@@ -69,17 +69,58 @@ __global__ __launch_bounds__(256) void kv(const char *src, size_t region, size_t
   if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// Both paths at once: waves 0-1 stream by LDS-DMA, waves 2-3 through registers (each pair moves half of every 4-KiB piece).
+template <int DEPTH>
+__global__ __launch_bounds__(256) void kmix(const char *src, size_t region, size_t xcd_stride, size_t blk_stride, int rowb,
+                                             int pieces, unsigned long long *cyc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const char *base = src + (size_t)xcd * xcd_stride;
+  const size_t lane_off = (size_t)(tid >> 3) * rowb + (tid & 7) * 16;
+  const size_t piece_b = (size_t)32 * rowb;
+  size_t off = ((size_t)idx * blk_stride) % region;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (wave < 2) {
+    for (int i = 0; i < pieces; ++i) {
+      __builtin_amdgcn_global_load_lds((gbl_void *)(base + off + lane_off), (lds_void *)(smem + wave * 1024 + (i & 15) * 4096), 16, 0, 0);
+      off += piece_b;
+      if (off + piece_b > region) off = 0;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    u32x4 v[DEPTH];
+    for (int i = 0; i < pieces; i += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        v[d] = *reinterpret_cast<const u32x4 *>(base + off + lane_off);
+        off += piece_b;
+        if (off + piece_b > region) off = 0;
+      }
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) *reinterpret_cast<u32x4 *>(smem + tid * 16 + ((i + d) & 15) * 4096) = v[d];
+    }
+  }
+  __syncthreads();
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 template <int DEPTH>
 void run(const char *what, const char *src, size_t region, size_t xcd_stride, size_t blk_stride, int rowb, int pieces,
          unsigned long long *cyc, int reps) {
   const int blocks = g_blocks;
   hipFuncSetAttribute(reinterpret_cast<const void *>(k<DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   hipFuncSetAttribute(reinterpret_cast<const void *>(kv<DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(kmix<DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float ms = 0;
   for (int rep = 0; rep < reps; ++rep) {
     hipEventRecord(e0);
-    if (g_vgpr) hipLaunchKernelGGL((kv<DEPTH>), dim3(blocks), dim3(256), 65536, 0, src, region, xcd_stride, blk_stride, rowb, pieces, cyc);
+    if (g_vgpr == 2) hipLaunchKernelGGL((kmix<DEPTH>), dim3(blocks), dim3(256), 65536, 0, src, region, xcd_stride, blk_stride, rowb, pieces, cyc);
+    else if (g_vgpr) hipLaunchKernelGGL((kv<DEPTH>), dim3(blocks), dim3(256), 65536, 0, src, region, xcd_stride, blk_stride, rowb, pieces, cyc);
     else hipLaunchKernelGGL((k<DEPTH>), dim3(blocks), dim3(256), 65536, 0, src, region, xcd_stride, blk_stride, rowb, pieces, cyc);
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
@@ -106,7 +147,7 @@ void suite(const char *src, unsigned long long *cyc) {
 int main(int argc, char **argv) {
   if (argc > 1) g_blocks = atoi(argv[1]);
   if (argc > 2) g_vgpr = atoi(argv[2]);
-  printf("%d blocks, %s\n", g_blocks, g_vgpr ? "global_load_dwordx4 -> VGPR -> ds_write_b128" : "global_load_lds_dwordx4");
+  printf("%d blocks, %s\n", g_blocks, g_vgpr == 2 ? "waves 0-1 LDS-DMA, waves 2-3 through registers" : g_vgpr ? "global_load_dwordx4 -> VGPR -> ds_write_b128" : "global_load_lds_dwordx4");
   char *src; unsigned long long *cyc;
   const size_t total = (size_t)2 << 30;
   if (hipMalloc(&src, total + (1 << 20)) != hipSuccess) { printf("alloc failed\n"); return 1; }
