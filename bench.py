@@ -45,7 +45,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "float32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "float32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA; F16 = BF16 rate)
 MODEL_FLOPS_PER_FRAME = {("yolov3", 608): 140.692e9, ("yolov3-tiny", 416): 5.565e9, ("yolov3-spp", 608): 141.449e9}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
 
@@ -58,7 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--model", default="yolov3")
     ap.add_argument("--dim", type=int, default=608)
     ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "float32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "float32"])
     ap.add_argument("--obj-bias", type=float, default=-8.5,
                     help="objectness bias of the procedural weights (sets candidates/frame)")
     ap.add_argument("--kmax", type=int, default=512, help="detection records per frame in the gather")

@@ -61,23 +61,40 @@ def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+def f16_round(t):
+    """float32 tensor -> nearest IEEE half (ties to even, subnormals kept, overflow -> inf) -> float32: the storage
+    rounding of the fp16 mode."""
+    return t.to(torch.float16).to(torch.float32)
+
+
+STORAGE_ROUND = {"bf16": bf16_round, "f16": f16_round}
+
+
+def storage_round(emulate):
+    """``emulate``: None / False (float32, the reference), True or "bf16", "f16" -> the rounding function (or None)."""
+    if not emulate:
+        return None
+    return STORAGE_ROUND["bf16" if emulate is True else str(emulate)]
+
+
 def _conv2d(x, w, stride, pad, accumulate):
     if accumulate == "f64":
         return F.conv2d(x.double(), w.double(), None, stride=stride, padding=pad).float()
     return F.conv2d(x, w, None, stride=stride, padding=pad)
 
 
-def conv_block(x, p, stride, pad, leaky, bf16_weights=False, accumulate="f32"):
+def conv_block(x, p, stride, pad, leaky, bf16_weights=False, accumulate="f32", round_weights=None):
     """conv -> [BN eval] -> [LeakyReLU 0.1]  (reference darknet.py:236-264, run :367-368).
 
     x: (B,Cin,H,W) f32.  p: dict with ``weight`` and either BN tensors or
     ``bias`` (numpy).  ``activation=linear`` means identity (darknet.py:258-261).
-    ``bf16_weights``: kernel weights rounded to bf16 first (bf16 emulation; BN tensors and biases
-    stay float32).  The result is float32 and NOT rounded here.
+    ``bf16_weights`` / ``round_weights`` ("bf16" / "f16"): kernel weights rounded to that storage type first
+    (16-bit emulation; BN tensors and biases stay float32).  The result is float32 and NOT rounded here.
     """
     w = torch.from_numpy(np.ascontiguousarray(p["weight"]))
-    if bf16_weights:
-        w = bf16_round(w)
+    rnd = storage_round(round_weights if round_weights else bf16_weights)
+    if rnd is not None:
+        w = rnd(w)
     if "bn_gamma" in p:
         y = _conv2d(x, w, stride, pad, accumulate)
         y = F.batch_norm(
@@ -191,28 +208,32 @@ class OracleDarknet:
                 rounds[i] = False
         return rounds
 
-    def forward(self, x, collect=None, emulate_bf16=False, accumulate="f32"):
+    def forward(self, x, collect=None, emulate_bf16=False, accumulate="f32", emulate=None):
         """x: torch (B,3,H,W) f32.  Returns dict like the reference (darknet.py:401-405).
 
         ``collect``: optional dict filled with {block_idx: tensor} of every
         block output (used by per-layer parity tests).
         ``emulate_bf16`` / ``accumulate``: see the module docstring (checker of the bf16 mode).
+        ``emulate``: None, "bf16" (== ``emulate_bf16=True``) or "f16": the same rounding points with IEEE-half
+        storage (the product's ``dtype="fp16"`` mode: same kernels, ``v_mfma_f32_16x16x32_f16``).
         """
         outs = []
         heads = []
-        rounds = self.bf16_rounding_points() if emulate_bf16 else None
+        emulate = emulate or ("bf16" if emulate_bf16 else None)
+        rnd = storage_round(emulate)
+        rounds = self.bf16_rounding_points() if rnd is not None else None
         with torch.no_grad():
-            if emulate_bf16:
-                x = bf16_round(x)
+            if rnd is not None:
+                x = rnd(x)
             for i, blk in enumerate(self.blocks):
                 kind = blk["type"]
                 if kind == "convolutional":
                     k = blk["size"]
                     pad = (k - 1) // 2 if "pad" in blk else 0      # darknet.py:240
                     x = conv_block(x, self.params[self._conv_slot[i]], blk["stride"], pad,
-                                   blk["activation"] == "leaky", bf16_weights=emulate_bf16, accumulate=accumulate)
-                    if emulate_bf16 and rounds[i]:
-                        x = bf16_round(x)
+                                   blk["activation"] == "leaky", round_weights=emulate, accumulate=accumulate)
+                    if rnd is not None and rounds[i]:
+                        x = rnd(x)
                 elif kind == "maxpool":
                     x = maxpool(x, blk["size"], blk["stride"])
                 elif kind == "upsample":
@@ -221,8 +242,8 @@ class OracleDarknet:
                     x = torch.cat([outs[j] for j in blk["layers"]], dim=1)   # darknet.py:372-375
                 elif kind == "shortcut":
                     x = outs[i - 1] + outs[i + blk["from"]]                  # darknet.py:379
-                    if emulate_bf16:
-                        x = bf16_round(x)
+                    if rnd is not None:
+                        x = rnd(x)
                 elif kind == "yolo":
                     anchors = [blk["anchors"][m] for m in blk["mask"]]       # darknet.py:44
                     heads.append(yolo_decode(x, anchors))

@@ -92,7 +92,7 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
     Y3_REQUIRE(in != nullptr, "op for block %d has no input pointer", op.block_idx);
     Y3_REQUIRE(op.d_out != nullptr || op.kind == Y3_OP_YOLO, "op for block %d has no output pointer", op.block_idx);
   }
-  Y3_REQUIRE(op.dtype == Y3_F32 || op.dtype == Y3_BF16, "op for block %d: unknown dtype %d", op.block_idx, op.dtype);
+  Y3_REQUIRE(op.dtype == Y3_F32 || op.dtype == Y3_BF16 || op.dtype == Y3_F16, "op for block %d: unknown dtype %d", op.block_idx, op.dtype);
   Y3_REQUIRE(op.batch > 0 && op.in_h > 0 && op.in_w > 0 && op.in_c > 0, "op for block %d: empty input shape", op.block_idx);
   switch (op.kind) {
     case Y3_OP_CONV: {
@@ -120,7 +120,7 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
             if (!(am & Y3_AM_NO_WRES) && y3_conv1x1_wres_supported(op) && ((am & Y3_AM_WRES_ALWAYS) || y3_conv1x1_wres_pays(op)))
               return y3_launch_conv1x1_wres(op, in, d_zero, s, name, dry_run);
             if ((am & Y3_AM_IGEMM3_1X1_BM64) && op.ksize == 1 && op.in_c >= 256 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32) &&
-                op.dtype == Y3_BF16)
+                y3_is16(op.dtype))
               return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3, 64);
             if ((am & Y3_AM_PATCH_WIDE) && op.ksize == 3 && op.stride == 1 && w > 128 && op.out_c >= 128 && y3_conv_patch_fits(op))
               return y3_launch_conv_patch(op, in, d_zero, s, name, dry_run);
@@ -132,12 +132,12 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
             // (Which kernel runs changes speed only: every MFMA conv kernel sums in the same K order.)
             const long long halo_tiles = (long long)y3_ceil_div(op.batch * op.in_h * op.in_w, 192) * (op.out_c / 128);
             const bool small_grid = !(am & Y3_AM_NO_SMALL_GRID) && k3 && halo_tiles < (3 * y3_device_cus()) / 4;
-            if (small_grid && op.dtype == Y3_BF16) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
+            if (small_grid && y3_is16(op.dtype)) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
             if (want_halo && halo_ok && !small_grid) return y3_launch_conv_halo(op, in, d_zero, s, name, dry_run);
             if (want_ws) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
             // 3x3 stride-2 layer with 256 input channels (76^2 -> 38^2): 865 against 762 TFLOP/s on the wave-specialised
             // implicit GEMM at batch 16; the other stride-2 layers measured faster on the LDS-DMA version
-            if (!(am & Y3_AM_NO_SMALL_GRID) && op.ksize == 3 && op.stride == 2 && op.in_c == 256 && op.out_c >= 128 && op.dtype == Y3_BF16 &&
+            if (!(am & Y3_AM_NO_SMALL_GRID) && op.ksize == 3 && op.stride == 2 && op.in_c == 256 && op.out_c >= 128 && y3_is16(op.dtype) &&
                 !(op.flags & Y3_F_OUT_F32) && (long long)op.batch * op.out_h * op.out_w >= 16384)
               return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
           }

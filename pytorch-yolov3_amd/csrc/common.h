@@ -13,6 +13,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
@@ -67,7 +70,22 @@ struct Y3DeviceOnce {
   }
 };
 
-static inline int y3_elem_size(int dtype) { return dtype == Y3_BF16 ? 2 : 4; }
+// 16-bit storage modes (bf16, IEEE half): the same kernels, instantiated per element type
+static inline bool y3_is16(int dtype) { return dtype == Y3_BF16 || dtype == Y3_F16; }
+static inline int y3_elem_size(int dtype) { return y3_is16(dtype) ? 2 : 4; }
+// kernel names carry the element type: Y3_KNAME(dtype, "conv_halo_ws_", "_256x128") -> "conv_halo_ws_bf16_256x128"
+#define Y3_KNAME(dt, pre, post) ((dt) == Y3_BF16 ? pre "bf16" post : ((dt) == Y3_F16 ? pre "f16" post : pre "f32" post))
+// host-side dispatch on the element type: f(T{}) with T = bf16_t / f16_t / float (a generic lambda: `using T = decltype(tag)`)
+template <typename F>
+static inline int y3_by_dtype(int dtype, F &&f) {
+  if (dtype == Y3_BF16) return f(bf16_t{});
+  if (dtype == Y3_F16) return f(f16_t{});
+  return f(float{});
+}
+template <typename F>
+static inline int y3_by_dtype16(int dtype, F &&f) {   // kernels that exist for the 16-bit modes only
+  return dtype == Y3_F16 ? f(f16_t{}) : f(bf16_t{});
+}
 static inline int y3_ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2); give each
@@ -98,6 +116,8 @@ template <>
 __device__ __forceinline__ float y3_to_float<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ float y3_to_float<bf16_t>(bf16_t v) { return (float)v; }
+template <>
+__device__ __forceinline__ float y3_to_float<f16_t>(f16_t v) { return (float)v; }
 
 template <typename T>
 __device__ __forceinline__ T y3_from_float(float v);
@@ -105,6 +125,61 @@ template <>
 __device__ __forceinline__ float y3_from_float<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ bf16_t y3_from_float<bf16_t>(float v) { return (bf16_t)v; }
+template <>
+__device__ __forceinline__ f16_t y3_from_float<f16_t>(float v) { return (f16_t)v; }   // v_cvt_f16_f32: nearest even, like numpy / torch
+
+// The two 16-bit element types behind one interface: 8- / 4-wide vectors, the MFMA that consumes them (both issue at the
+// same rate on gfx950: 16 passes for 16x16x32), conversions.  float32 accumulation in both.
+template <typename T>
+struct H16;
+template <>
+struct H16<bf16_t> {
+  typedef bf16x8 v8;
+  typedef bf16x4 v4;
+  static __device__ __forceinline__ f32x4 mfma(const v8 &w, const v8 &x, const f32x4 &acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc, 0, 0, 0);
+  }
+};
+template <>
+struct H16<f16_t> {
+  typedef f16x8 v8;
+  typedef f16x4 v4;
+  static __device__ __forceinline__ f32x4 mfma(const v8 &w, const v8 &x, const f32x4 &acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, acc, 0, 0, 0);
+  }
+};
+// acc += W (16 rows x 32 k) * X (32 k x 16 columns); operands as the 16 raw bytes a lane holds
+template <typename T>
+__device__ __forceinline__ f32x4 y3_mfma16(const u32x4 &w, const u32x4 &x, const f32x4 &acc) {
+  typedef typename H16<T>::v8 v8;
+  return H16<T>::mfma(__builtin_bit_cast(v8, w), __builtin_bit_cast(v8, x), acc);
+}
+// eight consecutive stored elements (16 raw bytes) added to v[0..7]: the shortcut operand of a conv epilogue
+template <typename T>
+__device__ __forceinline__ void y3_add8(float (&v)[8], const u32x4 &raw) {
+  const typename H16<T>::v8 r = __builtin_bit_cast(typename H16<T>::v8, raw);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] += (float)r[i];
+}
+template <typename T>
+__device__ __forceinline__ void y3_unpack8(float (&v)[8], const u32x4 &raw) {
+  const typename H16<T>::v8 r = __builtin_bit_cast(typename H16<T>::v8, raw);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+}
+// v[0..7] rounded to the storage type (nearest even), as the 16 bytes of one store
+template <typename T>
+__device__ __forceinline__ u32x4 y3_pack8(const float (&v)[8]) {
+  typename H16<T>::v8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (T)v[i];
+  return __builtin_bit_cast(u32x4, o);
+}
+template <typename T>
+__device__ __forceinline__ u32x2 y3_pack4(float a, float b, float c, float d) {
+  const typename H16<T>::v4 o = {(T)a, (T)b, (T)c, (T)d};
+  return __builtin_bit_cast(u32x2, o);
+}
 
 // Conv epilogue arithmetic for eight consecutive output channels: acc * scale + bias, then LeakyReLU(0.1).  Written
 // on 2-wide vectors so that hipcc emits v_pk_fma_f32 / v_pk_mul_f32, and with v_max_f32 spelled out: max(v, 0.1 v) is

@@ -43,7 +43,7 @@ __device__ __forceinline__ void wres_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN>
+template <typename T, int BN>
 __global__ __launch_bounds__(512, 2) void conv1x1_wres_kernel(WresArgs p) {
   constexpr int BM = 128, NS = 4;
   constexpr int NC = 256;                            // consumer threads (== loader threads)
@@ -165,8 +165,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wres_kernel(WresArgs p) {
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[g][ni]),
-                                                                  __builtin_bit_cast(bf16x8, xf[g][mi]), acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = y3_mfma16<T>(wf[g][ni], xf[g][mi], acc[mi][ni]);
     }
     // ---- epilogue: scale / bias / LeakyReLU in registers (the arithmetic of y3_bn_leaky8), bf16, park, write out
 #pragma unroll
@@ -174,20 +173,20 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wres_kernel(WresArgs p) {
       const int pl = wm * 64 + mi * 16 + fr;
 #pragma unroll
       for (int k = 0; k < NI / 2; ++k) {
-        bf16x8 o;
+        float o[8];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int ni = 2 * k + h;
           const f32x2 t0 = f32x2{acc[mi][ni][0], acc[mi][ni][1]} * f32x2{sc[ni][0], sc[ni][1]} + f32x2{bi[ni][0], bi[ni][1]};
           const f32x2 t1 = f32x2{acc[mi][ni][2], acc[mi][ni][3]} * f32x2{sc[ni][2], sc[ni][3]} + f32x2{bi[ni][2], bi[ni][3]};
           const f32x2 s0 = t0 * slope, s1 = t1 * slope;
-          o[4 * h + 0] = (bf16_t)y3_vmax(t0[0], s0[0]);
-          o[4 * h + 1] = (bf16_t)y3_vmax(t0[1], s0[1]);
-          o[4 * h + 2] = (bf16_t)y3_vmax(t1[0], s1[0]);
-          o[4 * h + 3] = (bf16_t)y3_vmax(t1[1], s1[1]);
+          o[4 * h + 0] = y3_vmax(t0[0], s0[0]);
+          o[4 * h + 1] = y3_vmax(t0[1], s0[1]);
+          o[4 * h + 2] = y3_vmax(t1[0], s1[0]);
+          o[4 * h + 3] = y3_vmax(t1[1], s1[1]);
         }
         const int oc = wn * (TN / 8) + k * 4 + fq;                       // 16-byte chunk of the pixel's row
-        *reinterpret_cast<bf16x8 *>(sP + pl * (BN * 2) + ((oc ^ (pl & (OCT - 1))) << 4)) = o;
+        *reinterpret_cast<u32x4 *>(sP + pl * (BN * 2) + ((oc ^ (pl & (OCT - 1))) << 4)) = y3_pack8<T>(o);
       }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -215,7 +214,7 @@ int wres_bn(const y3_op &op) {
 
 // 1x1 stride-1 bf16 conv without shortcut operand whose weight panel fits LDS
 bool y3_conv1x1_wres_supported(const y3_op &op) {
-  if (op.kind != Y3_OP_CONV || op.dtype != Y3_BF16 || op.ksize != 1 || op.stride != 1 || op.pad != 0) return false;
+  if (op.kind != Y3_OP_CONV || !y3_is16(op.dtype) || op.ksize != 1 || op.stride != 1 || op.pad != 0) return false;
   if (op.flags & (Y3_F_RESIDUAL | Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT)) return false;
   if (op.in_c % 64 != 0 || op.in_c < 128 || op.in_ld % 8 != 0 || op.out_ld % 8 != 0 || op.k_ld < op.in_c) return false;
   if (((uintptr_t)op.d_in | (uintptr_t)op.d_out) % 16 != 0) return false;
@@ -236,7 +235,7 @@ int y3_launch_conv1x1_wres(const y3_op &op, const void *d_in, const void *d_zero
                            bool dry_run) {
   Y3_REQUIRE(y3_conv1x1_wres_supported(op), "conv block %d: not a shape for the weights-resident 1x1 kernel", op.block_idx);
   const int bn = wres_bn(op);
-  *kernel_name = bn == 128 ? "conv1x1_wres_bf16_128x128" : "conv1x1_wres_bf16_128x64";
+  *kernel_name = bn == 128 ? Y3_KNAME(op.dtype, "conv1x1_wres_", "_128x128") : Y3_KNAME(op.dtype, "conv1x1_wres_", "_128x64");
   if (dry_run) return Y3_OK;
   WresArgs a;
   a.in = static_cast<const char *>(d_in);
@@ -250,27 +249,30 @@ int y3_launch_conv1x1_wres(const y3_op &op, const void *d_in, const void *d_zero
   a.n_tiles = op.out_c / bn;
   a.m_tiles = y3_ceil_div(a.M, 128);
   a.flags = op.flags;
-  static Y3DeviceOnce once;
-  int n_cu = 0;
-  {
-    const int rc = once.run([]() -> int {
-      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wres_kernel<128>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wres_kernel<64>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      return Y3_OK;
-    }, &n_cu);
-    if (rc != Y3_OK) return rc;
-  }
-  const size_t lds = (size_t)a.n_kt * bn * 128 + (size_t)128 * bn * 2 + (size_t)4 * 128 * 128;
-  Y3_REQUIRE(lds <= 160 * 1024, "conv block %d: weight panel does not fit LDS", op.block_idx);
-  // one workgroup per CU, a whole number of them per channel tile (at least one each: more channel tiles than CUs just
-  // means more than one workgroup per CU in turn)
-  int grid = a.n_tiles > n_cu ? a.n_tiles : n_cu - n_cu % a.n_tiles;
-  const long long tiles = (long long)a.m_tiles * a.n_tiles;
-  if (grid > tiles) grid = (int)tiles;
-  if (bn == 128) hipLaunchKernelGGL(conv1x1_wres_kernel<128>, dim3(grid), dim3(512), lds, s, a);
-  else hipLaunchKernelGGL(conv1x1_wres_kernel<64>, dim3(grid), dim3(512), lds, s, a);
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
+  return y3_by_dtype16(op.dtype, [&](auto tag) {
+    typedef decltype(tag) T;
+    static Y3DeviceOnce once;
+    int n_cu = 0;
+    {
+      const int rc = once.run([]() -> int {
+        Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wres_kernel<T, 128>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_wres_kernel<T, 64>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        return Y3_OK;
+      }, &n_cu);
+      if (rc != Y3_OK) return rc;
+    }
+    const size_t lds = (size_t)a.n_kt * bn * 128 + (size_t)128 * bn * 2 + (size_t)4 * 128 * 128;
+    Y3_REQUIRE(lds <= 160 * 1024, "conv block %d: weight panel does not fit LDS", op.block_idx);
+    // one workgroup per CU, a whole number of them per channel tile (at least one each: more channel tiles than CUs just
+    // means more than one workgroup per CU in turn)
+    int grid = a.n_tiles > n_cu ? a.n_tiles : n_cu - n_cu % a.n_tiles;
+    const long long tiles = (long long)a.m_tiles * a.n_tiles;
+    if (grid > tiles) grid = (int)tiles;
+    if (bn == 128) hipLaunchKernelGGL((conv1x1_wres_kernel<T, 128>), dim3(grid), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv1x1_wres_kernel<T, 64>), dim3(grid), dim3(512), lds, s, a);
+    Y3_HIP_CHECK(hipGetLastError());
+    return Y3_OK;
+  });
 }

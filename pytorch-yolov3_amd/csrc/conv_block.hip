@@ -81,11 +81,9 @@ __device__ __forceinline__ uint32_t lane32(uint32_t v) {
 }
 __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
 
-__device__ __forceinline__ f32x4 mma(const u32x4 &w, const u32x4 &x, const f32x4 &acc) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
-}
-
+template <typename T>
 __global__ __launch_bounds__(kNT) void conv_block_fused_kernel(BlockArgs p) {
+  auto mma = [](const u32x4 &w, const u32x4 &x, const f32x4 &acc) { return y3_mfma16<T>(w, x, acc); };
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -234,10 +232,7 @@ __global__ __launch_bounds__(kNT) void conv_block_fused_kernel(BlockArgs p) {
       for (int mi = 0; mi < kMA; ++mi) {
         float v[8];
         y3_bn_leaky8(v, acc[mi][2 * k], acc[mi][2 * k + 1], sl, sh, bl, bh, p.leaky1 != 0);
-        bf16x8 o;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
-        u32x4 ov = __builtin_bit_cast(u32x4, o);
+        u32x4 ov = y3_pack8<T>(v);
         if (!((inside >> mi) & 1u)) ov = u32x4{0u, 0u, 0u, 0u};   // the 3x3's zero padding
         *reinterpret_cast<u32x4 *>(smem + (midw[mi] ^ (k * 64))) = ov;
       }
@@ -391,15 +386,8 @@ __global__ __launch_bounds__(kNT) void conv_block_fused_kernel(BlockArgs p) {
           for (int mi = 0; mi < kMB; ++mi) {
             float v[8];
             y3_bn_leaky8(v, acc[mi][2 * k], acc[mi][2 * k + 1], sl, sh, bl, bh, p.leaky3 != 0);
-            if constexpr (RES) {
-              const bf16x8 xr = __builtin_bit_cast(bf16x8, rv[k][mi]);
-#pragma unroll
-              for (int r = 0; r < 8; ++r) v[r] += (float)xr[r];
-            }
-            bf16x8 o;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
-            if ((stored >> mi) & 1u) *reinterpret_cast<bf16x8 *>(p.out + lane32((uint32_t)(pxo[mi] * p.out_ld + ch0) * 2u)) = o;
+            if constexpr (RES) y3_add8<T>(v, rv[k][mi]);
+            if ((stored >> mi) & 1u) *reinterpret_cast<u32x4 *>(p.out + lane32((uint32_t)(pxo[mi] * p.out_ld + ch0) * 2u)) = y3_pack8<T>(v);
           }
         }
       };
@@ -447,12 +435,21 @@ bool choose_tile(int H, int W, int batch, int n_cu, int &TW, int &TH, double &ef
 bool y3_conv_block_fused_supported(const y3_op &op0, const y3_op &op1) {
   const int mode = y3_opt().fuse_block;
   if (!mode) return false;
-  if (op0.kind != Y3_OP_CONV || op1.kind != Y3_OP_CONV || op0.dtype != Y3_BF16 || op1.dtype != Y3_BF16) return false;
+  if (op0.kind != Y3_OP_CONV || op1.kind != Y3_OP_CONV || !y3_is16(op0.dtype) || op1.dtype != op0.dtype) return false;
   if (op0.ksize != 1 || op0.stride != 1 || op0.in_c % 64 != 0 || op0.in_c < 192 || op0.out_c != 128) return false;
   if (op1.ksize != 3 || op1.stride != 1 || op1.pad != 1 || op1.in_c != 128 || op1.out_c % 128 != 0) return false;
   const uint32_t bad = Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT;
   if ((op0.flags & (bad | Y3_F_RESIDUAL)) || (op1.flags & bad)) return false;
   if (op1.d_in != op0.d_out || op1.in_ld != op0.out_ld) return false;
+  // z must not overlap x: a workgroup writes its rectangle of z while its neighbours still read those pixels of x as their
+  // one-pixel border (phase A), and nothing orders workgroups of different rounds / streams.  The arena planner frees x after
+  // the 1x1 of a pair WITHOUT shortcut and may hand the same bytes to z (unfused that is safe: the 1x1's output is a
+  // separate buffer): such pairs run as two launches.  
+  {
+    const uintptr_t x0 = (uintptr_t)op0.d_in, z0 = (uintptr_t)op1.d_out;
+    const uintptr_t xb = (uintptr_t)op0.batch * op0.in_h * op0.in_w * op0.in_ld * 2, zb = (uintptr_t)op1.batch * op1.out_h * op1.out_w * op1.out_ld * 2;
+    if (x0 && z0 && x0 < z0 + zb && z0 < x0 + xb) return false;
+  }
   if (op1.flags & Y3_F_RESIDUAL)
     if (op1.d_res != op0.d_in || op1.res_ld != op0.in_ld || op1.out_c != op0.in_c) return false;
   if (op0.in_h != op1.in_h || op0.in_w != op1.in_w || op0.batch != op1.batch) return false;
@@ -470,7 +467,7 @@ bool y3_conv_block_fused_supported(const y3_op &op0, const y3_op &op1) {
 }
 
 int y3_launch_conv_block_fused(const y3_op &op0, const y3_op &op1, hipStream_t s, const char **kernel_name, bool dry_run) {
-  *kernel_name = "conv_block_fused_bf16_x128";
+  *kernel_name = Y3_KNAME(op0.dtype, "conv_block_fused_", "_x128");
   if (dry_run) return Y3_OK;
   BlockArgs a;
   a.x = static_cast<const char *>(op0.d_in);
@@ -481,26 +478,29 @@ int y3_launch_conv_block_fused(const y3_op &op0, const y3_op &op1, hipStream_t s
   a.res = (op1.flags & Y3_F_RESIDUAL) ? 1 : 0;
   a.leaky1 = (op0.flags & Y3_F_LEAKY) ? 1 : 0;
   a.leaky3 = (op1.flags & Y3_F_LEAKY) ? 1 : 0;
-  static Y3DeviceOnce once;
-  int n_cu = 0;
-  {
-    const int rc = once.run([]() -> int {
-      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_block_fused_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kBlockLds));
-      return Y3_OK;
-    }, &n_cu);
-    if (rc != Y3_OK) return rc;
-  }
-  double eff;
-  Y3_REQUIRE(choose_tile(a.H, a.W, op0.batch, n_cu, a.TW, a.TH, eff), "conv block %d: no tile shape", op0.block_idx);
-  a.tiles_x = y3_ceil_div(a.W, a.TW);
-  a.tiles_y = y3_ceil_div(a.H, a.TH);
-  a.inv_pw = (65536u + (uint32_t)(a.TW + 2) - 1u) / (uint32_t)(a.TW + 2);
-  a.inv_tw = (65536u + (uint32_t)a.TW - 1u) / (uint32_t)a.TW;
-  const int grid = a.tiles_x * a.tiles_y * op0.batch;
-  hipLaunchKernelGGL(conv_block_fused_kernel, dim3(grid), dim3(kNT), kBlockLds, s, a);
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
+  return y3_by_dtype16(op0.dtype, [&](auto tag) {
+    typedef decltype(tag) T;
+    static Y3DeviceOnce once;
+    int n_cu = 0;
+    {
+      const int rc = once.run([]() -> int {
+        Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_block_fused_kernel<T>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kBlockLds));
+        return Y3_OK;
+      }, &n_cu);
+      if (rc != Y3_OK) return rc;
+    }
+    double eff;
+    Y3_REQUIRE(choose_tile(a.H, a.W, op0.batch, n_cu, a.TW, a.TH, eff), "conv block %d: no tile shape", op0.block_idx);
+    a.tiles_x = y3_ceil_div(a.W, a.TW);
+    a.tiles_y = y3_ceil_div(a.H, a.TH);
+    a.inv_pw = (65536u + (uint32_t)(a.TW + 2) - 1u) / (uint32_t)(a.TW + 2);
+    a.inv_tw = (65536u + (uint32_t)a.TW - 1u) / (uint32_t)a.TW;
+    const int grid = a.tiles_x * a.tiles_y * op0.batch;
+    hipLaunchKernelGGL(conv_block_fused_kernel<T>, dim3(grid), dim3(kNT), kBlockLds, s, a);
+    Y3_HIP_CHECK(hipGetLastError());
+    return Y3_OK;
+  });
 }
 
 Y3_STAMP_READER(y3_debug_stamps_block)

@@ -46,17 +46,18 @@ constexpr int kPatchElems = kIR * kIR * 3;                    // 3675 bytes of t
 constexpr int kPre = (kPatchElems + kThreads - 1) / kThreads; // bytes prefetched per thread (8)
 constexpr int kLds = 2 * kInBytes + kNStem * kStemPitch + 64 * kW1Pitch + 512;   // + 256-entry byte -> bf16 table
 
+template <typename T>
 struct FusedArgs {
   const unsigned char *in;   // (B, H, W, 3) uint8 BGR
   int H, W, batch;
-  const bf16_t *w0;          // stem weights [32][32]: k = ky*9 + kx*3 + byte channel, zero padded
+  const T *w0;          // stem weights [32][32]: k = ky*9 + kx*3 + byte channel, zero padded
   const float *sc0, *bi0;
   uint32_t flags0;
-  const bf16_t *w1;          // second conv [>= 64][k_ld1], k = (ky*3 + kx)*32 + ci
+  const T *w1;          // second conv [>= 64][k_ld1], k = (ky*3 + kx)*32 + ci
   int k_ld1;
   const float *sc1, *bi1;
   uint32_t flags1;
-  bf16_t *out;
+  T *out;
   int out_ld, Ho, Wo;
   int tiles_x, tiles_y, n_tiles;
   int dbg;   // diagnostic: bit 0 skip phase 1, bit 1 skip phase 2, bit 2 skip phase 3 stores, bit 3 skip patch prefetch
@@ -64,21 +65,22 @@ struct FusedArgs {
 
 // acc * scale + bias -> LeakyReLU(0.1) -> bf16, four channels at a time; written with 2-wide vectors so that hipcc
 // emits v_pk_fma_f32 / v_pk_mul_f32 (the epilogues are VALU-bound: 35 k stem values per tile)
-__device__ __forceinline__ u32x2 bn_leaky_bf16x4(const f32x4 &a, const f32x4 &sc, const f32x4 &bi) {
+template <typename T>
+__device__ __forceinline__ u32x2 bn_leaky_pack4(const f32x4 &a, const f32x4 &sc, const f32x4 &bi) {
   const f32x2 lo = f32x2{a[0], a[1]} * f32x2{sc[0], sc[1]} + f32x2{bi[0], bi[1]};
   const f32x2 hi = f32x2{a[2], a[3]} * f32x2{sc[2], sc[3]} + f32x2{bi[2], bi[3]};
   const f32x2 tl = lo * Y3_LEAKY_SLOPE, th = hi * Y3_LEAKY_SLOPE;
-  const bf16x4 o = {(bf16_t)y3_vmax(lo[0], tl[0]), (bf16_t)y3_vmax(lo[1], tl[1]), (bf16_t)y3_vmax(hi[0], th[0]),
-                    (bf16_t)y3_vmax(hi[1], th[1])};
-  return __builtin_bit_cast(u32x2, o);
+  return y3_pack4<T>(y3_vmax(lo[0], tl[0]), y3_vmax(lo[1], tl[1]), y3_vmax(hi[0], th[0]), y3_vmax(hi[1], th[1]));
 }
 
-__global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs p) {
+template <typename T>
+__global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs<T> p) {
+  typedef typename H16<T>::v8 V8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t *in_tile = reinterpret_cast<bf16_t *>(smem);                 // [2][kIR][kInPitch]
+  T *in_tile = reinterpret_cast<T *>(smem);                 // [2][kIR][kInPitch]
   char *stem = smem + 2 * kInBytes;                                    // [kNStem][kStemPitch]
   char *w1s = stem + kNStem * kStemPitch;                              // [64][kW1Pitch]
-  bf16_t *lut = reinterpret_cast<bf16_t *>(w1s + 64 * kW1Pitch);       // lut[v] = bf16(v / 255.0f): one IEEE division per
+  T *lut = reinterpret_cast<T *>(w1s + 64 * kW1Pitch);       // lut[v] = bf16(v / 255.0f): one IEEE division per
                                                                        // table entry instead of one per input byte
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
         *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.w1) + ((long long)co * p.k_ld1) * 2 + ch * 16);
   }
   // stem weights re-indexed to k = ky*12 + kx*4 + c (c == 3 and k >= 36: zero); A fragments for both K steps
-  bf16x8 w0a[2], w0b[2];
+  V8 w0a[2], w0b[2];
 #pragma unroll
   for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -101,9 +103,9 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
       const int ky = k / 12, rem = k - ky * 12, kx = rem >> 2, c = rem & 3;
       const bool live = k < 36 && c < 3;
       const int kold = live ? ky * 9 + kx * 3 + c : 0;
-      const bf16_t za = p.w0[(0 + fr) * 32 + kold], zb = p.w0[(16 + fr) * 32 + kold];
-      w0a[st][j] = live ? za : (bf16_t)0.f;
-      w0b[st][j] = live ? zb : (bf16_t)0.f;
+      const T za = p.w0[(0 + fr) * 32 + kold], zb = p.w0[(16 + fr) * 32 + kold];
+      w0a[st][j] = live ? za : (T)0.f;
+      w0b[st][j] = live ? zb : (T)0.f;
     }
   // element offsets (relative to the pixel's first element in its patch row) of this lane's two 4-element pieces
   // of K step 0, and of its piece of K step 1 (only fq == 0 carries live values there: ky = 2, kx = 2)
@@ -165,14 +167,14 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
     }
   };
   auto patch_store = [&](int buf, const unsigned char (&pre)[kPre]) {
-    bf16_t *dst = in_tile + buf * (kIR * kInPitch);
+    T *dst = in_tile + buf * (kIR * kInPitch);
 #pragma unroll
     for (int j = 0; j < kPre; ++j)
       if (j < kPre - 1 || pr_last_live) dst[pr_dst[j]] = lut[pre[j]];
   };
 
   for (int i = tid; i < 2 * kIR * kInPitch / 2; i += kThreads) reinterpret_cast<uint32_t *>(in_tile)[i] = 0u;
-  if (tid < 256) lut[tid] = (bf16_t)((float)tid / 255.0f);
+  if (tid < 256) lut[tid] = (T)((float)tid / 255.0f);
   __syncthreads();   // the fourth channel of every patch pixel stays zero from here on
   int tile = blockIdx.x;
   int buf = 0;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
     __syncthreads();   // B1: this tile's input patch (and, first time, the weights) are in LDS; stem image is free
 
     // ---- phase 1: stem ------------------------------------------------------------------------------
-    const bf16_t *patch = in_tile + buf * (kIR * kInPitch);
+    const T *patch = in_tile + buf * (kIR * kInPitch);
     // Three fragments per wave are in flight at a time: a fragment is one dependent chain LDS read -> two MFMAs ->
     // scale / bias / leaky -> LDS write, and with two waves per SIMD a chain at a time left every latency exposed
     // (690 cycles per fragment; the phase was 42 % of the kernel, profiles/r02m_stem_phases.txt).
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
         const int q = (wave + (g + j) * (kThreads / 64)) * 16 + fr;
         const int qc = q < kNStem ? q : kNStem - 1;
         const int sy = qc / kSR, sx = qc - sy * kSR;
-        const bf16_t *base = patch + sy * kInPitch + sx * 4;
+        const T *base = patch + sy * kInPitch + sx * 4;
         lo[j] = *reinterpret_cast<const u32x2 *>(base + off_lo);
         hi[j] = *reinterpret_cast<const u32x2 *>(base + off_hi);
         s1[j] = *reinterpret_cast<const u32x2 *>(base + off_s1);
@@ -217,15 +219,15 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
       f32x4 acc0[kFG], acc1[kFG];
 #pragma unroll
       for (int j = 0; j < kFG; ++j) {
-        const bf16x8 xf0 = __builtin_bit_cast(bf16x8, u32x4{lo[j][0], lo[j][1], hi[j][0], hi[j][1]});
-        acc0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[0], xf0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b[0], xf0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const V8 xf0 = __builtin_bit_cast(V8, u32x4{lo[j][0], lo[j][1], hi[j][0], hi[j][1]});
+        acc0[j] = H16<T>::mfma(w0a[0], xf0, f32x4{0.f, 0.f, 0.f, 0.f});
+        acc1[j] = H16<T>::mfma(w0b[0], xf0, f32x4{0.f, 0.f, 0.f, 0.f});
       }
 #pragma unroll
       for (int j = 0; j < kFG; ++j) {
-        const bf16x8 xf1 = __builtin_bit_cast(bf16x8, fq == 0 ? u32x4{s1[j][0], s1[j][1], 0u, 0u} : u32x4{0u, 0u, 0u, 0u});
-        acc0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[1], xf1, acc0[j], 0, 0, 0);
-        acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b[1], xf1, acc1[j], 0, 0, 0);
+        const V8 xf1 = __builtin_bit_cast(V8, fq == 0 ? u32x4{s1[j][0], s1[j][1], 0u, 0u} : u32x4{0u, 0u, 0u, 0u});
+        acc0[j] = H16<T>::mfma(w0a[1], xf1, acc0[j]);
+        acc1[j] = H16<T>::mfma(w0b[1], xf1, acc1[j]);
       }
 #pragma unroll
       for (int j = 0; j < kFG; ++j) {
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
           }
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni) {
-            u32x2 o = bn_leaky_bf16x4(ni ? acc1[j] : acc0[j], sc0[ni], bi0[ni]);
+            u32x2 o = bn_leaky_pack4<T>(ni ? acc1[j] : acc0[j], sc0[ni], bi0[ni]);
             if (!inside) o = u32x2{0u, 0u};                             // the second conv's zero padding
             *reinterpret_cast<u32x2 *>(stem + qv[j] * kStemPitch + (ni * 16 + cq) * 2) = o;
           }
@@ -272,8 +274,8 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf)
-          acc[mi][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[nf]),
-                                                                __builtin_bit_cast(bf16x8, xf[mi]), acc[mi][nf], 0, 0, 0);
+          acc[mi][nf] = H16<T>::mfma(__builtin_bit_cast(V8, wf[nf]),
+                                                                __builtin_bit_cast(V8, xf[mi]), acc[mi][nf]);
     }
     if (next_tile < p.n_tiles) patch_store(buf ^ 1, pre);
     __syncthreads();   // B3: nobody reads the stem image any more
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(kThreads) void conv_stem_s2_fused_kernel(FusedArgs 
         const int px = (2 * wave + mi) * kTO + fr;
         const int co = nf * 16 + cq;                                   // 4 consecutive channels
         *reinterpret_cast<u32x2 *>(stem + px * 128 + (((co >> 3) ^ (px & 7)) << 4) + (co & 7) * 2) =
-            bn_leaky_bf16x4(acc[mi][nf], s1, b1);
+            bn_leaky_pack4<T>(acc[mi][nf], s1, b1);
       }
     }
     __syncthreads();   // B4
@@ -335,8 +337,9 @@ constexpr int kPLds = 2 * kPInBytes + 2 * kPStemBytes + 64 * kW1Pitch + 512 + kP
 static_assert(kPLds <= 160 * 1024, "LDS budget");
 static_assert(kPX == 16 && kPY == 8, "one 16-pixel output row per conv wave");
 
-template <int NC>   // conv waves (4: two output rows each, 8: one); the other 16 - NC waves are stem waves
-__global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
+template <typename T, int NC>   // conv waves (4: two output rows each, 8: one); the other 16 - NC waves are stem waves
+__global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs<T> p) {
+  typedef typename H16<T>::v8 V8;
   constexpr int NS = 16 - NC, NT = 1024;
   constexpr int MR = kPY / NC;                                         // output rows per conv wave
   constexpr int kIters = (kPNFrag + NS - 1) / NS;                      // stem fragments per stem wave
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
   char *in_tile = smem;                                                // [2][kPIY][kInPitch] bf16
   char *stem0 = smem + 2 * kPInBytes;                                  // [2][kPNStem][kStemPitch]
   char *w1s = stem0 + 2 * kPStemBytes;                                 // [64][kW1Pitch]
-  bf16_t *lut = reinterpret_cast<bf16_t *>(w1s + 64 * kW1Pitch);       // lut[v] = bf16(v / 255.0f)
+  T *lut = reinterpret_cast<T *>(w1s + 64 * kW1Pitch);       // lut[v] = bf16(v / 255.0f)
   char *stage = reinterpret_cast<char *>(lut) + 512;                   // [8][16][128]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
         *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(p.w1) + ((long long)co * p.k_ld1) * 2 + ch * 16);
   }
   for (int i = tid; i < 2 * kPInBytes / 4; i += NT) reinterpret_cast<uint32_t *>(in_tile)[i] = 0u;
-  if (tid < 256) lut[tid] = (bf16_t)((float)tid / 255.0f);
+  if (tid < 256) lut[tid] = (T)((float)tid / 255.0f);
   __syncthreads();   // the fourth channel of every patch pixel stays zero from here on
   const int tile0 = blockIdx.x, stride = gridDim.x;
   if (tile0 >= p.n_tiles) return;
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
   if (is_stem) {
     // =============================== stem waves ===============================
     const int sw = wave - NC, stid = tid - 64 * NC;
-    bf16x8 w0a[2], w0b[2];                                             // stem weights, k = ky*12 + kx*4 + c (see above)
+    V8 w0a[2], w0b[2];                                             // stem weights, k = ky*12 + kx*4 + c (see above)
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -402,9 +405,9 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
         const bool live = k < 36 && c < 3;
         const int kold = live ? ky * 9 + kx * 3 + c : 0;
         // MFMA row fr of the first / second fragment is channel 8 (fr >> 2) + (fr & 3) (+ 4): y3_pair_perm
-        const bf16_t za = p.w0[y3_pair_perm(fr) * 32 + kold], zb = p.w0[y3_pair_perm(16 + fr) * 32 + kold];
-        w0a[st][j] = live ? za : (bf16_t)0.f;
-        w0b[st][j] = live ? zb : (bf16_t)0.f;
+        const T za = p.w0[y3_pair_perm(fr) * 32 + kold], zb = p.w0[y3_pair_perm(16 + fr) * 32 + kold];
+        w0a[st][j] = live ? za : (T)0.f;
+        w0b[st][j] = live ? zb : (T)0.f;
       }
     int off_lo, off_hi;                                                 // bytes, relative to the pixel's first patch element
     {
@@ -481,8 +484,8 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
       for (int j = 0; j < kPre; ++j)
         if (j < kPre - 1 || pr_last_live) {
           char *d = dst + (pr_dst[j] & ~1);
-          *reinterpret_cast<bf16_t *>(d) = lut[pre[j] & 255];
-          if (!((pr_one >> j) & 1u)) *reinterpret_cast<bf16_t *>(d + 2 + 2 * (pr_dst[j] & 1)) = lut[pre[j] >> 8];
+          *reinterpret_cast<T *>(d) = lut[pre[j] & 255];
+          if (!((pr_one >> j) & 1u)) *reinterpret_cast<T *>(d + 2 + 2 * (pr_dst[j] & 1)) = lut[pre[j] >> 8];
         }
     };
     // stem image of one tile: kFG fragments in flight (LDS reads, two K steps each, scale / bias / leaky, LDS writes)
@@ -502,22 +505,22 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
         f32x4 a0[G], a1[G];
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-          const bf16x8 xf0 = __builtin_bit_cast(bf16x8, u32x4{lo[j][0], lo[j][1], hi[j][0], hi[j][1]});
-          a0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[0], xf0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          a1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b[0], xf0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          const V8 xf0 = __builtin_bit_cast(V8, u32x4{lo[j][0], lo[j][1], hi[j][0], hi[j][1]});
+          a0[j] = H16<T>::mfma(w0a[0], xf0, f32x4{0.f, 0.f, 0.f, 0.f});
+          a1[j] = H16<T>::mfma(w0b[0], xf0, f32x4{0.f, 0.f, 0.f, 0.f});
         }
 #pragma unroll
         for (int j = 0; j < G; ++j) {
           // K step 1 only carries tap (2, 2) in k = 32..34 (lanes fq == 0); every other weight of the step is zero, so
           // the data there only has to be finite: the same (valid) patch bytes again instead of selected zeros
-          const bf16x8 xf1 = __builtin_bit_cast(bf16x8, u32x4{s1[j][0], s1[j][1], s1[j][0], s1[j][1]});
-          a0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0a[1], xf1, a0[j], 0, 0, 0);
-          a1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0b[1], xf1, a1[j], 0, 0, 0);
+          const V8 xf1 = __builtin_bit_cast(V8, u32x4{s1[j][0], s1[j][1], s1[j][0], s1[j][1]});
+          a0[j] = H16<T>::mfma(w0a[1], xf1, a0[j]);
+          a1[j] = H16<T>::mfma(w0b[1], xf1, a1[j]);
         }
 #pragma unroll
         for (int j = 0; j < G; ++j) {
-          u32x2 o0 = bn_leaky_bf16x4(a0[j], sc0[0], bi0[0]);
-          u32x2 o1 = bn_leaky_bf16x4(a1[j], sc0[1], bi0[1]);
+          u32x2 o0 = bn_leaky_pack4<T>(a0[j], sc0[0], bi0[0]);
+          u32x2 o1 = bn_leaky_pack4<T>(a1[j], sc0[1], bi0[1]);
           if (!all_inside) {                                            // uniform: tiles on the frame border only
             const int q = (sw + NS * (g + j)) * 16 + fr;
             const int qc = q < kPNStem ? q : kPNStem - 1;
@@ -645,8 +648,8 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
       for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf)
-          acc[mr][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[nf]),
-                                                                __builtin_bit_cast(bf16x8, xf[mr]), acc[mr][nf], 0, 0, 0);
+          acc[mr][nf] = H16<T>::mfma(__builtin_bit_cast(V8, wf[nf]),
+                                                                __builtin_bit_cast(V8, xf[mr]), acc[mr][nf]);
     }
     Y3_STAMP(4);
     // write-out, wave-private: bn + leaky -> bf16 -> this wave's 16 pixels x 128 bytes per row -> two 1 KiB runs per row
@@ -654,8 +657,8 @@ __global__ __launch_bounds__(1024) void conv_stem_s2_ws_kernel(FusedArgs p) {
     for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
       for (int k = 0; k < 2; ++k) {                                      // fragment pair k: channels 32 k + 8 fq .. + 7
-        const u32x2 lo = bn_leaky_bf16x4(acc[mr][2 * k], s1v[2 * k], b1v[2 * k]);
-        const u32x2 hi = bn_leaky_bf16x4(acc[mr][2 * k + 1], s1v[2 * k + 1], b1v[2 * k + 1]);
+        const u32x2 lo = bn_leaky_pack4<T>(acc[mr][2 * k], s1v[2 * k], b1v[2 * k]);
+        const u32x2 hi = bn_leaky_pack4<T>(acc[mr][2 * k + 1], s1v[2 * k + 1], b1v[2 * k + 1]);
         *reinterpret_cast<u32x4 *>(my_stage + mr * 2048 + fr * 128 + (((k * 4 + fq) ^ (fr & 7)) << 4)) = u32x4{lo[0], lo[1], hi[0], hi[1]};
       }
     __builtin_amdgcn_wave_barrier();
@@ -708,17 +711,20 @@ constexpr int kRLds = kXBytes + kYBytes + 64 * kW1Pitch;
 constexpr int kXPre = (kRNP * 8 + kThreads - 1) / kThreads;   // 16-byte chunks of x prefetched per thread (6)
 static_assert(kRNP * kYPitch <= kYBytes && kRT * kRT * 128 <= kYBytes, "image / staging tile must fit");
 
+template <typename T>
 struct ResArgs {
-  const bf16_t *x;
+  const T *x;
   int H, W, batch, x_ld;
-  const bf16_t *w2; int k_ld2; const float *sc2, *bi2;   // 1x1: [>= 32][k_ld2], k = ci
-  const bf16_t *w3; int k_ld3; const float *sc3, *bi3;   // 3x3: [>= 64][k_ld3], k = (ky*3 + kx)*32 + ci
-  bf16_t *out;
+  const T *w2; int k_ld2; const float *sc2, *bi2;   // 1x1: [>= 32][k_ld2], k = ci
+  const T *w3; int k_ld3; const float *sc3, *bi3;   // 3x3: [>= 64][k_ld3], k = (ky*3 + kx)*32 + ci
+  T *out;
   int out_ld;
   int tiles_x, tiles_y, n_tiles;
 };
 
-__global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs p) {
+template <typename T>
+__global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs<T> p) {
+  typedef typename H16<T>::v8 V8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *xt = smem;                        // [kRNP][128], 16-byte chunks XOR-swizzled with (pixel & 7)
   char *yt = smem + kXBytes;              // [kRNP][kYPitch]; later the staging tile
@@ -837,9 +843,9 @@ __global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs p
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2f[ni][0]), __builtin_bit_cast(bf16x8, xa), a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2f[ni][1]), __builtin_bit_cast(bf16x8, xb), a, 0, 0, 0);
-        o[ni] = bn_leaky_bf16x4(a, sc2[ni], bi2[ni]);
+        a = H16<T>::mfma(__builtin_bit_cast(V8, w2f[ni][0]), __builtin_bit_cast(V8, xa), a);
+        a = H16<T>::mfma(__builtin_bit_cast(V8, w2f[ni][1]), __builtin_bit_cast(V8, xb), a);
+        o[ni] = bn_leaky_pack4<T>(a, sc2[ni], bi2[ni]);
         if (!inside) o[ni] = u32x2{0u, 0u};                              // the 3x3's zero padding
       }
       // channels 8 fq .. 8 fq + 7 of pixel q: one 16-byte write
@@ -872,8 +878,8 @@ __global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs p
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf)
-          acc[mi][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[nf]),
-                                                                __builtin_bit_cast(bf16x8, xf[mi]), acc[mi][nf], 0, 0, 0);
+          acc[mi][nf] = H16<T>::mfma(__builtin_bit_cast(V8, wf[nf]),
+                                                                __builtin_bit_cast(V8, xf[mi]), acc[mi][nf]);
     }
     __syncthreads();   // B3: nobody reads the image any more
 
@@ -891,14 +897,11 @@ __global__ __launch_bounds__(kThreads) void conv_resblock_fused_kernel(ResArgs p
         const int oyl = 2 * wave + mi;
         const int pp = (oyl + 1) * kRP + fr + 1;                          // this output pixel inside the patch
         const u32x4 xr = *reinterpret_cast<const u32x4 *>(xt + pp * 128 + (((k * 4 + fq) ^ (pp & 7)) << 4));
-        const bf16x8 xv = __builtin_bit_cast(bf16x8, xr);
         float v[8];
         y3_bn_leaky8(v, acc[mi][2 * k], acc[mi][2 * k + 1], s3[0], s3[1], b3[0], b3[1], true);   // packed arithmetic
-        bf16x8 o;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) o[r] = (bf16_t)(v[r] + (float)xv[r]);
+        y3_add8<T>(v, xr);
         const int px = oyl * kRT + fr;
-        *reinterpret_cast<bf16x8 *>(yt + px * 128 + (((k * 4 + fq) ^ (px & 7)) << 4)) = o;
+        *reinterpret_cast<u32x4 *>(yt + px * 128 + (((k * 4 + fq) ^ (px & 7)) << 4)) = y3_pack8<T>(v);
       }
     }
     __syncthreads();   // B4: staging complete; the x patch is dead
@@ -922,7 +925,7 @@ bool y3_conv_fused_stem_s2_supported(const y3_op &op0, const y3_op &op1) {
   if (!y3_opt().fuse_stem) return false;
   if (!y3_conv_stem_mfma_supported(op0) || op0.out_c != 32 || (op0.flags & Y3_F_RESIDUAL)) return false;
   if (!(op0.flags & Y3_F_LEAKY) || !(op1.flags & Y3_F_LEAKY)) return false;   // the kernel hard-wires LeakyReLU(0.1)
-  if (op1.kind != Y3_OP_CONV || op1.dtype != Y3_BF16 || op1.ksize != 3 || op1.stride != 2 || op1.pad != 1) return false;
+  if (op1.kind != Y3_OP_CONV || op1.dtype != op0.dtype || op1.ksize != 3 || op1.stride != 2 || op1.pad != 1) return false;
   if (op1.in_c != 32 || op1.out_c != 64 || op1.out_ld % 8 != 0 || op1.out_ld < 64) return false;
   if (op1.flags & (Y3_F_RESIDUAL | Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT)) return false;
   if (op1.d_in != op0.d_out || op1.in_h != op0.out_h || op1.in_w != op0.out_w || op1.batch != op0.batch) return false;
@@ -933,47 +936,50 @@ bool y3_conv_fused_stem_s2_supported(const y3_op &op0, const y3_op &op1) {
 
 int y3_launch_conv_fused_stem_s2(const y3_op &op0, const y3_op &op1, const void *d_in, hipStream_t s,
                                  const char **kernel_name, bool dry_run) {
-  *kernel_name = "conv_stem_s2_fused_u8_bf16";
+  *kernel_name = op0.dtype == Y3_F16 ? "conv_stem_s2_fused_u8_f16" : "conv_stem_s2_fused_u8_bf16";
   if (dry_run) return Y3_OK;
-  FusedArgs a;
-  a.in = static_cast<const unsigned char *>(d_in);
-  a.H = op0.in_h; a.W = op0.in_w; a.batch = op0.batch;
-  a.w0 = static_cast<const bf16_t *>(op0.d_weight);
-  a.sc0 = op0.d_scale; a.bi0 = op0.d_bias; a.flags0 = op0.flags;
-  a.w1 = static_cast<const bf16_t *>(op1.d_weight);
-  a.k_ld1 = op1.k_ld;
-  a.sc1 = op1.d_scale; a.bi1 = op1.d_bias; a.flags1 = op1.flags;
-  a.out = static_cast<bf16_t *>(op1.d_out);
-  a.out_ld = op1.out_ld; a.Ho = op1.out_h; a.Wo = op1.out_w;
-  a.dbg = 0;
-  static Y3DeviceOnce once;
-  int n_cu = 0;
-  {
-    const int rc = once.run([]() -> int {
-      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_stem_s2_fused_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_stem_s2_ws_kernel<4>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kPLds));
-      return Y3_OK;
-    }, &n_cu);
-    if (rc != Y3_OK) return rc;
-  }
-  const bool pipelined = y3_opt().fuse_stem != 2;                      // fuse_stem 2: the phase-by-phase kernel (A/B)
-  a.tiles_x = y3_ceil_div(a.Wo, pipelined ? kPX : kTO);
-  a.tiles_y = y3_ceil_div(a.Ho, pipelined ? kPY : kTO);
-  a.n_tiles = a.tiles_x * a.tiles_y * a.batch;
-  const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
-  if (pipelined) hipLaunchKernelGGL(conv_stem_s2_ws_kernel<4>, dim3(grid), dim3(1024), kPLds, s, a);
-  else hipLaunchKernelGGL(conv_stem_s2_fused_kernel, dim3(grid), dim3(kThreads), kLds, s, a);
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
+  return y3_by_dtype16(op0.dtype, [&](auto tag) {
+    typedef decltype(tag) T;
+    FusedArgs<T> a;
+    a.in = static_cast<const unsigned char *>(d_in);
+    a.H = op0.in_h; a.W = op0.in_w; a.batch = op0.batch;
+    a.w0 = static_cast<const T *>(op0.d_weight);
+    a.sc0 = op0.d_scale; a.bi0 = op0.d_bias; a.flags0 = op0.flags;
+    a.w1 = static_cast<const T *>(op1.d_weight);
+    a.k_ld1 = op1.k_ld;
+    a.sc1 = op1.d_scale; a.bi1 = op1.d_bias; a.flags1 = op1.flags;
+    a.out = static_cast<T *>(op1.d_out);
+    a.out_ld = op1.out_ld; a.Ho = op1.out_h; a.Wo = op1.out_w;
+    a.dbg = 0;
+    static Y3DeviceOnce once;                          // (one per element type: the lambda is instantiated per T)
+    int n_cu = 0;
+    {
+      const int rc = once.run([]() -> int {
+        Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_stem_s2_fused_kernel<T>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+        Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_stem_s2_ws_kernel<T, 4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kPLds));
+        return Y3_OK;
+      }, &n_cu);
+      if (rc != Y3_OK) return rc;
+    }
+    const bool pipelined = y3_opt().fuse_stem != 2;                      // fuse_stem 2: the phase-by-phase kernel (A/B)
+    a.tiles_x = y3_ceil_div(a.Wo, pipelined ? kPX : kTO);
+    a.tiles_y = y3_ceil_div(a.Ho, pipelined ? kPY : kTO);
+    a.n_tiles = a.tiles_x * a.tiles_y * a.batch;
+    const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
+    if (pipelined) hipLaunchKernelGGL((conv_stem_s2_ws_kernel<T, 4>), dim3(grid), dim3(1024), kPLds, s, a);
+    else hipLaunchKernelGGL(conv_stem_s2_fused_kernel<T>, dim3(grid), dim3(kThreads), kLds, s, a);
+    Y3_HIP_CHECK(hipGetLastError());
+    return Y3_OK;
+  });
 }
 
 // op0: 1x1 conv 64 -> 32 whose output only op1 reads; op1: 3x3 stride-1 conv 32 -> 64 with the shortcut operand == op0's
 // input (one Darknet-53 residual block, bf16, LeakyReLU on both)
 bool y3_conv_fused_resblock_supported(const y3_op &op0, const y3_op &op1) {
   if (!y3_opt().fuse_stem) return false;
-  if (op0.kind != Y3_OP_CONV || op1.kind != Y3_OP_CONV || op0.dtype != Y3_BF16 || op1.dtype != Y3_BF16) return false;
+  if (op0.kind != Y3_OP_CONV || op1.kind != Y3_OP_CONV || !y3_is16(op0.dtype) || op1.dtype != op0.dtype) return false;
   if (op0.ksize != 1 || op0.stride != 1 || op0.in_c != 64 || op0.out_c != 32) return false;
   if (op1.ksize != 3 || op1.stride != 1 || op1.pad != 1 || op1.in_c != 32 || op1.out_c != 64) return false;
   const uint32_t bad = Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT;
@@ -989,32 +995,35 @@ bool y3_conv_fused_resblock_supported(const y3_op &op0, const y3_op &op1) {
 
 int y3_launch_conv_fused_resblock(const y3_op &op0, const y3_op &op1, hipStream_t s, const char **kernel_name,
                                   bool dry_run) {
-  *kernel_name = "conv_resblock_fused_bf16_64_32_64";
+  *kernel_name = Y3_KNAME(op0.dtype, "conv_resblock_fused_", "_64_32_64");
   if (dry_run) return Y3_OK;
-  ResArgs a;
-  a.x = static_cast<const bf16_t *>(op0.d_in);
-  a.H = op0.in_h; a.W = op0.in_w; a.batch = op0.batch; a.x_ld = op0.in_ld;
-  a.w2 = static_cast<const bf16_t *>(op0.d_weight); a.k_ld2 = op0.k_ld; a.sc2 = op0.d_scale; a.bi2 = op0.d_bias;
-  a.w3 = static_cast<const bf16_t *>(op1.d_weight); a.k_ld3 = op1.k_ld; a.sc3 = op1.d_scale; a.bi3 = op1.d_bias;
-  a.out = static_cast<bf16_t *>(op1.d_out);
-  a.out_ld = op1.out_ld;
-  a.tiles_x = y3_ceil_div(a.W, kRT);
-  a.tiles_y = y3_ceil_div(a.H, kRT);
-  a.n_tiles = a.tiles_x * a.tiles_y * a.batch;
-  static Y3DeviceOnce once;
-  int n_cu = 0;
-  {
-    const int rc = once.run([]() -> int {
-      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_resblock_fused_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kRLds));
-      return Y3_OK;
-    }, &n_cu);
-    if (rc != Y3_OK) return rc;
-  }
-  const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
-  hipLaunchKernelGGL(conv_resblock_fused_kernel, dim3(grid), dim3(kThreads), kRLds, s, a);
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
+  return y3_by_dtype16(op0.dtype, [&](auto tag) {
+    typedef decltype(tag) T;
+    ResArgs<T> a;
+    a.x = static_cast<const T *>(op0.d_in);
+    a.H = op0.in_h; a.W = op0.in_w; a.batch = op0.batch; a.x_ld = op0.in_ld;
+    a.w2 = static_cast<const T *>(op0.d_weight); a.k_ld2 = op0.k_ld; a.sc2 = op0.d_scale; a.bi2 = op0.d_bias;
+    a.w3 = static_cast<const T *>(op1.d_weight); a.k_ld3 = op1.k_ld; a.sc3 = op1.d_scale; a.bi3 = op1.d_bias;
+    a.out = static_cast<T *>(op1.d_out);
+    a.out_ld = op1.out_ld;
+    a.tiles_x = y3_ceil_div(a.W, kRT);
+    a.tiles_y = y3_ceil_div(a.H, kRT);
+    a.n_tiles = a.tiles_x * a.tiles_y * a.batch;
+    static Y3DeviceOnce once;
+    int n_cu = 0;
+    {
+      const int rc = once.run([]() -> int {
+        Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_resblock_fused_kernel<T>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kRLds));
+        return Y3_OK;
+      }, &n_cu);
+      if (rc != Y3_OK) return rc;
+    }
+    const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
+    hipLaunchKernelGGL(conv_resblock_fused_kernel<T>, dim3(grid), dim3(kThreads), kRLds, s, a);
+    Y3_HIP_CHECK(hipGetLastError());
+    return Y3_OK;
+  });
 }
 
 Y3_STAMP_READER(y3_debug_stamps_fused)

@@ -52,13 +52,8 @@ struct HaloArgs {
 };
 
 template <typename T>
-struct MmaH;
-template <>
-struct MmaH<bf16_t> {
-  static __device__ __forceinline__ void run(f32x4 &acc, const u32x4 &w, const u32x4 &x) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x),
-                                                  acc, 0, 0, 0);
-  }
+struct MmaH {   // bf16 / IEEE half: one v_mfma_f32_16x16x32 per 64-byte K-half
+  static __device__ __forceinline__ void run(f32x4 &acc, const u32x4 &w, const u32x4 &x) { acc = y3_mfma16<T>(w, x, acc); }
 };
 template <>
 struct MmaH<float> {
@@ -566,9 +561,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     y3_bn_leaky8(v, lo, hi, sc_lo, sc_hi, bi_lo, bi_hi, leaky);
     if (has_res) {
       if constexpr (sizeof(T) == 2) {
-        const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[j]);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+        y3_add8<T>(v, resv[j]);
       } else {
         const float *rp = reinterpret_cast<const float *>(p.res) + (long long)m * p.res_ld + co;
         const f32x4 r0 = *reinterpret_cast<const f32x4 *>(rp), r1 = *reinterpret_cast<const f32x4 *>(rp + 4);
@@ -578,10 +571,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     }
     T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
     if constexpr (sizeof(T) == 2) {
-      bf16x8 ov;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) ov[r] = (bf16_t)v[r];
-      *reinterpret_cast<bf16x8 *>(op) = ov;
+      *reinterpret_cast<u32x4 *>(op) = y3_pack8<T>(v);
     } else {
       *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
       *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -866,9 +856,7 @@ __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int 
         if (oy < p.H && ox < p.W) {
           if (has_res) {
             if constexpr (sizeof(T) == 2) {
-              const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[AHEAD ? (mi & 1) : 0][r]);
-#pragma unroll
-              for (int q = 0; q < 8; ++q) v[q] += (float)rv[q];
+              y3_add8<T>(v, resv[AHEAD ? (mi & 1) : 0][r]);
             } else {
 #pragma unroll
               for (int q = 0; q < 4; ++q) { v[q] += resf[AHEAD ? (mi & 1) : 0][r][0][q]; v[4 + q] += resf[AHEAD ? (mi & 1) : 0][r][1][q]; }
@@ -876,10 +864,7 @@ __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int 
           }
           T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
           if constexpr (sizeof(T) == 2) {
-            bf16x8 ov;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) ov[q] = (bf16_t)v[q];
-            *reinterpret_cast<bf16x8 *>(op) = ov;
+            *reinterpret_cast<u32x4 *>(op) = y3_pack8<T>(v);
           } else {
             *reinterpret_cast<f32x4 *>(op) = f32x4{v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4 *>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -1050,9 +1035,8 @@ bool y3_conv_patch_fits(const y3_op &op) {
 int y3_launch_conv_patch(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
                          const char **kernel_name, bool dry_run) {
   const int es = y3_elem_size(op.dtype);
-  const bool bf = op.dtype == Y3_BF16;
   Y3_REQUIRE(y3_conv_patch_fits(op), "conv block %d: shape not supported by the patch kernel", op.block_idx);
-  *kernel_name = bf ? "conv_patch_wsp_bf16_8x32x128" : "conv_patch_wsp_f32_8x32x128";
+  *kernel_name = Y3_KNAME(op.dtype, "conv_patch_wsp_", "_8x32x128");
   if (dry_run) return Y3_OK;
   HaloArgs a;
   a.in = static_cast<const char *>(d_in);
@@ -1072,17 +1056,16 @@ int y3_launch_conv_patch(const y3_op &op, const void *d_in, const void *d_zero, 
   a.ngrp_w = a.n_tiles; a.m_tiles = 0;
   a.mul_hw = a.sh_hw = a.mul_w = a.sh_w = 0;
   a.flags = op.flags | (y3_debug_flags() ? 0x40000000u : 0u);
-  return bf ? launch_patch_wsp<bf16_t>(a, s) : launch_patch_wsp<float>(a, s);
+  return y3_by_dtype(op.dtype, [&](auto tag) { return launch_patch_wsp<decltype(tag)>(a, s); });
 }
 
 int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
                         const char **kernel_name, bool dry_run) {
   const int es = y3_elem_size(op.dtype);
-  const bool bf = op.dtype == Y3_BF16;
   Y3_REQUIRE(y3_conv_halo_ws_fits(op), "conv block %d: shape not supported by the halo kernel", op.block_idx);
   const int mi = halo_tile_fragments(op.batch * op.in_h * op.in_w, op.out_c / 128, op.in_c / (128 / es), y3_device_cus());
-  if (mi == 3) *kernel_name = bf ? "conv_halo_ws_bf16_192x128" : "conv_halo_ws_f32_192x128";
-  else *kernel_name = bf ? "conv_halo_ws_bf16_256x128" : "conv_halo_ws_f32_256x128";
+  if (mi == 3) *kernel_name = Y3_KNAME(op.dtype, "conv_halo_ws_", "_192x128");
+  else *kernel_name = Y3_KNAME(op.dtype, "conv_halo_ws_", "_256x128");
   if (dry_run) return Y3_OK;
   HaloArgs a;
   a.in = static_cast<const char *>(d_in);
@@ -1104,7 +1087,7 @@ int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, h
   fast_div((uint32_t)a.W, a.mul_w, a.sh_w);
   a.flags = op.flags | (y3_debug_flags() ? 0x40000000u : 0u);
   Y3_REQUIRE((long long)op.batch * a.HW < (1ll << 31), "conv block %d: too many pixels for the 32-bit tile index", op.block_idx);
-  return bf ? launch_halo_ws<bf16_t>(a, s) : launch_halo_ws<float>(a, s);
+  return y3_by_dtype(op.dtype, [&](auto tag) { return launch_halo_ws<decltype(tag)>(a, s); });
 }
 
 Y3_STAMP_READER(y3_debug_stamps_halo)

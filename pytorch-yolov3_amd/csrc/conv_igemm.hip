@@ -52,15 +52,10 @@ struct IgemmArgs {
 };
 
 template <typename T>
-struct Mma;
-
-template <>
-struct Mma<bf16_t> {
-  // one 128-byte K-tile = 64 bf16 = 2 MFMA k-steps of 32; a lane's 16-byte chunk = 8 k values
-  static __device__ __forceinline__ void run(f32x4 &acc, const u32x4 &w, const u32x4 &x) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w),
-                                                  __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
-  }
+struct Mma {
+  // 16-bit element types (bf16, IEEE half): one 128-byte K-tile = 64 elements = 2 MFMA k-steps of 32; a lane's 16-byte
+  // chunk = 8 k values
+  static __device__ __forceinline__ void run(f32x4 &acc, const u32x4 &w, const u32x4 &x) { acc = y3_mfma16<T>(w, x, acc); }
 };
 
 template <>
@@ -84,8 +79,7 @@ __device__ __forceinline__ void store4(char *dst, const float v[4], int nvalid) 
       f32x4 o = {v[0], v[1], v[2], v[3]};
       *reinterpret_cast<f32x4 *>(dst) = o;
     } else {
-      bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-      *reinterpret_cast<bf16x4 *>(dst) = o;
+      *reinterpret_cast<u32x2 *>(dst) = y3_pack4<TO>(v[0], v[1], v[2], v[3]);
     }
   } else {
     for (int r = 0; r < nvalid; ++r) p[r] = y3_from_float<TO>(v[r]);
@@ -263,7 +257,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += rv[r];
           } else {
-            const bf16x4 rv = *reinterpret_cast<const bf16x4 *>(rp);
+            const typename H16<T>::v4 rv = *reinterpret_cast<const typename H16<T>::v4 *>(rp);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
           }
@@ -588,11 +582,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
       y3_bn_leaky8(v, lo, hi, sc_lo, sc_hi, bi_lo, bi_hi, leaky);
       if (has_res) {
         if (res_fast) {
-          if constexpr (sizeof(T) == 2) {
-            const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[h * WR + j]);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
-          }
+          if constexpr (sizeof(T) == 2) y3_add8<T>(v, resv[h * WR + j]);
         } else {
           const T *rp = reinterpret_cast<const T *>(p.res) + (long long)m * p.res_ld + co;
           for (int r = 0; r < nvalid; ++r) v[r] += y3_to_float<T>(rp[r]);
@@ -611,10 +601,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
         bool done = false;
         if constexpr (sizeof(T) == 2) {
           if (nvalid == 8 && (p.out_ld % 8) == 0) {
-            bf16x8 ov;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) ov[r] = (bf16_t)v[r];
-            *reinterpret_cast<bf16x8 *>(op) = ov;
+            *reinterpret_cast<u32x4 *>(op) = y3_pack8<T>(v);
             done = true;
           }
         }
@@ -893,11 +880,7 @@ void conv_igemm3_kernel(IgemmArgs p) {
     y3_bn_leaky8(v, lo, hi, sc_lo, sc_hi, bi_lo, bi_hi, leaky);
     if (has_res) {
       if (res_fast) {
-        if constexpr (sizeof(T) == 2) {
-          const bf16x8 rv = __builtin_bit_cast(bf16x8, resv[j]);
-#pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
-        }
+        if constexpr (sizeof(T) == 2) y3_add8<T>(v, resv[j]);
       } else {
         const T *rp = reinterpret_cast<const T *>(p.res) + (long long)m * p.res_ld + co;
         for (int r = 0; r < nvalid; ++r) v[r] += y3_to_float<T>(rp[r]);
@@ -916,10 +899,7 @@ void conv_igemm3_kernel(IgemmArgs p) {
       bool done = false;
       if constexpr (sizeof(T) == 2) {
         if (nvalid == 8 && (p.out_ld % 8) == 0) {
-          bf16x8 ov;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) ov[r] = (bf16_t)v[r];
-          *reinterpret_cast<bf16x8 *>(op) = ov;
+          *reinterpret_cast<u32x4 *>(op) = y3_pack8<T>(v);
           done = true;
         }
       }
@@ -1048,7 +1028,8 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
   igemm_fast_div((uint32_t)a.HoWo, a.mul_hw, a.sh_hw);
   igemm_fast_div((uint32_t)a.Wo, a.mul_w, a.sh_w);
 
-  const bool bf = op.dtype == Y3_BF16;
+  const int dt = op.dtype;
+  const bool bf = y3_is16(dt);                   // a 16-bit storage mode (bf16 / IEEE half): same tiles, same selection
   // channel-tile width follows Cout so narrow layers do not multiply zero padding ...
   int bn = op.out_c > 64 ? 128 : (op.out_c > 32 ? 64 : 32);
   // ... and shrinks while the grid would leave most CUs without a workgroup (small maps / small batches: 13^2 x 8 frames
@@ -1063,27 +1044,27 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
     const bool generic = kmode != 0;
     if (generic) a.n_ktiles = y3_ceil_div(a.K, bke);
     if (bn == 128) {
-      *kernel_name = bf ? "conv_igemm_bf16_128x128" : "conv_igemm_f32_128x128";
+      *kernel_name = Y3_KNAME(dt, "conv_igemm_", "_128x128");
       if (dry_run) return Y3_OK;
-      return bf ? launch_cfg<bf16_t, 128, 128, 2, 2>(a, generic, s) : launch_cfg<float, 128, 128, 2, 2>(a, generic, s);
+      return y3_by_dtype(dt, [&](auto tag) { return launch_cfg<decltype(tag), 128, 128, 2, 2>(a, generic, s); });
     } else if (bn == 64) {
-      *kernel_name = bf ? "conv_igemm_bf16_128x64" : "conv_igemm_f32_128x64";
+      *kernel_name = Y3_KNAME(dt, "conv_igemm_", "_128x64");
       if (dry_run) return Y3_OK;
-      return bf ? launch_cfg<bf16_t, 128, 64, 2, 2>(a, generic, s) : launch_cfg<float, 128, 64, 2, 2>(a, generic, s);
+      return y3_by_dtype(dt, [&](auto tag) { return launch_cfg<decltype(tag), 128, 64, 2, 2>(a, generic, s); });
     }
-    *kernel_name = bf ? "conv_igemm_bf16_128x32" : "conv_igemm_f32_128x32";
+    *kernel_name = Y3_KNAME(dt, "conv_igemm_", "_128x32");
     if (dry_run) return Y3_OK;
-    return bf ? launch_cfg<bf16_t, 128, 32, 4, 1>(a, generic, s) : launch_cfg<float, 128, 32, 4, 1>(a, generic, s);
+    return y3_by_dtype(dt, [&](auto tag) { return launch_cfg<decltype(tag), 128, 32, 4, 1>(a, generic, s); });
   }
   if (version == 3 && bn == 128 && bm_knob == 64 && bf && !(op.flags & Y3_F_OUT_F32)) {
-    *kernel_name = "conv_igemm3_bf16_64x128";          // 64-pixel tiles: twice the workgroups, two per CU at 3 stages
+    *kernel_name = Y3_KNAME(dt, "conv_igemm3_", "_64x128");   // 64-pixel tiles: twice the workgroups, two per CU at 3 stages
     if (dry_run) return Y3_OK;
-    return launch_cfg3<bf16_t, 64, 128, 1, 4>(a, kmode, ns, s);
+    return y3_by_dtype16(dt, [&](auto tag) { return launch_cfg3<decltype(tag), 64, 128, 1, 4>(a, kmode, ns, s); });
   }
   if (version == 3 && bn == 128 && !(op.flags & Y3_F_OUT_F32)) {
-    *kernel_name = bf ? "conv_igemm3_bf16_128x128" : "conv_igemm3_f32_128x128";
+    *kernel_name = Y3_KNAME(dt, "conv_igemm3_", "_128x128");
     if (dry_run) return Y3_OK;
-    return bf ? launch_cfg3<bf16_t, 128, 128, 2, 2>(a, kmode, ns, s) : launch_cfg3<float, 128, 128, 2, 2>(a, kmode, ns, s);
+    return y3_by_dtype(dt, [&](auto tag) { return launch_cfg3<decltype(tag), 128, 128, 2, 2>(a, kmode, ns, s); });
   }
   // 96 x 64 tiles where they fit the chip in ONE round of equal workgroups and the tile above does not: yolov3-tiny's big
   // float32 layers at batch 8 are 352 / 344 tiles of 128 x 32 on 256 CUs (the CUs that get two take twice as long: 39 % of
@@ -1095,34 +1076,34 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
     const long long tcur = (long long)y3_ceil_div(a.M, 128) * y3_ceil_div(op.out_c, bn);
     const bool pays = t96 <= n_cu && t96 * 4 >= n_cu * 3 && tcur > n_cu && tcur < 2 * n_cu && a.n_ktiles >= 32;
     if (bm_knob == 96 || pays) {
-      *kernel_name = bf ? "conv_igemm2_bf16_96x64" : "conv_igemm2_f32_96x64";
+      *kernel_name = Y3_KNAME(dt, "conv_igemm2_", "_96x64");
       if (dry_run) return Y3_OK;
-      return bf ? launch_cfg2<bf16_t, 96, 64, 2, 2>(a, kmode, s) : launch_cfg2<float, 96, 64, 2, 2>(a, kmode, s);
+      return y3_by_dtype(dt, [&](auto tag) { return launch_cfg2<decltype(tag), 96, 64, 2, 2>(a, kmode, s); });
     }
   }
   if (bn == 128) {
-    *kernel_name = bf ? "conv_igemm2_bf16_128x128" : "conv_igemm2_f32_128x128";
+    *kernel_name = Y3_KNAME(dt, "conv_igemm2_", "_128x128");
     if (dry_run) return Y3_OK;
-    return bf ? launch_cfg2<bf16_t, 128, 128, 2, 2>(a, kmode, s) : launch_cfg2<float, 128, 128, 2, 2>(a, kmode, s);
+    return y3_by_dtype(dt, [&](auto tag) { return launch_cfg2<decltype(tag), 128, 128, 2, 2>(a, kmode, s); });
   } else if (bn == 64) {
-    *kernel_name = bf ? "conv_igemm2_bf16_128x64" : "conv_igemm2_f32_128x64";
+    *kernel_name = Y3_KNAME(dt, "conv_igemm2_", "_128x64");
     if (dry_run) return Y3_OK;
-    return bf ? launch_cfg2<bf16_t, 128, 64, 2, 2>(a, kmode, s) : launch_cfg2<float, 128, 64, 2, 2>(a, kmode, s);
+    return y3_by_dtype(dt, [&](auto tag) { return launch_cfg2<decltype(tag), 128, 64, 2, 2>(a, kmode, s); });
   }
-  *kernel_name = bf ? "conv_igemm2_bf16_128x32" : "conv_igemm2_f32_128x32";
+  *kernel_name = Y3_KNAME(dt, "conv_igemm2_", "_128x32");
   if (dry_run) return Y3_OK;
-  return bf ? launch_cfg2<bf16_t, 128, 32, 4, 1>(a, kmode, s) : launch_cfg2<float, 128, 32, 4, 1>(a, kmode, s);
+  return y3_by_dtype(dt, [&](auto tag) { return launch_cfg2<decltype(tag), 128, 32, 4, 1>(a, kmode, s); });
 }
 
 Y3_STAMP_READER(y3_debug_stamps_igemm)
 
 // ---- detection head: 1x1 conv (bias, no activation, float32 logits) + YOLO decode in one launch -------------------
 // op0: the head conv as the plan holds it (Y3_F_OUT_F32, Cout = anchors * attributes <= 256); op1: the Y3_OP_YOLO op
-// reading it.  bf16 networks only: the float32 parity path keeps the two kernels (sequential class loop).
+// reading it.  16-bit networks (bf16 / fp16) only: the float32 parity path keeps the two kernels (sequential class loop).
 
 bool y3_conv_head_decode_supported(const y3_op &op0, const y3_op &op1) {
   if (!y3_opt().fuse_head) return false;
-  if (op0.kind != Y3_OP_CONV || op1.kind != Y3_OP_YOLO || op0.dtype != Y3_BF16) return false;
+  if (op0.kind != Y3_OP_CONV || op1.kind != Y3_OP_YOLO || !y3_is16(op0.dtype)) return false;
   if (op0.ksize != 1 || op0.stride != 1 || !(op0.flags & Y3_F_OUT_F32)) return false;
   if (op0.flags & (Y3_F_LEAKY | Y3_F_RESIDUAL | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT)) return false;
   if (!y3_conv_igemm_supported(op0) || op0.in_c % 64 != 0 || op0.out_c > 256 || op0.cout_pad < 256) return false;
@@ -1134,7 +1115,7 @@ bool y3_conv_head_decode_supported(const y3_op &op0, const y3_op &op1) {
 
 int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d_zero, hipStream_t s,
                                const char **kernel_name, bool dry_run) {
-  *kernel_name = "conv_head_decode_bf16_64x256";
+  *kernel_name = Y3_KNAME(op0.dtype, "conv_head_decode_", "_64x256");
   if (dry_run) return Y3_OK;
   IgemmArgs a;
   a.in = static_cast<const char *>(op0.d_in);
@@ -1168,7 +1149,9 @@ int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d
   a.n_tiles = 1;
   a.n_major = 0;
   a.m_tiles = y3_ceil_div(a.M, 64);
-  hipLaunchKernelGGL((conv_igemm2_kernel<bf16_t, 64, 256, 1, 4, 0, true>), dim3(a.m_tiles), dim3(256), 0, s, a);
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
+  return y3_by_dtype16(op0.dtype, [&](auto tag) {
+    hipLaunchKernelGGL((conv_igemm2_kernel<decltype(tag), 64, 256, 1, 4, 0, true>), dim3(a.m_tiles), dim3(256), 0, s, a);
+    Y3_HIP_CHECK(hipGetLastError());
+    return Y3_OK;
+  });
 }

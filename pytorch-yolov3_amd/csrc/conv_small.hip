@@ -88,10 +88,7 @@ __global__ __launch_bounds__(256) void conv_stem3x3_kernel(SmallArgs p) {
     }
     if (nvalid == 8 && (p.out_ld % 8) == 0) {
       if constexpr (sizeof(TO) == 2) {
-        bf16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
-        *reinterpret_cast<bf16x8 *>(orow + co) = o;
+        *reinterpret_cast<u32x4 *>(orow + co) = y3_pack8<TO>(v);
       } else {
         *reinterpret_cast<f32x4 *>(orow + co) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4 *>(orow + co + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -109,12 +106,13 @@ __global__ __launch_bounds__(256) void conv_stem3x3_kernel(SmallArgs p) {
 // every wave builds the im2col fragments of its two pixel rows straight from that image: for one filter row the
 // 9 values (kx, c) of a pixel are 9 consecutive bf16, so K is ordered k = ky*9 + kx*3 + c_mem and the host
 // permutes the weights to match (c_mem = 2 - c_rgb: the BGR->RGB flip costs nothing).
+template <typename T>
 struct StemMfmaArgs {
   const uint8_t *in;       // (B, H, W, 3) uint8 BGR
-  const bf16_t *wgt;       // [32][32] bf16: row = output channel, k as above, zero padded
+  const T *wgt;       // [32][32] bf16: row = output channel, k as above, zero padded
   const float *scale;
   const float *bias;
-  bf16_t *out;
+  T *out;
   int B, H, W, Cout, out_ld, tiles_x, tiles_y;
   uint32_t flags;
 };
@@ -122,8 +120,10 @@ struct StemMfmaArgs {
 constexpr int kStemTH = 8, kStemTW = 32;
 constexpr int kStemRow = (kStemTW + 2) * 3 + 2;   // bf16 elements per halo row (102 used, padded to 104)
 
-__global__ __launch_bounds__(256) void conv_stem_mfma_kernel(StemMfmaArgs p) {
-  __shared__ __attribute__((aligned(16))) bf16_t tile[(kStemTH + 2) * kStemRow];
+template <typename T>
+__global__ __launch_bounds__(256) void conv_stem_mfma_kernel(StemMfmaArgs<T> p) {
+  typedef typename H16<T>::v8 V8;
+  __shared__ __attribute__((aligned(16))) T tile[(kStemTH + 2) * kStemRow];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bid = blockIdx.x;
   const int tx = bid % p.tiles_x;
@@ -141,13 +141,13 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(StemMfmaArgs p) {
     float v = 0.f;
     if ((unsigned)iy < (unsigned)p.H && ixb >= 0 && ixb < p.W * 3)
       v = (float)p.in[((long long)b * p.H + iy) * p.W * 3 + ixb] / 255.0f;
-    tile[r * kStemRow + cb] = (bf16_t)v;
+    tile[r * kStemRow + cb] = (T)v;
   }
 
   // ---- weights: two A fragments (channels 0-15, 16-31), lane (co = lane&15, q = lane>>4) holds k = 8q..8q+7
   const int fr = lane & 15, fq = lane >> 4;
-  const bf16x8 w0 = *reinterpret_cast<const bf16x8 *>(p.wgt + (0 + fr) * 32 + fq * 8);
-  const bf16x8 w1 = *reinterpret_cast<const bf16x8 *>(p.wgt + (16 + fr) * 32 + fq * 8);
+  const V8 w0 = *reinterpret_cast<const V8 *>(p.wgt + (0 + fr) * 32 + fq * 8);
+  const V8 w1 = *reinterpret_cast<const V8 *>(p.wgt + (16 + fr) * 32 + fq * 8);
   // per-lane LDS element offsets of k = 8q + j relative to the pixel's first byte in halo row `row`
   int koff[8];
 #pragma unroll
@@ -174,16 +174,16 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(StemMfmaArgs p) {
 #pragma unroll
     for (int gx = 0; gx < kStemTW / 16; ++gx) {
       const int px = gx * 16 + fr;
-      const bf16_t *base = tile + row * kStemRow + px * 3;
-      bf16x8 xf;
+      const T *base = tile + row * kStemRow + px * 3;
+      V8 xf;
 #pragma unroll
       for (int j = 0; j < 8; ++j) xf[j] = base[koff[j]];
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, xf, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, xf, acc1, 0, 0, 0);
+      acc0 = H16<T>::mfma(w0, xf, acc0);
+      acc1 = H16<T>::mfma(w1, xf, acc1);
       const int ox = x0 + px;
       if (oy < p.H && ox < p.W) {
-        bf16_t *op = p.out + (((long long)b * p.H + oy) * p.W + ox) * p.out_ld;
+        T *op = p.out + (((long long)b * p.H + oy) * p.W + ox) * p.out_ld;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           const f32x4 a = ni ? acc1 : acc0;
@@ -196,11 +196,10 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(StemMfmaArgs p) {
             v[r] = t;
           }
           if (co + 4 <= p.Cout) {
-            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-            *reinterpret_cast<bf16x4 *>(op + co) = o;
+            *reinterpret_cast<u32x2 *>(op + co) = y3_pack4<T>(v[0], v[1], v[2], v[3]);
           } else {
             for (int r = 0; r < 4; ++r)
-              if (co + r < p.Cout) op[co + r] = (bf16_t)v[r];
+              if (co + r < p.Cout) op[co + r] = (T)v[r];
           }
         }
       }
@@ -285,46 +284,45 @@ int y3_launch_conv_small(const y3_op &op, const void *d_in, hipStream_t s, const
   a.M = op.batch * op.out_h * op.out_w;
   a.flags = op.flags;
   const bool u8 = op.flags & Y3_F_IN_NHWC_U8BGR;
-  const bool out_bf16 = op.dtype == Y3_BF16 && !(op.flags & Y3_F_OUT_F32);
-  *kernel_name = u8 ? (out_bf16 ? "conv_stem3x3_u8_bf16" : "conv_stem3x3_u8_f32")
-                    : (out_bf16 ? "conv_stem3x3_nchw_bf16" : "conv_stem3x3_nchw_f32");
+  const int odt = (op.flags & Y3_F_OUT_F32) ? Y3_F32 : op.dtype;   // element type of the output
+  *kernel_name = u8 ? Y3_KNAME(odt, "conv_stem3x3_u8_", "") : Y3_KNAME(odt, "conv_stem3x3_nchw_", "");
   if (dry_run) return Y3_OK;
   const dim3 grid(y3_ceil_div(a.M, 256)), block(256);
   const size_t lds = ((size_t)27 * op.cout_pad + 256) * sizeof(float);
-  if (u8) {
-    if (out_bf16) hipLaunchKernelGGL((conv_stem3x3_kernel<bf16_t, 1>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((conv_stem3x3_kernel<float, 1>), grid, block, lds, s, a);
-  } else {
-    if (out_bf16) hipLaunchKernelGGL((conv_stem3x3_kernel<bf16_t, 0>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((conv_stem3x3_kernel<float, 0>), grid, block, lds, s, a);
-  }
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
+  return y3_by_dtype(odt, [&](auto tag) {
+    if (u8) hipLaunchKernelGGL((conv_stem3x3_kernel<decltype(tag), 1>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((conv_stem3x3_kernel<decltype(tag), 0>), grid, block, lds, s, a);
+    Y3_HIP_CHECK(hipGetLastError());
+    return Y3_OK;
+  });
 }
 
 // MFMA stem: needs weights in its own layout (bf16 [32][32], see yolov3/darknet.py) -> separate conv path (3)
 bool y3_conv_stem_mfma_supported(const y3_op &op) {
-  return (op.flags & Y3_F_IN_NHWC_U8BGR) && !(op.flags & (Y3_F_OUT_F32 | Y3_F_RESIDUAL)) && op.dtype == Y3_BF16 &&
+  return (op.flags & Y3_F_IN_NHWC_U8BGR) && !(op.flags & (Y3_F_OUT_F32 | Y3_F_RESIDUAL)) && y3_is16(op.dtype) &&
          op.in_c == 3 && op.ksize == 3 && op.stride == 1 && op.pad == 1 && op.out_c <= 32 && op.out_ld % 4 == 0;
 }
 
 int y3_launch_conv_stem_mfma(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
                              bool dry_run) {
   Y3_REQUIRE(y3_conv_stem_mfma_supported(op), "conv block %d: not a shape for the MFMA stem", op.block_idx);
-  *kernel_name = "conv_stem_mfma_u8_bf16";
+  *kernel_name = op.dtype == Y3_F16 ? "conv_stem_mfma_u8_f16" : "conv_stem_mfma_u8_bf16";
   if (dry_run) return Y3_OK;
-  StemMfmaArgs a;
-  a.in = static_cast<const uint8_t *>(d_in);
-  a.wgt = static_cast<const bf16_t *>(op.d_weight);
-  a.scale = op.d_scale; a.bias = op.d_bias;
-  a.out = static_cast<bf16_t *>(op.d_out);
-  a.B = op.batch; a.H = op.in_h; a.W = op.in_w; a.Cout = op.out_c; a.out_ld = op.out_ld;
-  a.tiles_x = y3_ceil_div(op.in_w, kStemTW);
-  a.tiles_y = y3_ceil_div(op.in_h, kStemTH);
-  a.flags = op.flags;
-  hipLaunchKernelGGL(conv_stem_mfma_kernel, dim3(a.tiles_x * a.tiles_y * op.batch), dim3(256), 0, s, a);
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
+  return y3_by_dtype16(op.dtype, [&](auto tag) {
+    typedef decltype(tag) T;
+    StemMfmaArgs<T> a;
+    a.in = static_cast<const uint8_t *>(d_in);
+    a.wgt = static_cast<const T *>(op.d_weight);
+    a.scale = op.d_scale; a.bias = op.d_bias;
+    a.out = static_cast<T *>(op.d_out);
+    a.B = op.batch; a.H = op.in_h; a.W = op.in_w; a.Cout = op.out_c; a.out_ld = op.out_ld;
+    a.tiles_x = y3_ceil_div(op.in_w, kStemTW);
+    a.tiles_y = y3_ceil_div(op.in_h, kStemTH);
+    a.flags = op.flags;
+    hipLaunchKernelGGL(conv_stem_mfma_kernel<T>, dim3(a.tiles_x * a.tiles_y * op.batch), dim3(256), 0, s, a);
+    Y3_HIP_CHECK(hipGetLastError());
+    return Y3_OK;
+  });
 }
 
 int y3_launch_conv_direct(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name,
@@ -338,11 +336,12 @@ int y3_launch_conv_direct(const y3_op &op, const void *d_in, hipStream_t s, cons
   a.total = (long long)op.batch * op.out_h * op.out_w * op.out_c;
   a.flags = op.flags;
   Y3_REQUIRE(op.k_ld >= op.ksize * op.ksize * op.in_c, "conv block %d: k_ld too small", op.block_idx);
-  *kernel_name = op.dtype == Y3_BF16 ? "conv_direct_bf16" : "conv_direct_f32";
+  *kernel_name = Y3_KNAME(op.dtype, "conv_direct_", "");
   if (dry_run) return Y3_OK;
   const dim3 grid((unsigned)((a.total + 255) / 256)), block(256);
-  if (op.dtype == Y3_BF16) hipLaunchKernelGGL(conv_direct_kernel<bf16_t>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(conv_direct_kernel<float>, grid, block, 0, s, a);
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
+  return y3_by_dtype(op.dtype, [&](auto tag) {
+    hipLaunchKernelGGL(conv_direct_kernel<decltype(tag)>, grid, block, 0, s, a);
+    Y3_HIP_CHECK(hipGetLastError());
+    return Y3_OK;
+  });
 }

@@ -32,9 +32,10 @@ __device__ __forceinline__ void load_vec(const T *p, float out[VEC]) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) out[j] = f[j];
     } else {
-      const bf16x8 h = __builtin_bit_cast(bf16x8, raw);
+      float v8[8];
+      y3_unpack8<T>(v8, raw);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) out[j] = (float)h[j];
+      for (int j = 0; j < 8; ++j) out[j] = v8[j];
     }
   }
 }
@@ -46,10 +47,10 @@ __device__ __forceinline__ void store_vec(T *p, const float in[VEC]) {
   } else if constexpr (sizeof(T) == 4) {
     *reinterpret_cast<f32x4 *>(p) = f32x4{in[0], in[1], in[2], in[3]};
   } else {
-    bf16x8 h;
+    float v8[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) h[j] = (bf16_t)in[j];
-    *reinterpret_cast<bf16x8 *>(p) = h;
+    for (int j = 0; j < 8; ++j) v8[j] = in[j];
+    *reinterpret_cast<u32x4 *>(p) = y3_pack8<T>(v8);
   }
 }
 
@@ -169,13 +170,12 @@ int launch_layer(Which w, const y3_op &op, const void *d_in, hipStream_t s, bool
   if (w == ADD) wide = wide && op.res_ld % vec == 0 && ((uintptr_t)op.d_res % 16 == 0);
   a.total = (long long)op.batch * op.out_h * op.out_w * (wide ? op.in_c / vec : op.in_c);
   if (dry_run) return Y3_OK;
-  if (op.dtype == Y3_BF16) {
-    if (wide) launch_one<bf16_t, 8>(w, a, s); else launch_one<bf16_t, 1>(w, a, s);
-  } else {
-    if (wide) launch_one<float, 4>(w, a, s); else launch_one<float, 1>(w, a, s);
-  }
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
+  return y3_by_dtype(op.dtype, [&](auto tag) {
+    typedef decltype(tag) T;
+    if (wide) launch_one<T, 16 / sizeof(T)>(w, a, s); else launch_one<T, 1>(w, a, s);
+    Y3_HIP_CHECK(hipGetLastError());
+    return Y3_OK;
+  });
 }
 
 }  // namespace
@@ -189,7 +189,7 @@ int y3_launch_maxpool(const y3_op &op, const void *d_in, hipStream_t s, const ch
     Y3_REQUIRE(op.out_h == (op.in_h - op.ksize) / op.stride + 1 && op.out_w == (op.in_w - op.ksize) / op.stride + 1,
                "maxpool block %d: output size mismatch", op.block_idx);
   }
-  *kernel_name = op.dtype == Y3_BF16 ? "maxpool_bf16" : "maxpool_f32";
+  *kernel_name = Y3_KNAME(op.dtype, "maxpool_", "");
   return launch_layer(MAXPOOL, op, d_in, s, dry_run);
 }
 
@@ -197,19 +197,19 @@ int y3_launch_upsample(const y3_op &op, const void *d_in, hipStream_t s, const c
                        bool dry_run) {
   Y3_REQUIRE(op.stride >= 1 && op.out_h == op.in_h * op.stride && op.out_w == op.in_w * op.stride,
              "upsample block %d: output size mismatch", op.block_idx);
-  *kernel_name = op.dtype == Y3_BF16 ? "upsample_bf16" : "upsample_f32";
+  *kernel_name = Y3_KNAME(op.dtype, "upsample_", "");
   return launch_layer(UPSAMPLE, op, d_in, s, dry_run);
 }
 
 int y3_launch_add(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name, bool dry_run) {
   Y3_REQUIRE(op.out_h == op.in_h && op.out_w == op.in_w, "add block %d: size mismatch", op.block_idx);
-  *kernel_name = op.dtype == Y3_BF16 ? "add_bf16" : "add_f32";
+  *kernel_name = Y3_KNAME(op.dtype, "add_", "");
   return launch_layer(ADD, op, d_in, s, dry_run);
 }
 
 int y3_launch_copy(const y3_op &op, const void *d_in, hipStream_t s, const char **kernel_name, bool dry_run) {
   Y3_REQUIRE(op.out_h == op.in_h && op.out_w == op.in_w, "copy block %d: size mismatch", op.block_idx);
-  *kernel_name = op.dtype == Y3_BF16 ? "copy_bf16" : "copy_f32";
+  *kernel_name = Y3_KNAME(op.dtype, "copy_", "");
   return launch_layer(COPY, op, d_in, s, dry_run);
 }
 
@@ -241,8 +241,9 @@ __device__ __forceinline__ u32x4 vmax16(const u32x4 &a, const u32x4 &b) {
     const f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b);
     return __builtin_bit_cast(u32x4, f32x4{fmaxf(x[0], y[0]), fmaxf(x[1], y[1]), fmaxf(x[2], y[2]), fmaxf(x[3], y[3])});
   } else {
-    const bf16x8 x = __builtin_bit_cast(bf16x8, a), y = __builtin_bit_cast(bf16x8, b);
-    bf16x8 r;
+    typedef typename H16<T>::v8 V8;
+    const V8 x = __builtin_bit_cast(V8, a), y = __builtin_bit_cast(V8, b);
+    V8 r;
 #pragma unroll
     for (int j = 0; j < 8; ++j) r[j] = (float)x[j] >= (float)y[j] ? x[j] : y[j];
     return __builtin_bit_cast(u32x4, r);
@@ -336,7 +337,7 @@ bool y3_maxpool_spp_supported(const y3_op &a, const y3_op &b, const y3_op &c) {
 
 int y3_launch_maxpool_spp(const y3_op &a, const y3_op &b, const y3_op &c, hipStream_t s, const char **kernel_name,
                           bool dry_run) {
-  *kernel_name = a.dtype == Y3_BF16 ? "maxpool_spp_pyramid_bf16" : "maxpool_spp_pyramid_f32";
+  *kernel_name = Y3_KNAME(a.dtype, "maxpool_spp_pyramid_", "");
   if (dry_run) return Y3_OK;
   const y3_op *o[3] = {&a, &b, &c};
   SppArgs p;
@@ -350,10 +351,11 @@ int y3_launch_maxpool_spp(const y3_op &a, const y3_op &b, const y3_op &c, hipStr
   }
   const size_t lds = spp_lds_bytes(a);
   const dim3 grid((unsigned)(a.batch * p.cgroups)), block(256);
-  if (a.dtype == Y3_BF16) hipLaunchKernelGGL((maxpool_spp_kernel<bf16_t>), grid, block, lds, s, p);
-  else hipLaunchKernelGGL((maxpool_spp_kernel<float>), grid, block, lds, s, p);
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
+  return y3_by_dtype(a.dtype, [&](auto tag) {
+    hipLaunchKernelGGL((maxpool_spp_kernel<decltype(tag)>), grid, block, lds, s, p);
+    Y3_HIP_CHECK(hipGetLastError());
+    return Y3_OK;
+  });
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -28,7 +28,7 @@ _MODEL_OPTIONS = [
     (("-p", "--prob-thresh"), dict(type=float, default=0.05, metavar="<prob>", help="keep detections scoring at least this (default 0.05)")),
     (("-i", "--iou-thresh"), dict(type=float, default=0.3, metavar="<iou>", help="NMS overlap above which the weaker box goes (default 0.3)")),
     (("-n", "--class-names"), dict(type=pathlib.Path, metavar="<path>", help="text file, one class name per line; labels show indices without it")),
-    (("--dtype",), dict(default="float32", choices=["float32", "bf16"], help="conv arithmetic: float32 (the reference's; default, boxes and scores within 1e-3 of its CPU path) or bf16 (about 7x the frames/s; scores within ~1e-2)")),
+    (("--dtype",), dict(default="float32", choices=["float32", "fp16", "bf16"], help="conv arithmetic: float32 (the reference's; default, boxes and scores within 1e-3 of its CPU path), fp16 or bf16 storage with float32 accumulation (about 7x the frames/s; scores within ~1e-3 / ~1e-2)")),
     (("-b", "--batch-size"), dict(type=int, default=16, metavar="<n>", help="frames per GPU batch for folders and videos (default 16)")),
 ]
 _OUTPUT_OPTIONS = [

@@ -23,7 +23,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # Y3_HIP_LIB: developer override (e.g. the diagnostic build with in-kernel phase stamps)
 LIB_PATH = os.environ.get("Y3_HIP_LIB") or os.path.join(_HERE, "..", "lib", "libyolov3_hip.so")
 
-Y3_F32, Y3_BF16 = 0, 1
+Y3_F32, Y3_BF16, Y3_F16 = 0, 1, 2
 OP_CONV, OP_MAXPOOL, OP_UPSAMPLE, OP_ADD, OP_COPY, OP_YOLO = 1, 2, 3, 4, 5, 6
 F_LEAKY, F_RESIDUAL, F_OUT_F32, F_IN_NCHW_F32, F_IN_NHWC_U8BGR, F_PLAN_INPUT, F_FUSE_NEXT = 1, 2, 4, 8, 16, 32, 64
 PATH_IGEMM, PATH_STEM, PATH_DIRECT, PATH_STEM_MFMA = 0, 1, 2, 3
@@ -64,7 +64,7 @@ AM_DEFAULT = AM_HALO_WIDE | AM_HALO_NARROW | AM_IGEMM3_1X1_DEEP | AM_HALO_MID | 
 AM_IGEMM_ONLY = 0
 AM_HALO_ALL = AM_HALO_WIDE | AM_HALO_NARROW | AM_HALO_MID          # conv_bench: the halo kernel wherever it fits
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/yolov3_hip.h declares

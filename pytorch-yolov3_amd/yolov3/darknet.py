@@ -9,7 +9,8 @@ What is different underneath: no nn.Module graph.  ``forward`` compiles (once pe
 shape) a flat op plan (yolov3/plan.py) and hands it to libyolov3_hip.so through the C ABI
 (include/yolov3_hip.h); activations are NHWC in an arena, BN is a per-channel scale/bias in
 the conv epilogue, shortcuts/routes/head-concat are fused away.  Extension over the
-reference: ``dtype="bf16"`` (bf16 storage, fp32 accumulate) and uint8 BGR frame input with
+reference: ``dtype="bf16"`` / ``dtype="fp16"`` (16-bit storage, fp32 accumulate: the same kernels on the
+bf16 / f16 MFMA, same rate; fp16 keeps 11 significand bits instead of 8) and uint8 BGR frame input with
 the BGR->RGB, /255 preprocessing fused into the first conv (``forward_frames``).
 """
 import ctypes
@@ -34,6 +35,23 @@ def f32_to_bf16_bits(a):
     u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
     r = ((u >> np.uint64(16)) & np.uint64(1)) + np.uint64(0x7FFF)
     return ((u + r) >> np.uint64(16)).astype(np.uint16)
+
+
+def f32_to_f16_bits(a):
+    """Round-to-nearest-even float32 -> IEEE half bit patterns (uint16); subnormals kept, overflow -> inf (numpy's
+    conversion, the same rounding as v_cvt_f16_f32 and torch's ``.half()``)."""
+    with np.errstate(over="ignore"):
+        return np.ascontiguousarray(a, dtype=np.float32).astype(np.float16).view(np.uint16)
+
+
+# storage modes: name -> (C ABI element type, bytes per element, torch view dtype, host rounding to bit patterns)
+DTYPES = {
+    "float32": (_hip.Y3_F32, 4, torch.float32, None),
+    "bf16": (_hip.Y3_BF16, 2, torch.bfloat16, f32_to_bf16_bits),
+    "fp16": (_hip.Y3_F16, 2, torch.float16, f32_to_f16_bits),
+}
+DTYPE_ALIASES = {"float32": "float32", "fp32": "float32", "f32": "float32", "bf16": "bf16", "bfloat16": "bf16",
+                 "fp16": "fp16", "f16": "fp16", "float16": "fp16", "half": "fp16"}
 
 
 class BlockInfo(object):
@@ -78,8 +96,9 @@ class Darknet(object):
             device (str): "cpu" [default, like the reference: darknet.py:319] only builds the description;
                 ``forward`` needs "cuda" / "cuda:N" (an MI355X): pass it here or call ``.cuda()`` as the
                 reference's command line does (__main__.py:119-120).
-            dtype (str): "float32" (parity path, exact fp32 MFMA) or "bf16"
-                (bf16 activations/weights, fp32 accumulation; throughput path).
+            dtype (str): "float32" (parity path, exact fp32 MFMA), "bf16" (bf16 activations/weights, fp32
+                accumulation; the benchmarked throughput path) or "fp16" (IEEE half storage, same kernels and rate,
+                eight times finer rounding: the throughput path closest to the reference's float32 results).
         """
         self.blocks, self.net_info = parse_config(config_fpath)
         if self.net_info is None:
@@ -95,8 +114,7 @@ class Darknet(object):
         self.device = device
         self.header = None
         self.training = False
-        self.dtype = {"float32": "float32", "fp32": "float32", "f32": "float32",
-                      "bf16": "bf16", "bfloat16": "bf16"}[str(dtype).replace("torch.", "")]
+        self.dtype = DTYPE_ALIASES[str(dtype).replace("torch.", "")]
 
         # absolute route indices + cache set, as the reference computes them (darknet.py:334-349)
         self.blocks_to_cache = set()
@@ -190,8 +208,11 @@ class Darknet(object):
             bias = p["bias"].astype(np.float32)
         return scale, bias
 
-    def _device_weights(self, slot, path, elem_bf16, dev):
-        key = (slot, path, elem_bf16, str(dev))
+    def _device_weights(self, slot, path, dtype, dev):
+        """Device copies of one conv's parameters in the layout of kernel family ``path``, weights rounded to the
+        storage type ``dtype`` ("float32" / "bf16" / "fp16")."""
+        key = (slot, path, dtype, str(dev))
+        es, to_bits = DTYPES[dtype][1], DTYPES[dtype][3]
         if key in self._dev_weights:
             return self._dev_weights[key]
         c = self._convs[slot]
@@ -199,14 +220,14 @@ class Darknet(object):
         w = self._params[slot]["weight"].astype(np.float32)
         scale, bias = self._fold_bn(slot)
         if path == _hip.PATH_STEM_MFMA:
-            # bf16 [32][32]: row = output channel, k = ky*9 + kx*3 + c_mem with c_mem the BYTE order of the
+            # 16-bit [32][32]: row = output channel, k = ky*9 + kx*3 + c_mem with c_mem the BYTE order of the
             # uint8 BGR frame (c_mem = 2 - c_rgb), zero padded (csrc/conv_small.hip: conv_stem_mfma_kernel)
             cout_pad = 32
             k_ld = 32
             host = np.zeros((32, 32), dtype=np.float32)
             wk = w[:, ::-1, :, :].transpose(0, 2, 3, 1).reshape(cout, 27)      # (co, ky, kx, c_mem)
             host[:cout, :27] = wk
-            dw = torch.from_numpy(f32_to_bf16_bits(host).view(np.int16)).to(dev)
+            dw = torch.from_numpy(to_bits(host).view(np.int16)).to(dev)
         elif path == _hip.PATH_STEM:
             cout_pad = _round_up(cout, 8)
             k_ld = cout_pad
@@ -214,13 +235,12 @@ class Darknet(object):
             host[:, :cout] = w.transpose(2, 3, 1, 0).reshape(k * k * cin, cout)
             dw = torch.from_numpy(host).to(dev)
         else:
-            es = 2 if elem_bf16 else 4
             cout_pad = _round_up(cout, 128)
             k_ld = _round_up(k * k * cin, 128 // es)
             host = np.zeros((cout_pad, k_ld), dtype=np.float32)
             host[:cout, :k * k * cin] = w.transpose(0, 2, 3, 1).reshape(cout, k * k * cin)
-            if elem_bf16:
-                dw = torch.from_numpy(f32_to_bf16_bits(host).view(np.int16)).to(dev)
+            if to_bits is not None:
+                dw = torch.from_numpy(to_bits(host).view(np.int16)).to(dev)
             else:
                 dw = torch.from_numpy(host).to(dev)
         sc = np.zeros(cout_pad, dtype=np.float32)
@@ -247,8 +267,8 @@ class Darknet(object):
             raise RuntimeError("call load_weights() / set_params() before forward()")
         dev = self._torch_device()
         lib = _hip.lib()
-        bf16 = self.dtype == "bf16"
-        es = 2 if bf16 else 4
+        c_dtype, es = DTYPES[self.dtype][0], DTYPES[self.dtype][1]
+        bf16 = es == 2                       # a 16-bit storage mode (bf16 or fp16)
         desc = build_plan(self.blocks, self.net_info, batch, height, width, es, reuse=not self.keep_all, fuse=self.fuse)
         cp = _CompiledPlan()
         cp.batch = batch
@@ -275,7 +295,7 @@ class Darknet(object):
         for n, od in enumerate(desc["ops"]):
             op = ops[n]
             kind = od["kind"]
-            op.dtype = _hip.Y3_BF16 if bf16 else _hip.Y3_F32
+            op.dtype = c_dtype
             op.batch = batch
             op.block_idx = od["block"]
             tin = od["inp"]
@@ -310,7 +330,7 @@ class Darknet(object):
                 op.cout_pad = _round_up(c["cout"], 128)
                 op.k_ld = _round_up(c["k"] * c["k"] * c["cin"], 128 // es)
                 path = lib.y3_conv_path(ctypes.byref(op))     # (does not depend on the plan options)
-                wts = self._device_weights(od["slot"], path, bf16, dev)
+                wts = self._device_weights(od["slot"], path, self.dtype, dev)
                 op.cout_pad, op.k_ld = wts["cout_pad"], wts["k_ld"]
                 op.d_weight = wts["weight"].data_ptr()
                 op.d_scale = wts["scale"].data_ptr()
@@ -428,11 +448,11 @@ class Darknet(object):
         t = cp.desc["tensor_of"][i]
         if t is None:
             raise ValueError("block {} is fused into its consumer and never materialised".format(i))
-        es = 4 if (t.f32 or self.dtype != "bf16") else 2
+        es = 4 if t.f32 else DTYPES[self.dtype][1]
         start = cp.desc["offsets"][t.buf]
         nelem = cp.batch * t.h * t.w * t.ld
         raw = cp.arena[start:start + nelem * es]
-        arr = raw.view(torch.float32 if es == 4 else torch.bfloat16).reshape(cp.batch, t.h, t.w, t.ld)
+        arr = raw.view(torch.float32 if es == 4 else DTYPES[self.dtype][2]).reshape(cp.batch, t.h, t.w, t.ld)
         return arr[:, :, :, t.off:t.off + t.c].permute(0, 3, 1, 2).float().contiguous()
 
     def plan_report(self):

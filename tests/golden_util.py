@@ -143,9 +143,10 @@ def compare_detections(g, prefix, det, rows=None, prob_tol=1e-5, cand=None):
     return len(diff), bad, len(flipped)
 
 
-def bf16_agreement():
-    """tests/golden/bf16_agreement.json (tools/make_bf16_fixture.py): what the bf16-emulating oracle reaches against
-    the reference's float32 detections on the G7 frames -- the floor for the HIP bf16 path."""
+def bf16_agreement(emulate="bf16"):
+    """tests/golden/bf16_agreement.json / f16_agreement.json (tools/make_bf16_fixture.py [--emulate f16]): what the oracle
+    emulating that storage type reaches against the reference's float32 detections on the G7 frames -- the floor for the
+    HIP bf16 / fp16 path."""
     import json
-    with open(os.path.join(GOLDEN, "bf16_agreement.json")) as fh:
+    with open(os.path.join(GOLDEN, "%s_agreement.json" % emulate)) as fh:
         return json.load(fh)

@@ -167,7 +167,7 @@ def test_resize_and_prepare_frames():
 def test_library_loads_and_exports_every_declared_symbol():
     from yolov3 import _hip
     lib = _hip.lib()
-    assert lib.y3_abi_version() == _hip.ABI_VERSION == 4
+    assert lib.y3_abi_version() == _hip.ABI_VERSION == 5
     with open(os.path.join(ROOT, "include", "yolov3_hip.h")) as fh:
         header = fh.read()
     declared = set(re.findall(r"\b(y3_[a-z0-9_]+)\s*\(", header))

@@ -7,6 +7,9 @@ The reference has no bf16 mode; the bf16-emulating oracle (oracle/darknet_oracle
 row) and the score differences on the common rows, for the oracle accumulating in float32 and in float64 (the spread
 between the two is the summation-order noise).  tests/test_gpu_bf16.py and bench.py (``bf16_agreement``) compare the HIP
 bf16 path with these floors.  Runs on CPU, needs nothing outside the repository:  python tools/make_bf16_fixture.py
+
+``--emulate f16`` (round 5) writes tests/golden/f16_agreement.json instead: the same table for the fp16 storage mode
+(``OracleDarknet.forward(emulate="f16")``), the floors of the ``dtype="fp16"`` HIP path.
 """
 import json
 import os
@@ -51,7 +54,7 @@ def bench_regime():
         for name in (str(n) for n in g["names"]):
             frame = bench_regime_frame(name, dim)
             x = torch.from_numpy(orc.frames_to_input([resize_bilinear_u8(frame, dim, dim)]))
-            o = net.forward(x, emulate_bf16=True, accumulate="f32")
+            o = net.forward(x, emulate=EMULATE, accumulate="f32")
             for tag in ("a", "b"):
                 pth, ith = g[tag + "_thresholds"]
                 det = orc.postprocess(o["bbox_xywh"].numpy(), o["class_prob"].numpy(), o["class_idx"].numpy(), [frame.shape],
@@ -82,7 +85,7 @@ def planted():
     pool = {t: [0, 0, 0, 0] for t in ("a", "b")}
     for name in (str(n) for n in g["names"]):
         frame = resize_bilinear_u8(load_jpeg_bgr("000000%s.jpg" % name), 608, 608)
-        o = net.forward(torch.from_numpy(orc.frames_to_input([frame])), emulate_bf16=True, accumulate="f32")
+        o = net.forward(torch.from_numpy(orc.frames_to_input([frame])), emulate=EMULATE, accumulate="f32")
         for tag in ("a", "b"):
             pth, ith = g[tag + "_thresholds"]
             det = orc.postprocess(o["bbox_xywh"].numpy(), o["class_prob"].numpy(), o["class_idx"].numpy(), [frame.shape],
@@ -104,9 +107,18 @@ def planted():
     return entry
 
 
+EMULATE = "bf16"
+
+
 def main():
-    path = os.path.join(GOLDEN, "bf16_agreement.json")
-    if sys.argv[1:] == ["planted"]:                    # only that section (the rest takes minutes)
+    global EMULATE
+    argv = sys.argv[1:]
+    if argv[:1] == ["--emulate"]:
+        EMULATE = argv[1]
+        argv = argv[2:]
+    assert EMULATE in ("bf16", "f16")
+    path = os.path.join(GOLDEN, "%s_agreement.json" % EMULATE)
+    if argv == ["planted"]:                    # only that section (the rest takes minutes)
         with open(path) as fh:
             table = json.load(fh)
         table["planted"] = {"yolov3": planted()}
@@ -122,7 +134,7 @@ def main():
         net = orc.OracleDarknet(MODELS[model]).set_params(golden_params(model))
         entry = {}
         for acc in ("f32", "f64"):
-            o = net.forward(x, emulate_bf16=True, accumulate=acc)
+            o = net.forward(x, emulate=EMULATE, accumulate=acc)
             for tag in ("a", "b"):
                 pth, ith = g[tag + "_thresholds"]
                 dets = orc.postprocess(o["bbox_xywh"].numpy(), o["class_prob"].numpy(), o["class_idx"].numpy(),
@@ -138,7 +150,7 @@ def main():
         table[model] = entry
     table["bench_regime"] = bench_regime()
     table["planted"] = {"yolov3": planted()}
-    with open(os.path.join(GOLDEN, "bf16_agreement.json"), "w") as fh:
+    with open(path, "w") as fh:
         json.dump(table, fh, indent=1, sort_keys=True)
 
 
