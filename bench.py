@@ -20,6 +20,7 @@ At N = 1 the same run also measures and reports, in that line:
   cpu_baseline    the CPU oracle (the reference's "-d cpu" op sequence) on the host cores, SURVEY.md 8(d) protocol
   other_configs   BASELINE.json's other single-GPU configurations (parity cases, each with its own roofline)
   bf16_agreement  bf16 detections against the reference's float32 detections on the golden frames (tests/golden)
+  f16_agreement   the same for the fp16 storage mode (same kernels on the f16 MFMA; `other_configs` has its rate)
 """
 import argparse
 import hashlib
@@ -47,7 +48,7 @@ import torch  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "float32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA; F16 = BF16 rate)
 MODEL_FLOPS_PER_FRAME = {("yolov3", 608): 140.692e9, ("yolov3-tiny", 416): 5.565e9, ("yolov3-spp", 608): 141.449e9}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
 
 
 def parse_args(argv=None):
@@ -63,6 +64,10 @@ def parse_args(argv=None):
                     help="objectness bias of the procedural weights (sets candidates/frame)")
     ap.add_argument("--kmax", type=int, default=512, help="detection records per frame in the gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help="(internal) run only the CPU baseline and print its JSON object")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed windows of --steps steps each, back to back; value / ms_per_step = the MEDIAN window, the line "
+                         "carries min / median / max (`repeats`)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip pcie_inclusive / other_configs / bf16_agreement (A/B runs, profiling)")
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU-baseline work (bounded sample)")
@@ -111,6 +116,144 @@ def usable_cpus():
     except (OSError, ValueError):
         pass
     return max(1, n)
+
+
+def _read(path, default=None):
+    try:
+        with open(path) as fh:
+            return fh.read().strip()
+    except OSError:
+        return default
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in (text or "").split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def cpu_topology():
+    """{cpu: (numa node, (package, core id))} of the CPUs this process may run on (sysfs; node -1 when unknown)."""
+    allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
+    node_of = {}
+    base = "/sys/devices/system/node"
+    try:
+        for name in os.listdir(base):
+            if name.startswith("node") and name[4:].isdigit():
+                for c in _parse_cpulist(_read(os.path.join(base, name, "cpulist"))):
+                    node_of[c] = int(name[4:])
+    except OSError:
+        pass
+    topo = {}
+    for c in allowed:
+        t = "/sys/devices/system/cpu/cpu%d/topology/" % c
+        topo[c] = (node_of.get(c, -1), (int(_read(t + "physical_package_id", "0") or 0), int(_read(t + "core_id", str(c)) or c)))
+    return topo
+
+
+def _cpu_busy(interval=0.3):
+    """Per-CPU busy share over ``interval`` seconds (/proc/stat), {} if unreadable."""
+    def snap():
+        out = {}
+        for ln in (_read("/proc/stat", "") or "").splitlines():
+            if ln.startswith("cpu") and ln[3:4].isdigit():
+                f = ln.split()
+                v = [int(x) for x in f[1:9]]
+                out[int(f[0][3:])] = (sum(v), v[3] + v[4])      # total, idle + iowait
+        return out
+    a = snap()
+    time.sleep(interval)
+    b = snap()
+    return {c: 1.0 - (b[c][1] - a[c][1]) / max(1, b[c][0] - a[c][0]) for c in b if c in a}
+
+
+def pick_quiet_cpus(n):
+    """``n`` CPUs for the CPU baseline: distinct physical cores of ONE NUMA node, the ones that were least busy over the last
+    0.3 s (the pool's hosts are shared: 256 hardware threads, a 16-CPU quota per tenant -- which cores the threads land on, and
+    who else is on them, is most of the 5x run-to-run spread rounds 1-4 saw).  Falls back to the first ``n`` allowed CPUs."""
+    topo = cpu_topology()
+    busy = _cpu_busy()
+    cores = {}
+    for c, (node, core) in topo.items():
+        cores.setdefault((node, core), []).append(c)
+    by_node = {}
+    for (node, core), cpus in cores.items():
+        by_node.setdefault(node, []).append((max(busy.get(c, 0.0) for c in cpus), min(cpus)))
+    best = None
+    for node, lst in by_node.items():
+        lst.sort()
+        if len(lst) >= n:
+            cost = sum(b for b, _ in lst[:n])
+            if best is None or cost < best[0]:
+                best = (cost, node, [c for _, c in lst[:n]])
+    if best is None:
+        return sorted(topo)[:n], -1
+    return sorted(best[2]), best[1]
+
+
+def gpu_numa_nodes():
+    """NUMA node and PCI address of every GPU in HIP's enumeration order, from sysfs only (NO GPU call: the ranks bind their
+    threads before the runtime starts any).  KFD topology nodes with SIMDs are the GPUs, in the order the runtime enumerates
+    them; numeric HIP_/ROCR_/CUDA_VISIBLE_DEVICES lists are honoured.  [] when the topology cannot be read."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    gpus = []
+    try:
+        ids = sorted(int(n) for n in os.listdir(base) if n.isdigit())
+    except OSError:
+        return []
+    for n in ids:
+        props = {}
+        for ln in (_read(os.path.join(base, str(n), "properties"), "") or "").splitlines():
+            k, _, v = ln.partition(" ")
+            props[k] = v.strip()
+        try:
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+        except ValueError:
+            continue
+        bdf = "%04x:%02x:%02x.%d" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7)
+        node = _read("/sys/bus/pci/devices/%s/numa_node" % bdf)
+        cpus = _parse_cpulist(_read("/sys/bus/pci/devices/%s/local_cpulist" % bdf))
+        gpus.append({"bdf": bdf, "numa_node": int(node) if node not in (None, "") else -1, "local_cpus": cpus})
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = os.environ.get(var)
+        if val and all(p.strip().isdigit() for p in val.split(",")):
+            gpus = [gpus[int(p)] for p in val.split(",") if int(p) < len(gpus)]
+    return gpus
+
+
+def bind_rank_to_gpu_node(local_rank):
+    """Before any GPU call: restrict this rank (and every thread it will start: the HIP runtime's, torch's) to the CPUs of its
+    GPU's NUMA node, so that pinned frame / record buffers (first touch) and the enqueue thread sit on the socket the GPU hangs
+    off.  The headline is PCIe inclusive: on a two-socket node a rank on the wrong socket pulls every frame over the
+    inter-socket link.  Returns what it did for the JSON line (``per_rank.placement``)."""
+    info = {"numa_node": None, "gpu_bdf": None, "cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "bound": False}
+    if os.environ.get("Y3_BENCH_NO_BIND") == "1" or not hasattr(os, "sched_setaffinity"):
+        return info
+    gpus = gpu_numa_nodes()
+    if local_rank >= len(gpus):
+        return info
+    g = gpus[local_rank]
+    info["gpu_bdf"], info["numa_node"] = g["bdf"], g["numa_node"]
+    allowed = os.sched_getaffinity(0)
+    want = g["local_cpus"] & allowed
+    if g["numa_node"] >= 0 and not want:
+        want = {c for c, (node, _) in cpu_topology().items() if node == g["numa_node"]}
+    if want and want != allowed:
+        try:
+            os.sched_setaffinity(0, want)
+            info["bound"] = True
+        except OSError:
+            pass
+    info["cpus"] = len(os.sched_getaffinity(0))
+    return info
 
 
 def cpu_model():
@@ -329,8 +472,11 @@ class Workload(object):
             return self.pipe.submit(self.warm_frames if warm else self.frames, to_host=False)
         return self.pipe.submit(self.host_warm if warm else self.host_frames)
 
-    def timed(self, steps, warmup, distributed=False, resident=False):
-        """`warmup` untimed steps, then EXACTLY `steps` steps bracketed by barrier + synchronize; max over ranks."""
+    def timed(self, steps, warmup, distributed=False, resident=False, repeats=1):
+        """`warmup` untimed steps, then ``repeats`` back-to-back windows of EXACTLY `steps` steps, each bracketed by barrier +
+        synchronize on both sides and reduced to the max over ranks.  Returns the MEDIAN window's time (every rank picks the
+        same window: the list is identical on all ranks after the all-reduce); ``self.windows_s`` keeps all of them, and
+        ``rank_elapsed_s`` / ``host_enqueue_s`` are those of the median window."""
         import torch.distributed as dist
         for i in range(max(warmup, self.nstream)):
             self.step(i, resident, warm=True)
@@ -338,24 +484,32 @@ class Workload(object):
         if os.environ.get("Y3_BENCH_DEBUG_AFTER_WARMUP"):      # diagnostic libraries only (the product library rejects the key)
             from yolov3 import _hip
             _hip.check(_hip.lib().y3_set_tuning(b"debug", int(os.environ["Y3_BENCH_DEBUG_AFTER_WARMUP"])))
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            self.step(i, resident)
-        self.host_enqueue_s = time.perf_counter() - t0       # host time to enqueue the K steps (the GPU runs behind it)
-        torch.cuda.synchronize()
-        self.rank_elapsed_s = time.perf_counter() - t0       # this rank alone, before the closing barrier
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if distributed:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return elapsed
+        windows, mine = [], []
+        for _ in range(max(1, repeats)):
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                self.step(i, resident)
+            host_enqueue = time.perf_counter() - t0          # host time to enqueue the K steps (the GPU runs behind it)
+            torch.cuda.synchronize()
+            rank_elapsed = time.perf_counter() - t0          # this rank alone, before the closing barrier
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            if distributed:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            windows.append(elapsed)
+            mine.append((rank_elapsed, host_enqueue))
+        order = sorted(range(len(windows)), key=lambda k: windows[k])
+        med = order[(len(order) - 1) // 2]                    # lower median: an actually measured window
+        self.windows_s = windows
+        self.rank_elapsed_s, self.host_enqueue_s = mine[med]
+        return windows[med]
 
     def kept_per_frame(self):
         return int(self.pipe.dets[0].count.cpu().numpy().mean())
@@ -414,10 +568,28 @@ def lib_sha256():
         return hashlib.sha256(fh.read()).hexdigest()
 
 
+def _elf_sections(elf):
+    """(name, type, bytes) of every section of an ELF64 image."""
+    import struct
+    shoff = struct.unpack_from("<Q", elf, 0x28)[0]
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", elf, 0x3A)
+    hdrs = [elf[shoff + k * shentsize:shoff + (k + 1) * shentsize] for k in range(shnum)]
+    so, ss = struct.unpack_from("<QQ", hdrs[shstrndx], 0x18)
+    names = elf[so:so + ss]
+    for h in hdrs:
+        nm, typ = struct.unpack_from("<II", h, 0)
+        off, size = struct.unpack_from("<QQ", h, 0x18)
+        yield names[nm:names.index(b"\0", nm)].decode(), typ, (b"" if typ == 8 else elf[off:off + size])
+
+
 def device_code_sha256(path=None):
-    """sha256 over the gfx950 code objects inside the library (the clang offload bundles' device entries, in file order).
-    Kernel traffic depends on the device code only: host-side edits (a comment shifts the __LINE__ of an error message)
-    change the file's hash but not this one."""
+    """sha256 over the gfx950 code objects inside the library (the clang offload bundles' device entries, in file order):
+    of each, the sections that ARE the kernels -- .text (instructions), .rodata (kernel descriptors, constants), .data and
+    .note (the kernels' metadata: names, registers, LDS).  Kernel traffic depends on the device code only: host-side edits (a
+    comment shifts the __LINE__ of an error message) change the file's hash but not this one, and neither does the directory
+    the objects were compiled in -- hipcc derives a per-translation-unit id (``__hip_cuid_<hash>``) from the source PATH, which
+    lands in the symbol / string / hash tables of every code object (38-103 differing bytes per object between two
+    checkouts: VERDICT r04 item 9) and is left out here.  tests/test_code_object.py builds one source in two directories."""
     import struct
     if path is None:
         from yolov3 import _hip
@@ -438,7 +610,10 @@ def device_code_sha256(path=None):
             triple = data[off + 24:off + 24 + tl]
             off += 24 + tl
             if sz and not triple.startswith(b"host"):
-                h.update(data[i + o:i + o + sz])
+                for name, _, body in _elf_sections(data[i + o:i + o + sz]):
+                    if name in (".text", ".rodata", ".data", ".note"):
+                        h.update(name.encode() + b":%d:" % len(body))
+                        h.update(body)
                 found += 1
         pos = i + 24
     return h.hexdigest() if found else None
@@ -446,7 +621,7 @@ def device_code_sha256(path=None):
 
 def load_traffic_table():
     """HBM-side traffic per launch comes from separate rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a
-    pass and counters cannot be read from inside this process): tools/profile_gpu.sh -> profiles/r03_traffic.json,
+    pass and counters cannot be read from inside this process): tools/profile_gpu.sh -> TRAFFIC_FILE (profiles/r05_traffic.json),
     which records the sha256 of the library it measured and of its device code objects.  A table measured on other
     kernels is not used."""
     try:
@@ -462,6 +637,58 @@ def load_traffic_table():
         os.path.relpath(TRAFFIC_FILE, ROOT))
 
 
+def cpu_baseline_in_child(args):
+    """The CPU baseline as a NUMBER: a fresh child process, started before this process makes any GPU
+    call (no runtime threads, no pinned memory, nothing else of this job running), confined to ``cores`` quiet physical cores
+    of one NUMA node with as many OpenMP threads; load average recorded on both sides.  Returns the child's JSON object."""
+    cores = usable_cpus()
+    cpus, node = pick_quiet_cpus(cores)
+    env = dict(os.environ)
+    # (the process is confined to those cores, one OpenMP thread per core; NOT OMP_PROC_BIND: with torch's thread pools bound
+    # thread by thread the same run took 3.5x longer here, 60 % of it in the kernel)
+    env.update({"OMP_NUM_THREADS": str(len(cpus)), "MKL_NUM_THREADS": str(len(cpus)), "Y3_CPU_BASELINE_CHILD": "1"})
+    env.pop("OMP_PROC_BIND", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--model", args.model, "--dim", str(args.dim),
+           "--obj-bias", str(args.obj_bias), "--cpu-budget", str(args.cpu_budget)]
+    load0 = os.getloadavg()
+    t0 = time.perf_counter()
+
+    def pin():
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError:
+            pass
+    try:
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                              preexec_fn=pin, timeout=max(120.0, 6 * args.cpu_budget))
+    except subprocess.TimeoutExpired:
+        return {"error": "cpu baseline child timed out"}
+    out = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{"):
+            out = json.loads(ln)
+    if proc.returncode != 0 or out is None:
+        return {"error": "cpu baseline child failed (rc %s): %s" % (proc.returncode, proc.stderr[-400:])}
+    out["process"] = "fresh child process, started and finished before this process made any GPU call"
+    out["pinned_cpus"] = cpus
+    out["numa_node"] = node
+    out["loadavg_before"] = [round(v, 2) for v in load0]
+    out["loadavg_after"] = [round(v, 2) for v in os.getloadavg()]
+    out["wall_s"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
+def cpu_baseline_child_main(args):
+    """``bench.py --cpu-baseline-child``: only the CPU baseline, one JSON line (see cpu_baseline_in_child)."""
+    from yolov3 import weights as W
+    from yolov3.cfgparse import parse_config
+    cfg = os.path.join(ROOT, "pytorch-yolov3_amd", "models", args.model + ".cfg")
+    blocks, net_info = parse_config(cfg)
+    params = W.synth_params(blocks, net_info, seed=0, obj_bias=args.obj_bias, calib=W.load_calibration(args.model))
+    print(json.dumps(cpu_baseline(cfg, params, args.model, args.dim, args.cpu_budget)), flush=True)
+    return 0
+
+
 def cpu_baseline(cfg, params, model, dim, budget_s):
     """the reference's "-d cpu" op sequence (oracle/: torch-CPU Conv2d -> BN -> LeakyReLU as separate
     float32 ops, NCHW, numpy greedy NMS) on the host cores.  Two legs inside ``budget_s`` seconds of CPU work: batch 1 -- what
@@ -475,6 +702,8 @@ def cpu_baseline(cfg, params, model, dim, budget_s):
     from oracle import darknet_oracle as orc
     from yolov3.synthdata import synth_frames
     cores = usable_cpus()
+    if os.environ.get("Y3_CPU_BASELINE_CHILD") == "1" and hasattr(os, "sched_getaffinity"):
+        cores = min(cores, len(os.sched_getaffinity(0)))      # the parent pinned this process to that many quiet cores
     torch.set_num_threads(cores)
     onet = orc.OracleDarknet(cfg).set_params(params)
     frames = [f for f in synth_frames(123, 16, dim, dim)]
@@ -516,25 +745,30 @@ def cpu_baseline(cfg, params, model, dim, budget_s):
                            legs[16]["timed"], " (truncated to the budget)" if legs[16]["truncated"] else "", best, spent, budget_s))
 
 
-def bf16_agreement(dev):
-    """bf16 HIP detections against the reference's float32 ``inference()`` lists on the golden frames
-    (tests/golden/inference_yolov3.npz, produced by the reference; floors from the bf16-emulating oracle in
-    tests/golden/bf16_agreement.json).  Keep-set Jaccard by prediction row and score differences on common rows."""
+def lowp_agreement(dev, dtype="bf16"):
+    """bf16 / fp16 HIP detections against the reference's float32 ``inference()`` lists on the golden frames
+    (tests/golden/inference_yolov3.npz, produced by the reference; floors from the oracle emulating that storage type in
+    tests/golden/bf16_agreement.json / f16_agreement.json).  Keep-set Jaccard by prediction row and score differences on
+    common rows; at the bench regime also how many (frame, threshold) pairs -- and how many of the AUDITED-CLEAN ones, where
+    no float32 deviation below 6e-5 can move an integer -- come out EXACTLY as the reference's lists (rows, classes, boxes)."""
+    emu = {"bf16": "bf16", "fp16": "f16"}[dtype]
+    ideal_key = "ideal_%s_jaccard" % emu
     import yolov3
     from yolov3 import weights as W
     from yolov3.synthdata import synth_frames
     from PIL import Image
     gdir = os.path.join(ROOT, "tests", "golden")
     g = np.load(os.path.join(gdir, "inference_yolov3.npz"))
-    with open(os.path.join(gdir, "bf16_agreement.json")) as fh:
-        floors = json.load(fh)["yolov3"]
+    with open(os.path.join(gdir, "%s_agreement.json" % emu)) as fh:
+        floor_table = json.load(fh)
+    floors = floor_table["yolov3"]
 
     def jpeg(name):
         return np.ascontiguousarray(np.asarray(Image.open(os.path.join(gdir, "images", name)).convert("RGB"))[:, :, ::-1])
 
     frames = [jpeg("000000229358.jpg"), synth_frames(9, 1, 608, 608)[0], jpeg("000000393569.jpg")]
     cfg = os.path.join(ROOT, "pytorch-yolov3_amd", "models", "yolov3.cfg")
-    net = yolov3.Darknet(cfg, device=str(dev), dtype="bf16").eval()
+    net = yolov3.Darknet(cfg, device=str(dev), dtype=dtype).eval()
     net.set_params(W.synth_params(net.blocks, net.net_info, seed=0, obj_bias=-5.0, calib=W.load_calibration("yolov3")))
     out = {}
     for tag in ("a", "b"):
@@ -554,20 +788,19 @@ def bf16_agreement(dev):
             ref_kept += len(want)
         dps = np.array(dps) if dps else np.zeros(1)
         out["thr_%.2f_iou_%.1f" % (pth, ith)] = dict(
-            keep_set_jaccard=[round(j, 4) for j in jac], ideal_bf16_jaccard=ideal, kept=kept, reference_kept=ref_kept,
+            keep_set_jaccard=[round(j, 4) for j in jac], **{ideal_key: ideal}, kept=kept, reference_kept=ref_kept,
             score_abs_diff=dict(median=float(np.median(dps)), p90=float(np.percentile(dps, 90)),
                                 p99=float(np.percentile(dps, 99)), max=float(dps.max())))
     # the BENCHMARKED regime (objectness bias -8.5, tens of kept boxes per frame): all nine sample images and the procedural
     # frames of tests/golden/inference_bench_regime_yolov3.npz, one image per call, pooled over frames
     g2 = np.load(os.path.join(gdir, "inference_bench_regime_yolov3.npz"))
-    with open(os.path.join(gdir, "bf16_agreement.json")) as fh:
-        floors2 = json.load(fh)["bench_regime"]["yolov3"]
+    floors2 = floor_table["bench_regime"]["yolov3"]
     obj_bias = float(g2["obj_bias"])
     net.set_params(W.synth_params(net.blocks, net.net_info, seed=0, obj_bias=obj_bias, calib=W.load_calibration("yolov3")))
     regime = {"obj_bias": obj_bias, "frames": len(g2["names"])}
     for tag in ("a", "b"):
         pth, ith = g2[tag + "_thresholds"]
-        common = union = kept = ref_kept = 0
+        common = union = kept = ref_kept = pairs = exact = clean = clean_exact = 0
         dps = []
         for name in (str(n) for n in g2["names"]):
             frame = jpeg("000000%s.jpg" % name[3:]) if name.startswith("img") else synth_frames(int(name[5:]), 1, 608, 608)[0]
@@ -581,17 +814,26 @@ def bf16_agreement(dev):
             kept += len(rows)
             ref_kept += len(want)
             dps += [abs(float(res[1][mine[r]]) - gp[r]) for r in rows & want]
+            # exactly the reference's list: same prediction rows, and on them the same class and integer box
+            ref_at = {int(r): k for k, r in enumerate(g2[key + "rows"])}
+            same = rows == want and all(int(res[2][k]) == int(g2[key + "cls"][ref_at[int(r)]]) and
+                                        np.array_equal(res[0][k], g2[key + "tlbr"][ref_at[int(r)]]) for k, r in enumerate(res[3]))
+            is_clean = bool(g2[key + "audit"][4])
+            pairs += 1
+            exact += int(same)
+            clean += int(is_clean)
+            clean_exact += int(is_clean and same)
         dps = np.array(dps) if dps else np.zeros(1)
         regime["thr_%.2f_iou_%.1f" % (pth, ith)] = dict(
-            keep_set_jaccard=round(common / max(union, 1), 4), ideal_bf16_jaccard=floors2["all_" + tag]["jaccard"], kept=kept,
-            reference_kept=ref_kept, score_abs_diff=dict(median=float(np.median(dps)), p99=float(np.percentile(dps, 99)), max=float(dps.max())))
+            keep_set_jaccard=round(common / max(union, 1), 4), **{ideal_key: floors2["all_" + tag]["jaccard"]}, kept=kept,
+            reference_kept=ref_kept, score_abs_diff=dict(median=float(np.median(dps)), p99=float(np.percentile(dps, 99)), max=float(dps.max())),
+            frames=pairs, frames_exactly_as_reference=exact, audited_clean_frames=clean, audited_clean_frames_exact=clean_exact)
     out["bench_regime"] = regime
     # PLANTED parameters (tools/make_planted.py): the procedural backbone with a 19 x 19 head fitted on the nine sample images
     # so that each has a handful of confident detections with margins (kept scores >= 0.6, class margins ~1, everything else
     # below 0.01) -- the regime real weights are in.  Reference lists: tests/golden/inference_planted_yolov3.npz.
     g3 = np.load(os.path.join(gdir, "inference_planted_yolov3.npz"))
-    with open(os.path.join(gdir, "bf16_agreement.json")) as fh:
-        floors3 = json.load(fh)["planted"]["yolov3"]
+    floors3 = floor_table["planted"]["yolov3"]
     net.set_params(W.planted_params(net.blocks, net.net_info))
     planted = {"frames": len(g3["names"])}
     from yolov3.preprocess import resize_bilinear_u8
@@ -618,23 +860,28 @@ def bf16_agreement(dev):
                     box_max = max(box_max, int(np.abs(res[0][k] - g3[key + "tlbr"][j]).max()))
         dps = np.array(dps) if dps else np.zeros(1)
         planted["thr_%.2f_iou_%.1f" % (pth, ith)] = dict(
-            keep_set_jaccard=round(common / max(union, 1), 4), ideal_bf16_jaccard=floors3["all_" + tag]["jaccard"], kept=kept,
+            keep_set_jaccard=round(common / max(union, 1), 4), **{ideal_key: floors3["all_" + tag]["jaccard"]}, kept=kept,
             reference_kept=ref_kept, common=common, same_class_on_common=same_cls, box_abs_diff_px_max=box_max,
             score_abs_diff=dict(median=float(np.median(dps)), p99=float(np.percentile(dps, 99)), max=float(dps.max())))
     out["planted"] = planted
-    out["note"] = ("yolov3 608 bf16 HIP path vs the reference's float32 inference() on 3 golden frames, procedural weights "
-                   "(thousands of overlapping near-threshold boxes per frame); ideal_bf16_jaccard = the bf16-emulating "
-                   "oracle on the same frames (tests/golden/bf16_agreement.json); bench_regime = the same at the objectness "
+    out["note"] = ("yolov3 608 %s HIP path vs the reference's float32 inference() on 3 golden frames, procedural weights "
+                   "(thousands of overlapping near-threshold boxes per frame); %s = the oracle emulating that storage type "
+                   "on the same frames (tests/golden/%s_agreement.json); bench_regime = the same at the objectness "
                    "bias the throughput is measured at, pooled over the nine sample images + procedural frames; planted = a fitted "
-                   "head that gives every sample image a handful of confident detections with margins (tools/make_planted.py)")
+                   "head that gives every sample image a handful of confident detections with margins (tools/make_planted.py)"
+                   % (dtype, ideal_key, emu))
     return out
 
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args.cpu_baseline_child:
+        return cpu_baseline_child_main(args)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    t_start = time.perf_counter()
+    phases = {}
     # (Y3_BENCH_FORCE_LAUNCH=1: go through the launcher with one rank as well -- the only way to exercise it, RCCL included, on
     # a box with one GPU: tests/test_callers.py)
     if (args.gpus > 1 or os.environ.get("Y3_BENCH_FORCE_LAUNCH") == "1") and "WORLD_SIZE" not in os.environ:
@@ -656,6 +903,15 @@ def main(argv=None):
     if torch.cuda.device_count() <= local_rank:
         sys.stderr.write("bench.py: rank %d needs GPU %d, %d visible\n" % (rank, local_rank, torch.cuda.device_count()))
         return 2
+    # ---- everything that must happen BEFORE this process touches the GPU (device_count above does not) ----------------
+    # (1) the CPU baseline, in a fresh pinned child process, on an otherwise idle job (rank 0 at N = 1 only)
+    cpu_base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline_in_child(args)
+        phases["cpu_baseline_s"] = round(time.perf_counter() - t_start, 1)
+    # (2) this rank's threads onto the CPUs of its GPU's NUMA node (pinned buffers are allocated after this)
+    placement = bind_rank_to_gpu_node(local_rank)
+    t_gpu0 = time.perf_counter()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ranks_seen = 1
@@ -687,11 +943,30 @@ def main(argv=None):
     if use_graph:
         options = {"auto_mask": _hip.options().auto_mask | (_hip.AM_HALO_TILE256 if nstream > 1 else 0), "use_graph": 1}
     wl = Workload(args.model, args.dim, my_frames, args.dtype, params, dev, rank, world, args.kmax, nstream, options=options)
-    elapsed = wl.timed(args.steps, args.warmup, distributed, resident=args.resident)
+    phases["init_s"] = round(time.perf_counter() - t_gpu0, 1)          # process group, weights, plans, pinned buffers
+    t_timed0 = time.perf_counter()
+    elapsed = wl.timed(args.steps, args.warmup, distributed, resident=args.resident, repeats=args.repeats)
+    phases["warmup_and_timed_s"] = round(time.perf_counter() - t_timed0, 1)
+    windows_ms = sorted(w / args.steps * 1e3 for w in wl.windows_s)
     kept = wl.kept_per_frame()
+    # was the sysfs guess the GPU this rank really runs on?  (torch exposes the PCI address once the device is initialised)
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        real = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        placement["gpu_bdf_verified"] = (placement.get("gpu_bdf") == real) if placement.get("gpu_bdf") else None
+    except Exception:
+        placement["gpu_bdf_verified"] = None
+    if distributed:      # every rank's placement in rank 0's line
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, placement)
+    else:
+        gathered = [placement]
 
     per_rank = rank_stats(wl.rank_elapsed_s, wl.host_enqueue_s, args.steps, world, dev) if distributed else \
         rank_stats(wl.rank_elapsed_s, wl.host_enqueue_s, args.steps, 1, None)
+    per_rank["placement"] = gathered
+    per_rank["cpus_per_rank"] = [p.get("cpus") for p in gathered]
+    per_rank["numa_node"] = [p.get("numa_node") for p in gathered]
     extras = rank == 0 and world == 1 and not args.no_extras and not args.resident and args.scaling == "weak"
     line = None
     if rank == 0:
@@ -706,6 +981,10 @@ def main(argv=None):
             "metric": "frames/sec (608x608)" if dim == 608 else "frames/sec (%dx%d)" % (dim, dim),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            # R back-to-back windows of exactly `steps` steps each; value / ms_per_step are the median window's
+            "repeats": {"windows": len(windows_ms), "ms_per_step_min": round(windows_ms[0], 4),
+                        "ms_per_step_median": round(elapsed / args.steps * 1e3, 4), "ms_per_step_max": round(windows_ms[-1], 4),
+                        "value_min": round(sum(all_frames) / windows_ms[-1] * 1e3, 1), "value_max": round(sum(all_frames) / windows_ms[0] * 1e3, 1)},
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%s %dx%d batch=%d/GPU %s, procedural weights, uint8 frames %s -> "
@@ -738,6 +1017,8 @@ def main(argv=None):
                                "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
                            for k, v in report["by_kernel"].items()}
 
+    phases["report_s"] = round(time.perf_counter() - t_timed0 - phases["warmup_and_timed_s"], 1)
+    t_extras0 = time.perf_counter()
     if extras:
         # ---- the same steps with the frames already in HBM and the records left there (the kernels alone) ----------
         e2 = wl.timed(args.steps, min(args.warmup, 5), False, resident=True)
@@ -750,7 +1031,7 @@ def main(argv=None):
         # ---- the other single-GPU configurations of BASELINE.json (parity cases; each with its own roofline) -----
         others = []
         for model, dim, batch, dtype in (("yolov3-tiny", 416, 8, "float32"), ("yolov3-spp", 608, 16, "bf16"),
-                                         ("yolov3", 608, 16, "float32")):
+                                         ("yolov3", 608, 16, "fp16"), ("yolov3", 608, 16, "bf16"), ("yolov3", 608, 16, "float32")):
             if (model, dim, batch, dtype) == (args.model, args.dim, args.batch, args.dtype):
                 continue
             p = params if model == args.model else params_for(model, args.obj_bias)
@@ -771,16 +1052,21 @@ def main(argv=None):
             del w2
             torch.cuda.empty_cache()
         line["other_configs"] = others
-        try:
-            line["bf16_agreement"] = bf16_agreement(dev)
-        except Exception as exc:        # the golden files are test data: their absence must not void the bench line
-            line["bf16_agreement"] = {"error": repr(exc)}
+        for key, dt in (("bf16_agreement", "bf16"), ("f16_agreement", "fp16")):
+            try:
+                line[key] = lowp_agreement(dev, dt)
+            except Exception as exc:    # the golden files are test data: their absence must not void the bench line
+                line[key] = {"error": repr(exc)}
+        phases["extras_s"] = round(time.perf_counter() - t_extras0, 1)
 
-    # ---- CPU baseline: the oracle (reference "-d cpu" op sequence) timed on the host cores ----------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(wl.cfg, params, args.model, args.dim, args.cpu_budget)
+    # ---- CPU baseline: the oracle (reference "-d cpu" op sequence) timed on the host cores, measured in a child process
+    # BEFORE this process touched the GPU (top of main)
+    if rank == 0 and cpu_base is not None:
+        line["cpu_baseline"] = cpu_base
 
     if rank == 0:
+        phases["total_s"] = round(time.perf_counter() - t_start, 1)
+        line["phases_s"] = phases
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()          # ranks > 0 wait for rank 0's profiling passes before the group goes away

@@ -15,9 +15,27 @@ import os
 # the other: the pipeline's copy stream next to its three compute streams needs more (yolov3/pipeline.py;
 # profiles/r03c_pcie_inclusive.txt: 4.9 k against 6.3 k frames/s).  Read by the runtime when it initialises, i.e. at the first
 # GPU call of the process -- importing this package before that is enough.
+_HW_QUEUES_PRESET = os.environ.get("GPU_MAX_HW_QUEUES")          # what the caller's environment said (None: nothing)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: F401,E402  (must be loaded before libyolov3_hip.so, see above)
+
+# If the process had ALREADY initialised HIP when this module was imported (``import torch; torch.cuda.*`` first), the
+# runtime has read its environment and the setdefault above came too late: the pipeline then runs on the default 4 queues
+# (~4.9 k instead of ~6.3 k frames/s) with nothing to show for it.  ``hw_queues()`` says what is in effect, as far as that
+# can be known; yolov3/pipeline.py warns, bench.py records it.
+_HIP_UP_AT_IMPORT = bool(torch.cuda.is_initialized())
+
+
+def hw_queues():
+    """(value of GPU_MAX_HW_QUEUES the HIP runtime saw or will see, whether that is certain).  Not certain -- and probably the
+    runtime's default of 4 -- when HIP was initialised before this package was imported without the variable set."""
+    if _HIP_UP_AT_IMPORT and _HW_QUEUES_PRESET is None:
+        return 4, False
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), True
+    except ValueError:
+        return 4, False
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # Y3_HIP_LIB: developer override (e.g. the diagnostic build with in-kernel phase stamps)

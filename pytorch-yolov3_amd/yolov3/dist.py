@@ -43,6 +43,25 @@ def all_gather_records(records, world, group=None):
     return out
 
 
+def regather_if_truncated(gathered, kmax, repack, world, group=None, round_to=64):
+    """The "ragged alternative" of SURVEY.md 8(e), on top of the fixed-size gather: ``gathered`` (world*b, kmax, 8) are the
+    records of all ranks; field 7 carries every frame's TRUE count, so every rank reads the same maximum.  If some frame kept
+    more than ``kmax`` boxes, every rank calls ``repack(kmax2)`` -> its own (b, kmax2, 8) records with room for the largest
+    count (rounded up to ``round_to``) and ONE more all-gather returns all of them; otherwise ``gathered`` comes back as it
+    is.  Collective: all ranks call it, in the same order.  Nothing is ever dropped (the reference returns every kept box:
+    /root/reference/yolov3/inference.py:355-366).  Returns host or device records like ``repack`` / ``gathered``."""
+    cnt = counts_of(gathered)
+    most = int(cnt.max()) if cnt.shape[0] else 0
+    if most <= kmax:
+        return gathered
+    kmax2 = (most + round_to - 1) // round_to * round_to
+    rec2 = repack(kmax2)
+    if not isinstance(rec2, torch.Tensor):
+        rec2 = torch.from_numpy(np.ascontiguousarray(rec2))
+    out = all_gather_records(rec2, world, group)
+    return out.cpu().numpy() if out.is_cuda else out
+
+
 def pack_records_host(dets, kmax):
     """Host-side packer with the layout of the device kernel ``y3_pack_records`` (used by the CPU
     tests of the collective plumbing; the product path packs on the GPU).

@@ -12,13 +12,17 @@ kernels.  This is the loop ``bench.py`` times (its headline number is this class
 ``stream.detect_in_frames`` / the command line run: the benchmarked configuration IS the package's.
 
 Results equal per-frame ``inference()`` bit for bit (frames are independent, kernel choice does not change a bit:
-tests/test_gpu_properties.py, tests/test_gpu_pipeline.py).
+tests/test_gpu_properties.py, tests/test_gpu_pipeline.py) -- with one rank or N: a frame that kept more than ``kmax`` boxes is
+fetched again in full (one rank) or gathered again with records for the largest count (N ranks, ``results``: SURVEY.md 8(e)'s
+"ragged alternative"; the counts ride in the first gather, so every rank takes the same decision).
 """
+import warnings
+
 import numpy as np
 import torch
 
 from . import _hip
-from .dist import DetectionGather, unpack_records
+from .dist import DetectionGather, all_gather_records, regather_if_truncated, unpack_records
 from .inference import Detector
 
 
@@ -66,6 +70,14 @@ class Pipeline(object):
         self.width = int(width or net.net_info["width"])
         self.prob_thresh, self.nms_iou_thresh = float(np.float32(prob_thresh)), float(nms_iou_thresh)
         self.dev = dev = net._torch_device()
+        self.group = group
+        nq, sure = _hip.hw_queues()
+        if in_flight > 1 and (nq < in_flight + 2 or not sure):
+            warnings.warn("yolov3.Pipeline: {} batches in flight + a copy stream (+ a gather stream) want GPU_MAX_HW_QUEUES >= {}, "
+                          "but the HIP runtime {} {} hardware queues (it reads the variable when it initialises: import yolov3 -- or "
+                          "set GPU_MAX_HW_QUEUES=8 -- before the first torch.cuda call); streams that share a queue run one after "
+                          "the other (measured: 4.9 k instead of 6.3 k frames/s)".format(
+                              in_flight, in_flight + 2, "has" if sure else "was probably initialised with", nq), RuntimeWarning)
         self.copy_blocks = int(copy_blocks)
         # several batches in flight: CU time counts, not one launch's tail -> the strip kernel's 256-pixel tiles
         # (include/yolov3_hip.h: Y3_AM_HALO_TILE256).  Explicit ``options`` win.
@@ -95,6 +107,10 @@ class Pipeline(object):
             self._host_frames = [None] * self.nbuf           # pinned staging / caller-fillable buffers, made on demand
             self.free_ev = [torch.cuda.Event() for _ in range(self.nbuf)]
             self.ready_ev = [torch.cuda.Event() for _ in range(self.nbuf)]
+            # "has the upload that last READ this host buffer finished": one event per HOST buffer (keyed by its address), not per
+            # device buffer -- the device-buffer rotation (uploads % nbuf) and a caller's own host-buffer rotation are unrelated
+            # (a caller double-buffering with host_frames(0) / (1) got the event of a long-finished upload)
+            self._host_ev = {}
             for e in self.free_ev + self.ready_ev:
                 e.record()
             self.host_rec = [torch.empty((world * self.batch, self.kmax, 8), dtype=torch.int32).pin_memory()
@@ -119,11 +135,27 @@ class Pipeline(object):
 
     def upload_done(self, j, wait=True):
         """Has the last upload that read ``host_frames(j)`` finished (``wait``: block until it has)?"""
-        ev = self.ready_ev[j % self.nbuf]
+        buf = self._host_frames[j % self.nbuf]
+        return True if buf is None else self.host_buffer_free(buf, wait)
+
+    def host_buffer_free(self, host, wait=True):
+        """Same question for ANY pinned tensor that was handed to ``submit``: may the caller overwrite it?"""
+        ev = self._host_ev.get(host.data_ptr())
+        if ev is None:
+            return True
         if wait:
             ev.synchronize()
             return True
         return ev.query()
+
+    def _record_host_read(self, host):
+        ev = self._host_ev.get(host.data_ptr())
+        if ev is None:
+            if len(self._host_ev) >= 64:        # callers that pass a fresh pinned tensor every time: forget finished uploads
+                for ptr in [p for p, e in self._host_ev.items() if e.query()]:
+                    del self._host_ev[ptr]
+            ev = self._host_ev[host.data_ptr()] = torch.cuda.Event()
+        ev.record(self.copy_stream)
 
     def next_slot(self):
         """(stream, ticket buffer index) the NEXT ``submit`` will use: callers that prepare device frames themselves (resize on the
@@ -147,9 +179,9 @@ class Pipeline(object):
                 self._uploads += 1
                 host = frames if (isinstance(frames, torch.Tensor) and frames.is_pinned()) else None
                 if host is None:
-                    # pageable input: stage it (the staging buffer is free once the upload that last read it has finished)
-                    self.ready_ev[j].synchronize()
+                    # pageable input: stage it (the staging buffer is free once the upload that last READ IT has finished)
                     host = self.host_frames(j)
+                    self.host_buffer_free(host, wait=True)
                     src = frames if isinstance(frames, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frames))
                     if src.dim() != 4 or src.shape[0] > self.batch:
                         raise ValueError("expected at most {} frames of shape ({}, {}, 3), got {}".format(
@@ -164,6 +196,7 @@ class Pipeline(object):
                                                  min(host.numel(), self.dev_frames[j].numel()), self.copy_blocks,
                                                  _hip.stream_ptr(self.copy_stream)))
                     self.ready_ev[j].record(self.copy_stream)
+                    self._record_host_read(host)
                 cur.wait_event(self.ready_ev[j])
                 fr = self.dev_frames[j]
             if tuple(fr.shape) != (self.batch, self.height, self.width, 3):
@@ -203,12 +236,31 @@ class Pipeline(object):
         rec = self.records(ticket)
         k, d = ticket % self.in_flight, ticket % self.max_open
         mine = rec[:self.batch] if self.world == 1 else rec     # single rank: all frames are ours
-        if self.world == 1 and mine.size and int(mine[:, 0, 7].max()) > self.kmax:
+        collective = self.gathers[d].collective                # a process group is up (N ranks, or one: tests)
+        if not collective and mine.size and int(mine[:, 0, 7].max()) > self.kmax:
             # (the ticket's detector buffers still hold the whole batch: they are reused max_open tickets later)
             with torch.cuda.device(self.dev), torch.cuda.stream(self.streams[k]):
                 full = self.dets[d].fetch(return_rows=return_rows, kmax=int(mine[:, 0, 7].max()))
             return full[:self._frames_in[d]]
+        if collective:
+            # N ranks: every kept box of every rank's frames (the reference returns them all: inference.py:355-366).  The true
+            # counts came with the first gather, so all ranks see the same maximum and take the same branch: when a frame kept
+            # more than kmax boxes, every rank packs its batch again with room for the largest count and the records are
+            # gathered a second time (a collective: all ranks call results() for the same tickets in the same order).
+            det = self.dets[d]
+
+            def repack(kmax2):
+                with torch.cuda.device(self.dev), torch.cuda.stream(self.streams[k]):
+                    rec2 = torch.zeros((self.batch, kmax2, 8), dtype=torch.int32, device=self.dev)
+                    _hip.check(_hip.lib().y3_pack_records(
+                        det.count.data_ptr(), det.tlbr.data_ptr(), det.prob.data_ptr(), det.cls.data_ptr(), det.row.data_ptr(),
+                        self.batch, self.rows, kmax2, rec2.data_ptr(), None, _hip.stream_ptr(self.streams[k])))
+                return rec2
+            with torch.cuda.device(self.dev), torch.cuda.stream(self.streams[k]):
+                mine = regather_if_truncated(mine, self.kmax, repack, self.world, self.group)
         items = unpack_records(mine)
+        if any(item[4] for item in items):
+            raise RuntimeError("Pipeline.results: a frame was truncated to kmax = {} boxes".format(self.kmax))
         n = self._frames_in[d] if self.world == 1 else len(items)
         return [item[:4] if return_rows else item[:3] for item in items[:n]]
 

@@ -80,3 +80,34 @@ def test_no_kernel_spills_and_budgets_fit_a_cu(kernels):
         assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 512, name
         assert k[".group_segment_fixed_size"] <= 160 * 1024, name
         assert k[".wavefront_size"] == 64, name
+
+
+def test_device_code_hash_does_not_depend_on_the_build_directory(tmp_path):
+    """bench.py ties profiles/r0N_traffic.json to the library by a hash over its DEVICE code.  hipcc embeds an id derived
+    from the source path in every code object's symbol tables; the hash must not see it: one source
+    compiled into two directories, under two different source paths, hashes the same -- and the raw objects do differ."""
+    import shutil
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "pytorch-yolov3_amd", "csrc")
+    objs = []
+    for sub in ("a", os.path.join("b", "deeper")):
+        d = tmp_path / sub
+        d.mkdir(parents=True)
+        for name in ("yolo_decode.hip", "common.h", "decode_core.h"):
+            shutil.copy(os.path.join(csrc, name), str(d / name))
+        out = str(d / "yolo_decode.o")
+        subprocess.check_call([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                               "-ffp-contract=off", "-Wno-unused-function", "-c", str(d / "yolo_decode.hip"), "-o", out])
+        objs.append(out)
+    raw = [open(o, "rb").read() for o in objs]
+    code = [[elf for _, elf in _code_objects(r)] for r in raw]
+    assert code[0] != code[1], "expected the path-derived id to differ between the two builds"
+    assert bench.device_code_sha256(objs[0]) == bench.device_code_sha256(objs[1])
+    # ... and it is a hash of the kernels: another source gives another value
+    assert bench.device_code_sha256(objs[0]) != bench.device_code_sha256(LIB)

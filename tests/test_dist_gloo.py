@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from yolov3.dist import all_gather_records, counts_of, pack_records_host, shard_range, unpack_records
+from yolov3.dist import all_gather_records, counts_of, pack_records_host, regather_if_truncated, shard_range, unpack_records
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
@@ -91,6 +91,70 @@ def test_all_gather_gloo(world, n_frames):
             tl, pr, cl, rw, trunc = got[rank][f]
             assert tl == want[f][0].tolist() and cl == want[f][2].tolist() and rw == want[f][3].tolist()
             assert np.allclose(pr, want[f][1]) and not trunc
+
+
+def _big_dets(frame_id, k):
+    rs = np.random.RandomState(1000 + frame_id)
+    c = rs.randint(0, 500, size=(k, 2))
+    tlbr = np.concatenate([c, c + rs.randint(1, 50, size=(k, 2))], axis=1).astype(np.int64)
+    return [tlbr, rs.rand(k).astype(np.float32), rs.randint(0, 80, size=k).astype(np.int64), np.arange(k, dtype=np.int64)]
+
+
+def _ragged_frames(n_frames, kmax):
+    """Frame 1 keeps 2 x kmax boxes, frame n - 1 keeps kmax + 1, the others a handful."""
+    return [_big_dets(f, 2 * kmax) if f == 1 else (_big_dets(f, kmax + 1) if f == n_frames - 1 else _fake_dets(f)) for f in range(n_frames)]
+
+
+def _ragged_worker(rank, world, port, n_frames, kmax, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(n_frames, rank, world)
+    dets = _ragged_frames(n_frames, kmax)[lo:hi]
+    first = all_gather_records(torch.from_numpy(pack_records_host(dets, kmax)), world)
+    calls = []
+
+    def repack(kmax2):
+        calls.append(kmax2)
+        return pack_records_host(dets, kmax2)
+    full = regather_if_truncated(first, kmax, repack, world)
+    out = unpack_records(full)
+    q.put((rank, calls, [(d[0].tolist(), d[1].tolist(), d[2].tolist(), d[3].tolist(), d[4]) for d in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frames_with_more_than_kmax_boxes_are_gathered_in_full():
+    """VERDICT r04 item 4a / SURVEY.md 8(e) "ragged alternative": with N ranks a frame that keeps more than kmax boxes is not
+    truncated -- the true counts ride in the first gather, every rank sees the same maximum, packs again with room for it and
+    ONE more all-gather returns every kept box of every frame on every rank, equal to the single-rank lists."""
+    world, n_frames, kmax = 2, 6, 16
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, n_frames, kmax, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, calls, frames = q.get(timeout=120)
+        got[rank] = (calls, frames)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = _ragged_frames(n_frames, kmax)
+    for rank in range(world):
+        calls, frames = got[rank]
+        assert calls == [64]                          # one re-pack on EVERY rank (also the one whose frames all fit): 2 x 16 -> 64
+        assert len(frames) == n_frames
+        for f in range(n_frames):
+            tl, pr, cl, rw, trunc = frames[f]
+            assert not trunc and len(pr) == len(want[f][1])
+            assert tl == want[f][0].tolist() and cl == want[f][2].tolist() and rw == want[f][3].tolist()
+            assert np.array_equal(np.array(pr, dtype=np.float32), want[f][1])
+    # nothing above kmax: the first gather is returned as it is, no second collective
+    rec = torch.from_numpy(pack_records_host([_fake_dets(f) for f in range(4)], kmax))
+    assert regather_if_truncated(rec, kmax, lambda k: (_ for _ in ()).throw(AssertionError("no repack expected")), 1) is rec
 
 
 def _run_bench(args, env_extra=None, timeout=300):

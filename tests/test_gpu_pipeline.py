@@ -73,6 +73,81 @@ def test_pipeline_refetches_frames_with_more_than_kmax_detections():
         assert _same(g, w)
 
 
+def test_upload_done_follows_the_host_buffer_not_the_device_buffer():
+    """``upload_done(j)`` must answer for the upload that last READ ``host_frames(j)``.  A caller that
+    double-buffers with host buffers 0 / 1 while the pipeline rotates six device buffers: with the copy stream held up (a long
+    sleep kernel queued on it), the third upload -- host buffer 0 again, device buffer 2 -- is still pending, so buffer 0 must
+    NOT be reported free (it was, from the long-finished first upload's event), and the results stay those of the frames."""
+    net = _net("yolov3-tiny", "float32")
+    frames = synth_frames(77, 16, 416, 416)
+    want = [yolov3.inference(net, f, prob_thresh=0.1, nms_iou_thresh=0.3, return_rows=True)[0] for f in frames]
+    pipe = Pipeline(net, 2, in_flight=3, prob_thresh=0.1, nms_iou_thresh=0.3)
+    tickets, got = [], []
+    for b in range(8):
+        j = b % 2
+        host = pipe.host_frames(j)
+        assert pipe.upload_done(j)                               # waits for the upload that read THIS buffer
+        host.copy_(torch.from_numpy(frames[2 * b:2 * b + 2]))
+        if b == 2:
+            with torch.cuda.stream(pipe.copy_stream):
+                torch.cuda._sleep(200_000_000)                   # ~0.1 s: the next upload queues behind it
+        if len(tickets) == pipe.max_open:
+            got += pipe.results(tickets.pop(0), return_rows=True)
+        tickets.append(pipe.submit(host))
+        if b == 2:
+            assert not pipe.upload_done(0, wait=False), "host buffer 0 reported free while its upload is still queued"
+            assert pipe.upload_done(1, wait=False)               # buffer 1's upload (b = 1) finished long ago
+    for t in tickets:
+        got += pipe.results(t, return_rows=True)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert _same(g, w)
+
+
+_REGATHER_SCRIPT = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import numpy as np, torch, torch.distributed as dist, yolov3
+from yolov3 import weights as W
+from yolov3.pipeline import Pipeline
+from yolov3.synthdata import synth_frames
+from golden_util import MODELS
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[3], rank=0, world_size=1, device_id=torch.device("cuda", 0))
+net = yolov3.Darknet(MODELS["yolov3-tiny"], device="cuda", dtype="float32").eval()
+net.set_params(W.synth_params(net.blocks, net.net_info, seed=0, obj_bias=-2.0, calib=W.load_calibration("yolov3-tiny")))
+frames = synth_frames(5, 2, 416, 416)
+want = [yolov3.inference(net, f, prob_thresh=0.05, nms_iou_thresh=0.3)[0] for f in frames]
+pipe = Pipeline(net, 2, in_flight=2, prob_thresh=0.05, nms_iou_thresh=0.3, kmax=8, world=1)
+assert pipe.gathers[0].collective
+ok = True
+for rep in range(3):                                  # the second gather must not disturb the tickets around it
+    got = pipe.results(pipe.submit(frames))
+    ok = ok and len(got) == len(want) and all(len(g) == len(w) and all(np.array_equal(a, b) for a, b in zip(g, w)) for g, w in zip(got, want))
+print(json.dumps({"equal": bool(ok), "most_kept": max(len(w[1]) for w in want)}))
+dist.destroy_process_group()
+"""
+
+
+def test_frames_over_kmax_are_regathered_through_rccl():
+    """VERDICT r04 item 4a on the GPU: with a process group up (one rank here: the only thing a 1-GPU box can run; world 2 is the
+    gloo test tests/test_dist_gloo.py::test_frames_with_more_than_kmax_boxes_are_gathered_in_full) a frame that keeps more than
+    kmax boxes goes through the second all-gather -- pack with room for the largest count on the device, RCCL, unpack -- and the
+    lists equal per-frame ``inference()``."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, "-c", _REGATHER_SCRIPT, os.path.join(ROOT, "pytorch-yolov3_amd"), os.path.join(ROOT, "tests"),
+                           str(port)], capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0, proc.stderr[-2500:]
+    d = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][0])
+    assert d["most_kept"] > 8 and d["equal"], d
+
+
 _RATE_SCRIPT = r"""
 import json, sys, time
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
