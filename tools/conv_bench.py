@@ -57,6 +57,8 @@ VARIANTS = [
     ("halo_ws_256", dict(BASE, auto_mask=AM.AM_HALO_ALL | AM.AM_HALO_TILE256)),
     ("igemm_v2_bn128", dict(BASE, auto_mask=AM.AM_NO_BN_SHRINK)),
     ("wres_1x1", dict(BASE, auto_mask=AM.AM_WRES_ALWAYS)),           # weights-resident persistent 1x1 kernel wherever it is supported
+    ("igemm_v4_256", dict(BASE, igemm_version=4)),                   # register-staged loader waves, 256 x 128 tiles (round 5)
+    ("igemm_v4_128", dict(BASE, igemm_version=4, igemm_bm=128)),     # ... 128 x 128 tiles, two workgroups per CU
 ]
 
 
@@ -83,8 +85,8 @@ def main():
     if os.environ.get("Y3_CONV_BENCH_DEBUG"):          # diagnostic libraries only (timing experiments)
         _hip.check(lib.y3_set_tuning(b"debug", int(os.environ["Y3_CONV_BENCH_DEBUG"])))
     dev = torch.device("cuda:0")
-    bf = args.dtype == "bf16"
-    tdt = torch.bfloat16 if bf else torch.float32
+    bf = args.dtype in ("bf16", "fp16")                  # a 16-bit storage mode
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.dtype, torch.float32)
     es = 2 if bf else 4
     zero = torch.zeros(4096, dtype=torch.uint8, device=dev)
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -114,7 +116,7 @@ def main():
             outs.append(torch.zeros((B, ho, ho, out_ld), dtype=torch.float32 if (f32out or not bf) else tdt, device=dev))
         op = _hip.Y3Op()
         op.kind = _hip.OP_CONV
-        op.dtype = _hip.Y3_BF16 if bf else _hip.Y3_F32
+        op.dtype = {"bf16": _hip.Y3_BF16, "fp16": _hip.Y3_F16}.get(args.dtype, _hip.Y3_F32)
         op.flags = _hip.F_LEAKY | (_hip.F_RESIDUAL if res else 0) | (_hip.F_OUT_F32 if (f32out and bf) else 0)
         op.batch = B
         op.in_h = op.in_w = h
