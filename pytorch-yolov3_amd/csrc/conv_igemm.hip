@@ -19,8 +19,6 @@
 // Padding taps and M-tail rows read a zero page instead of branching.
 #include <string.h>
 
-#include <type_traits>
-
 #include "common.h"
 #include "decode_core.h"
 
@@ -912,293 +910,11 @@ void conv_igemm3_kernel(IgemmArgs p) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// v4 (round 5): wave-specialised like v3, but the loader waves stage the operands THROUGH REGISTERS
-// (global_load_dwordx4 -> ds_write_b128) instead of LDS-DMA, on tiles of BM = 256 (or 128) pixels x 128 channels.
-// Why it was built: a CU takes in 28.8 B/clk through L1 misses by LDS-DMA and 39.7 B/clk through registers
-// (profiles/r04s_fill_path.txt); a 128 x 128 x 64 step must stage 64 B per MFMA clock, a 256 x 128 x 64 step 48 B.
-// Pipeline: two LDS stages + two register sets per loader lane.  During the consumers' step kt the loaders write tile kt + 1
-// (in registers since two steps) into the stage tile kt - 1 vacated and issue the loads of tile kt + 3 into the registers that
-// became free: a load has two K-steps to land, one raw barrier per step pairs "tile kt is in LDS" with "stage of kt - 1 free".
-// K order: channel chunk outermost, tap innermost -- bit-identical to v1 / v2 / v3 and the strip / patch kernels.
-// KMODE 0 only (Cin a multiple of the 64- / 32-element K-tile): what the stride-2 3x3 and the 1x1 layers of Darknet-53 are.
-// The loads are inline asm with counted waits: left to the compiler, the wait before a tile's ds_write was vmcnt(0) at the
-// loop header (it cannot see across the back edge that exactly the twelve loads of the following tile are younger), which
-// halves the distance the loads run ahead.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N + 256) void conv_igemm4_kernel(IgemmArgs p) {
-  constexpr int NC = 64 * WAVES_M * WAVES_N;         // consumer (MFMA) threads
-  constexpr int NL = 256;                            // loader threads: 4 waves, one per SIMD
-  constexpr int RB = 128;
-  constexpr int ES = sizeof(T);
-  constexpr int BKE = RB / ES;
-  constexpr int G = RB / 64;
-  constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
-  constexpr int MI = TM / 16, NI = TN / 16;
-  constexpr int RPL = NL / 8;                        // rows per loader pass (32)
-  constexpr int A_CH = BM / RPL, B_CH = BN / RPL;    // 16-byte pieces per loader lane and K-tile
-  constexpr int STAGE = (BM + BN) * RB;
-  static_assert(MI >= 1 && NI >= 1 && BM % RPL == 0 && BN % RPL == 0, "tile shape");
+// (Round 5: a v4 -- v3 with REGISTER-STAGED loader waves, global_load_dwordx4 -> ds_write_b128, on 256 x 128 and 128 x 128
+// tiles -- was built, bit-identical, and measured 480 / 658 / 582 / 711 TFLOP/s on the four stride-2 layers against 568 / 772 /
+// 846 / 797 for v2 / v3: removed again, profiles/r05b_igemm4_register_staged.txt; the history keeps it.)
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // max(2 stages, the fp32 output tile)
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = wave >= NC / 64;
-
-  const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (p.n_major ? tile % p.m_tiles : tile / p.n_tiles) * BM;
-  const int n0 = (p.n_major ? tile / p.m_tiles : tile % p.n_tiles) * BN;
-  const int n_kt = p.n_ktiles;
-
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int wm = (wave % (NC / 64)) / WAVES_N, wn = (wave % (NC / 64)) % WAVES_N;
-  const int fr = lane & 15, fq = lane >> 4;
-
-  if (loader) {
-    __builtin_amdgcn_s_setprio(3);
-    const int ltid = tid - NC;
-    const int slot = ltid & 7;
-    const int row0 = ltid >> 3;
-    const int kc = slot ^ (row0 & 7);                 // logical chunk at this LDS position (swizzle on the source side)
-    int a_off[A_CH];                                  // byte offset of the lane's piece from p.in (signed: padding rows lie before
-    uint32_t a_taps[A_CH];                            // the tensor; the launcher checks that it has fewer than 2^31 bytes)
-#pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      const int m = m0 + row0 + RPL * i;
-      a_off[i] = 0;
-      a_taps[i] = 0u;
-      if (m < p.M) {
-        const uint32_t um = (uint32_t)m;
-        const uint32_t b = (__umulhi(um, p.mul_hw) + um) >> p.sh_hw;
-        const uint32_t rem = um - b * (uint32_t)p.HoWo;
-        const uint32_t oy = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
-        const uint32_t ox = rem - oy * (uint32_t)p.Wo;
-        const int iy0 = (int)oy * p.stride - p.pad;
-        const int ix0 = (int)ox * p.stride - p.pad;
-        a_off[i] = (((int)b * p.H + iy0) * p.W + ix0) * (p.in_ld * ES) + kc * 16;
-        uint32_t vx = 0u, mask = 0u;
-        for (int kx = 0; kx < p.ks; ++kx) vx |= ((unsigned)(ix0 + kx) < (unsigned)p.W ? 1u : 0u) << kx;
-        for (int ky = 0; ky < p.ks; ++ky)
-          if ((unsigned)(iy0 + ky) < (unsigned)p.H) mask |= vx << (ky * p.ks);
-        a_taps[i] = mask;
-      }
-    }
-    const uint32_t b_lane = (uint32_t)row0 * (uint32_t)p.k_ld * ES + kc * 16;
-    const char *b_tile = p.wgt + ((long long)n0 * p.k_ld) * ES;
-    const long long b_pass = (long long)RPL * p.k_ld * ES;
-    char *my_lds = smem + ltid * 16;                  // + stage * STAGE + pass * (NL * 16): lane-linear, 4 KiB per pass
-
-    u32x4 ra[2][A_CH], rb[2][B_CH];                   // two register sets, addressed statically (the loop is unrolled by two)
-    // (the lambdas take the register sets through pointers: hipcc does not capture a variable that a generic lambda names
-    // in asm operands only)
-    // Tiles past the last one are "fetched" too -- every piece from the zero page -- so that each step issues the same twelve
-    // loads and the counted wait below is one constant (a second code path with vmcnt(0) made hipcc merge the two through a
-    // third register set: 24 moves a step and spills).
-    auto fetch = [&](int kt, auto setc) {
-      constexpr int S = decltype(setc)::value;
-      u32x4(*pa)[A_CH] = ra;
-      u32x4(*pb)[B_CH] = rb;
-      const bool live = kt < n_kt;
-      const int chunk = kt / p.n_taps;                // chunk outermost, tap innermost
-      const int tap = kt - chunk * p.n_taps;
-      const int ky = tap / p.ks, kx = tap - ky * p.ks;
-      const char *a_tap = p.in + ((long long)(ky * p.W + kx) * p.in_ld + chunk * BKE) * ES;     // wave-uniform
-      const long long koff = ((long long)tap * p.Cin + chunk * BKE) * ES;
-#pragma unroll
-      for (int i = 0; i < B_CH; ++i) {
-        const char *base = live ? b_tile + (koff + i * b_pass) : p.zero;       // wave-uniform
-        const uint32_t off = live ? b_lane : 0u;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pb[S][i]) : "v"(off), "s"(base) : "memory");
-      }
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i) {
-        const char *src = (live && ((a_taps[i] >> tap) & 1u)) ? a_tap + a_off[i] : p.zero;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pa[S][i]) : "v"(src) : "memory");
-      }
-    };
-    // every load of set S has landed; at most `YOUNGER` loads issued after them (the next tile's, into the other set) may fly
-    auto landed = [&](auto setc, auto younger) {
-      constexpr int S = decltype(setc)::value;
-      constexpr int Y = decltype(younger)::value;
-      u32x4(*pa)[A_CH] = ra;
-      u32x4(*pb)[B_CH] = rb;
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Y) : "memory");
-      // (volatile asm statements keep their order: every use of the set's registers below comes after the wait)
-#pragma unroll
-      for (int i = 0; i < B_CH; ++i) asm volatile("" : "+v"(pb[S][i]));
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i) asm volatile("" : "+v"(pa[S][i]));
-    };
-    constexpr std::integral_constant<int, A_CH + B_CH> PER{};
-    auto stash = [&](int stage, auto setc) {
-      constexpr int S = decltype(setc)::value;
-      char *sA = my_lds + stage * STAGE;
-      char *sB = sA + BM * RB;
-#pragma unroll
-      for (int i = 0; i < B_CH; ++i) *reinterpret_cast<u32x4 *>(sB + i * (NL * 16)) = rb[S][i];
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4 *>(sA + i * (NL * 16)) = ra[S][i];
-    };
-    using std::integral_constant;
-    constexpr integral_constant<int, 0> S0{};
-    constexpr integral_constant<int, 1> S1{};
-    fetch(0, S0);
-    fetch(1, S1);
-    landed(S0, PER);
-    stash(0, S0);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(2, S0);
-    __builtin_amdgcn_sched_barrier(0);
-    // step kt: B(kt); tile kt + 1 (set (kt + 1) & 1) -> stage (kt + 1) & 1; loads of tile kt + 3 into that set
-    auto step = [&](int kt, auto setc) {
-      __builtin_amdgcn_s_waitcnt(0xC07F);             // this lane's LDS writes of tile kt are done ...
-      __builtin_amdgcn_s_barrier();                   // ... everyone's; the consumers are done with tile kt - 1
-      if (kt + 1 < n_kt) {
-        // tile kt + 1 sits in this set's registers once its loads are in; the only younger loads are tile kt + 2's
-        landed(setc, PER);
-        stash((kt + 1) & 1, setc);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(kt + 3, setc);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    int kt = 0;
-#pragma unroll 1
-    for (; kt + 1 < n_kt; kt += 2) {
-      step(kt, S1);
-      step(kt + 1, S0);
-    }
-    if (kt < n_kt) step(kt, S1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's dummy loads: nothing may land in a register that is reused
-  } else {
-    // ---------------- consumer waves: fragment reads + MFMAs only (two per SIMD at BM = 256) ----------------
-    if (NC > 256 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    for (int kt = 0; kt < n_kt; ++kt) {
-      __builtin_amdgcn_s_barrier();
-      const char *sA = smem + (kt & 1) * STAGE;
-      const char *sB = sA + BM * RB;
-      u32x4 xf[G][MI], wf[G][NI];
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const int row = wn * TN + ni * 16 + fr;
-          wf[g][ni] = *reinterpret_cast<const u32x4 *>(sB + row * RB + ((((g * 4 + fq) ^ (row & 7))) << 4));
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int row = wm * TM + mi * 16 + fr;
-          xf[g][mi] = *reinterpret_cast<const u32x4 *>(sA + row * RB + ((((g * 4 + fq) ^ (row & 7))) << 4));
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < G; ++g)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], wf[g][ni], xf[g][mi]);
-    }
-  }
-
-  // ---------------- epilogue: the consumer threads write out (as in the strip kernel) ----------------
-  constexpr int OCT_PER_ROW = BN / 8;
-  constexpr int WR = BM * OCT_PER_ROW / NC;
-  static_assert(WR * NC == BM * OCT_PER_ROW && NC % OCT_PER_ROW == 0, "write-out must tile evenly");
-  constexpr int CPR = BN / 4;
-  constexpr int SWZ = (CPR < 16 ? CPR : 16) - 1;
-  float *sC = reinterpret_cast<float *>(smem);
-  const int oc_mine = tid % OCT_PER_ROW;
-  const int co = n0 + oc_mine * 8;
-  const bool has_res = p.flags & Y3_F_RESIDUAL;
-  const bool leaky = p.flags & Y3_F_LEAKY;
-  const int nvalid = p.Cout - co < 8 ? p.Cout - co : 8;
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_s_barrier();         // every consumer is done reading the last stage
-  f32x4 sc_lo, sc_hi, bi_lo, bi_hi;
-  u32x4 resv[WR];
-  const bool res_fast = has_res && sizeof(T) == 2 && (p.res_ld % 8) == 0 && co + 8 <= p.Cout;
-  if (!loader) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int cl = wn * TN + ni * 16 + fq * 4;
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int pl = wm * TM + mi * 16 + fr;
-        *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
-      }
-    }
-    sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
-    sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
-    bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
-    bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
-    if (res_fast) {
-#pragma unroll
-      for (int j = 0; j < WR; ++j) {
-        const int m = m0 + (tid / OCT_PER_ROW) + j * (NC / OCT_PER_ROW);
-        const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
-        resv[j] = (m < p.M && co < p.Cout) ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
-      }
-    }
-  }
-  __syncthreads();
-  if (loader || nvalid <= 0) return;
-#pragma unroll
-  for (int j = 0; j < WR; ++j) {
-    const int pl = (tid / OCT_PER_ROW) + j * (NC / OCT_PER_ROW);
-    const int m = m0 + pl;
-    if (m >= p.M) continue;
-    const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
-    const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
-    float v[8];
-    y3_bn_leaky8(v, lo, hi, sc_lo, sc_hi, bi_lo, bi_hi, leaky);
-    if (has_res) {
-      if (res_fast) {
-        if constexpr (sizeof(T) == 2) y3_add8<T>(v, resv[j]);
-      } else {
-        const T *rp = reinterpret_cast<const T *>(p.res) + (long long)m * p.res_ld + co;
-        for (int r = 0; r < nvalid; ++r) v[r] += y3_to_float<T>(rp[r]);
-      }
-    }
-    T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
-    bool done = false;
-    if constexpr (sizeof(T) == 2) {
-      if (nvalid == 8 && (p.out_ld % 8) == 0) {
-        *reinterpret_cast<u32x4 *>(op) = y3_pack8<T>(v);
-        done = true;
-      }
-    }
-    if (!done)
-      for (int r = 0; r < nvalid; ++r) op[r] = y3_from_float<T>(v[r]);
-  }
-}
-
-template <typename T, int BM, int BN, int WM, int WN>
-int launch_cfg4(IgemmArgs a, hipStream_t s) {
-  constexpr size_t kLds = 2 * (BM + BN) * 128 > BM * BN * 4 ? 2 * (BM + BN) * 128 : BM * BN * 4;
-  static Y3DeviceOnce once;
-  {
-    const int rc = once.run([]() -> int {
-      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm4_kernel<T, BM, BN, WM, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
-      return Y3_OK;
-    });
-    if (rc != Y3_OK) return rc;
-  }
-  a.m_tiles = y3_ceil_div(a.M, BM);
-  a.n_tiles = y3_ceil_div(a.Cout, BN);
-  hipLaunchKernelGGL((conv_igemm4_kernel<T, BM, BN, WM, WN>), dim3(a.m_tiles * a.n_tiles), dim3(64 * WM * WN + 256), kLds, s, a);
-  Y3_HIP_CHECK(hipGetLastError());
-  return Y3_OK;
-}
-
-// y3_options: igemm_version 1 = register-staged single buffer, 2 = LDS-DMA double buffer, 3 = wave-specialised, 4 = wave-
-// specialised with register-staged loaders (256 x 128 tiles; igemm_bm = 128: 128 x 128), bf16 / fp16 layers it supports;
+// y3_options: igemm_version 1 = register-staged single buffer, 2 = LDS-DMA double buffer, 3 = wave-specialised;
 // igemm_bm 64 = 64-pixel tiles for the wave-specialised kernel (bf16), else 128; igemm_ns = its LDS stages (3 or 4)
 
 template <typename T, int BM, int BN, int WM, int WN, int NS>
@@ -1344,17 +1060,6 @@ int y3_launch_conv_igemm(const y3_op &op, const void *d_in, const void *d_zero, 
     *kernel_name = Y3_KNAME(dt, "conv_igemm_", "_128x32");
     if (dry_run) return Y3_OK;
     return y3_by_dtype(dt, [&](auto tag) { return launch_cfg<decltype(tag), 128, 32, 4, 1>(a, generic, s); });
-  }
-  if (version == 4 && bn == 128 && bf && kmode == 0 && !(op.flags & Y3_F_OUT_F32) && op.out_c % 8 == 0 &&
-      (long long)op.batch * op.in_h * op.in_w * op.in_ld * es < (1ll << 31)) {      // 32-bit signed byte offsets into the input
-    if (bm_knob == 128) {
-      *kernel_name = Y3_KNAME(dt, "conv_igemm4_", "_128x128");
-      if (dry_run) return Y3_OK;
-      return y3_by_dtype16(dt, [&](auto tag) { return launch_cfg4<decltype(tag), 128, 128, 2, 2>(a, s); });
-    }
-    *kernel_name = Y3_KNAME(dt, "conv_igemm4_", "_256x128");
-    if (dry_run) return Y3_OK;
-    return y3_by_dtype16(dt, [&](auto tag) { return launch_cfg4<decltype(tag), 256, 128, 4, 2>(a, s); });
   }
   if (version == 3 && bn == 128 && bm_knob == 64 && bf && !(op.flags & Y3_F_OUT_F32)) {
     *kernel_name = Y3_KNAME(dt, "conv_igemm3_", "_64x128");   // 64-pixel tiles: twice the workgroups, two per CU at 3 stages

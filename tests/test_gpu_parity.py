@@ -444,9 +444,6 @@ def test_kernel_choice_does_not_change_a_bit(dtype):
     for opts in ({"auto_mask": _hip.AM_IGEMM_ONLY}, {"auto_mask": halo | _hip.AM_PATCH_WIDE}, {"auto_mask": halo | _hip.AM_HALO_TILE256},
                  {"auto_mask": _hip.AM_IGEMM_ONLY, "igemm_version": 3, "igemm_ns": 3},
                  {"auto_mask": _hip.AM_IGEMM_ONLY, "igemm_bm": 96},           # 96 x 64 tiles wherever Cout is a multiple of 64
-                 # register-staged loader waves (round 5: csrc/conv_igemm.hip v4), 256- and 128-pixel tiles, on every 16-bit
-                 # layer they support (float32: not instantiated, the knob changes nothing)
-                 {"auto_mask": _hip.AM_IGEMM_ONLY, "igemm_version": 4}, {"auto_mask": _hip.AM_IGEMM_ONLY, "igemm_version": 4, "igemm_bm": 128},
                  None):
         net = _net("yolov3", dtype=dtype, options=opts)
         outs.append({k: v.clone() for k, v in net.forward_frames(frames).items()})

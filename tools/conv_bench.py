@@ -57,8 +57,6 @@ VARIANTS = [
     ("halo_ws_256", dict(BASE, auto_mask=AM.AM_HALO_ALL | AM.AM_HALO_TILE256)),
     ("igemm_v2_bn128", dict(BASE, auto_mask=AM.AM_NO_BN_SHRINK)),
     ("wres_1x1", dict(BASE, auto_mask=AM.AM_WRES_ALWAYS)),           # weights-resident persistent 1x1 kernel wherever it is supported
-    ("igemm_v4_256", dict(BASE, igemm_version=4)),                   # register-staged loader waves, 256 x 128 tiles (round 5)
-    ("igemm_v4_128", dict(BASE, igemm_version=4, igemm_bm=128)),     # ... 128 x 128 tiles, two workgroups per CU
 ]
 
 
