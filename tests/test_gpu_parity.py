@@ -225,6 +225,42 @@ def test_inference_bench_regime_all_sample_images_fp32(model):
     assert n_clean >= 4
 
 
+@pytest.mark.parametrize("model", ["yolov3-tiny", "yolov3", "yolov3-spp"])
+def test_inference_exact_identity_set_fp32(model):
+    """G7x (round 5): "identical box indices / classes after NMS" on a fixture that is thick enough for
+    Darknet-53 too -- >= 20 audited-clean (frame, threshold) pairs and >= 200 kept boxes per model at thresholds 0.2 / 0.3 and
+    0.3 / 0.3 (tools/make_goldens.py g7x_exact: the reference's ``inference()``, one frame per call, on the sample images and on
+    procedural frames; a pair is kept only if no deviation below 6e-5 can move a pixel, a threshold test, an arg-max or a
+    suppression).  The float32 HIP path must return EVERY list exactly: rows, classes, integer boxes; no flip rule, no
+    exemption.  The fp16 / bf16 paths are counted on the same set (printed; fp16 asserted to match the large majority)."""
+    from golden_util import bench_regime_frame
+    g = np.load(os.path.join(GOLDEN, "inference_exact_%s.npz" % model))
+    pairs = [str(p) for p in g["pairs"]]
+    dim = MODEL_DIMS[model]
+    exact = {}
+    for dtype in ("float32", "fp16", "bf16"):
+        net = yolov3.Darknet(MODELS[model], device="cuda", dtype=dtype)
+        net.load_weights(golden_weights_path(model, obj_bias=float(g["obj_bias"]))).eval()
+        n_same = boxes = 0
+        for p in pairs:
+            name, tag = p.rsplit("_", 1)
+            pth, ith = g[tag + "_thresholds"]
+            frame = bench_regime_frame(name, dim)
+            res = yolov3.inference(net, frame, device="cuda", prob_thresh=float(pth), nms_iou_thresh=float(ith), return_rows=True)[0]
+            order, gorder = np.argsort(res[3]), np.argsort(g[p + "_rows"])
+            same = (len(order) == len(gorder) and np.array_equal(res[3][order], g[p + "_rows"][gorder]) and
+                    np.array_equal(res[2][order], g[p + "_cls"][gorder]) and np.array_equal(res[0][order], g[p + "_tlbr"][gorder]))
+            if dtype == "float32":
+                assert same, (model, p, "differs from the reference's list")
+                np.testing.assert_allclose(res[1][order], g[p + "_prob"][gorder], atol=SCORE_ATOL)
+            n_same += int(same)
+            boxes += len(g[p + "_rows"])
+        exact[dtype] = n_same
+        print("%s %s: %d of %d audited-clean pairs (%d kept boxes) reproduced EXACTLY" % (model, dtype, n_same, len(pairs), boxes))
+    assert exact["float32"] == len(pairs) >= 20 and boxes >= 200
+    assert exact["fp16"] >= exact["bf16"]
+
+
 @pytest.mark.parametrize("model", ["yolov3-tiny", "yolov3"])
 def test_inference_net_sized_crops_fp32(model):
     """G7c: the reference's ``inference()`` lists on net-sized centre crops of the sample images (no resize anywhere between

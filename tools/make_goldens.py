@@ -26,6 +26,8 @@ Golden sets:
                                + audited-clean procedural frames (exact identity, no exemption)
   G7c inference_crops_<model>.npz  the same records on NET-SIZED centre crops of the sample images (416^2: eight images;
                                608^2: the one 640 x 640 image): end-to-end fixtures that pass through no resize at all
+  G7x inference_exact_<model>.npz  >= 24 audited-clean (frame, threshold) pairs / >= 240 kept boxes per model at thresholds
+                               0.2 and 0.3: exact identity with no exemption, on Darknet-53 as well (round 5)
   G9 coco_export.json         to_coco() and devtools.coco_util.match_ids() on a small detection set
 """
 import hashlib
@@ -435,6 +437,84 @@ def g7p_bench_regime(model, n_synth_search=60, n_synth_keep=4, crops=False):
             print("G7'", model, "%-10s %s candidates %4d kept %3d fragile %3d clean %s" % row)
 
 
+# ---------------------------------------------------------------- G7x (exact identity, Darknet-53: VERDICT r04 item 5)
+EXACT_OBJ_BIAS = {"yolov3": -7.5, "yolov3-spp": -8.5, "yolov3-tiny": -4.0}
+EXACT_TAGS = (("b", 0.2, 0.3), ("c", 0.3, 0.3))
+
+
+def g7x_exact(model, want_pairs=24, want_boxes=240, max_frames=400, obj_bias=None, explore=0):
+    """AUDITED-CLEAN (frame, threshold) pairs only, enough of them: the reference's inference() -- one frame per call, like its
+    own test (/root/reference/tests/test_inference.py:51-59) -- on the nine sample images and on procedural frames, at
+    thresholds 0.2 / 0.3 and 0.3 / 0.3 and an objectness bias that leaves ten to forty candidates per frame.  A pair is kept
+    only if, ON THE REFERENCE'S OWN NUMBERS, every candidate's four scaled coordinates are at least DIST_PX from an integer,
+    every score of the frame at least THR_MARGIN from the threshold, every candidate's class margin at least CLS_MARGIN and every
+    IoU the greedy NMS evaluates at least 1e-4 from its threshold: no float32 deviation below 6e-5 (measured for the HIP path:
+    < 6e-5 on boxes, < 1.5e-5 on scores) can then move an integer, a threshold test, an arg-max or a suppression, so a
+    correct float32 implementation returns EXACTLY these lists -- rows, classes, boxes -- with no exemption
+    (tests/test_gpu_parity.py::test_inference_exact_identity_set_fp32 asserts >= 20 pairs and >= 200 boxes per model).
+    tests/golden/inference_exact_<model>.npz."""
+    dim = MODELS[model]["dim"]
+    obj_bias = EXACT_OBJ_BIAS[model] if obj_bias is None else obj_bias
+    net = make_net(model, obj_bias=obj_bias)
+    arrays, pairs = {}, []
+    boxes = frames_seen = 0
+    sources = [("img" + j[6:12], None) for j in SAMPLE_IMAGES] + [("synth%d" % s, s) for s in range(2000, 2000 + max_frames)]
+    for name, seed in sources:
+        frame = load_jpeg_bgr("000000%s.jpg" % name[3:]) if seed is None else SD.synth_frames(seed, 1, dim, dim)[0]
+        frames_seen += 1
+        resized = PP.resize_bilinear_u8(frame, dim, dim)
+        x = torch.tensor(np.transpose(np.flip(resized[None], 3), (0, 3, 1, 2)).astype(np.float32) / 255.0)
+        raw = net.forward(x)
+        bb = raw["bbox_xywh"].detach().numpy()[0]
+        pr = raw["class_prob"].detach().numpy()[0]
+        ci = raw["class_idx"].numpy()[0]
+        margin = None
+        for tag, pth, ith in EXACT_TAGS:
+            cand = np.where(pr >= pth)[0]
+            if len(cand) < 3:
+                continue
+            oh, ow = frame.shape[:2]
+            sc = bb[cand].copy()
+            sc[:, [0, 2]] *= ow
+            sc[:, [1, 3]] *= oh
+            dist = np.abs(sc - np.rint(sc)).min(axis=1)
+            thr_margin = float(np.abs(pr - np.float32(pth)).min())
+            if dist.min() < DIST_PX or thr_margin < THR_MARGIN:
+                if explore:
+                    print("  ", name, tag, "cand", len(cand), "not clean (pixel / threshold)")
+                continue
+            if margin is None:
+                margin = cls_margin(net, x)[0]
+            ti = ref.cxywh_to_tlbr(sc.astype(np.int64))
+            iou_margin = nms_iou_margin(ti, pr[cand], ci[cand], ith) if len(cand) > 1 else 1.0
+            if margin[cand].min() < CLS_MARGIN or iou_margin < 1e-4:
+                continue
+            res = ref.inference(net, [frame], device="cpu", prob_thresh=pth, nms_iou_thresh=ith)
+            tlbr, prob, cls = res[0]
+            keep = ref.non_max_suppression(ti, pr[cand], class_idx=ci[cand], iou_thresh=ith)
+            assert np.array_equal(ti[keep], tlbr) and np.array_equal(pr[cand][keep], prob)
+            key = "%s_%s_" % (name, tag)
+            arrays[key + "tlbr"] = tlbr.astype(np.int64)
+            arrays[key + "prob"] = prob.astype(np.float32)
+            arrays[key + "cls"] = cls.astype(np.int64)
+            arrays[key + "rows"] = cand[keep].astype(np.int64)
+            arrays[key + "audit"] = np.array([float(dist.min()), thr_margin, float(margin[cand].min()), iou_margin, len(cand)])
+            pairs.append(key[:-1])
+            boxes += len(keep)
+            print("G7x", model, key[:-1], "candidates", len(cand), "kept", len(keep), "| pairs", len(pairs), "boxes", boxes)
+        if (len(pairs) >= want_pairs and boxes >= want_boxes) or (explore and frames_seen >= explore):
+            break
+    print("G7x", model, "obj_bias", obj_bias, ":", len(pairs), "clean pairs,", boxes, "kept boxes from", frames_seen, "frames")
+    if explore:
+        return
+    assert len(pairs) >= want_pairs and boxes >= want_boxes, "not enough clean pairs: raise max_frames"
+    arrays["pairs"] = np.array(pairs)
+    arrays["obj_bias"] = np.array(obj_bias)
+    for tag, pth, ith in EXACT_TAGS:
+        arrays[tag + "_thresholds"] = np.array([pth, ith])
+    np.savez_compressed(os.path.join(GOLD, "inference_exact_%s.npz" % model), **arrays)
+
+
 # ---------------------------------------------------------------- G6
 def g6_nms():
     cases = []
@@ -519,6 +599,12 @@ if __name__ == "__main__":
     if "g7p" in which:
         for model in MODELS:
             g7p_bench_regime(model)
+    if "g7x" in which:
+        for model in ("yolov3", "yolov3-spp", "yolov3-tiny"):
+            g7x_exact(model)
+    if "g7x-explore" in which:                     # how many candidates / clean pairs a bias gives, 12 frames, nothing written
+        for bias in (-6.0, -7.0, -7.5):
+            g7x_exact("yolov3", obj_bias=bias, explore=12)
     if "g7c" in which:
         for model in ("yolov3-tiny", "yolov3"):
             g7p_bench_regime(model, crops=True)
