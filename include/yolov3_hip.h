@@ -40,6 +40,7 @@ extern "C" {
 /* element types of activations / weights */
 #define Y3_F32 0
 #define Y3_BF16 1
+#define Y3_F64 3   /* float64: box coordinates handed to y3_nms_float / y3_cxywh_to_tlbr_float only (no network runs in it) */
 #define Y3_F16 2   /* IEEE half storage, float32 accumulation: every kernel of the bf16 mode instantiated on
                       v_mfma_f32_16x16x32_f16 (same rate, same bytes, 11 instead of 8 significand bits) */
 
@@ -219,8 +220,18 @@ int y3_nms(const int64_t *d_tlbr, const float *d_prob, const int64_t *d_cls, int
            void *d_workspace, size_t workspace_bytes, int64_t *d_keep, int32_t *d_keep_count,
            void *stream);
 
+/* the same on FLOATING-POINT boxes: the reference's non_max_suppression takes any numeric dtype (inference.py:161-217;
+ * its own inference() only passes integers) and numpy then computes areas, intersections, IoU and the comparison with the
+ * threshold in the array's dtype.  d_tlbr (n,4) float32 (box_dtype Y3_F32) or float64 (Y3_F64), d_prob (n) float64
+ * (exact for float32 / float64 scores), d_cls (n) int64 or NULL; outputs and order as y3_nms. */
+size_t y3_nms_float_workspace_bytes(int n);
+int y3_nms_float(const void *d_tlbr, int box_dtype, const double *d_prob, const int64_t *d_cls, int n, double iou_thresh,
+                 void *d_workspace, size_t workspace_bytes, int64_t *d_keep, int32_t *d_keep_count, void *stream);
+
 /* cxywh_to_tlbr (inference.py:269-283) on int64 rows of `cols` >= 4 columns ---------------- */
 int y3_cxywh_to_tlbr(const int64_t *d_xywh, int64_t *d_tlbr, int n, int cols, void *stream);
+/* ... and on float32 / float64 rows (dtype Y3_F32 / Y3_F64): tl = c - floor(wh / 2), br = c + floor(wh / 2), numpy's `//` */
+int y3_cxywh_to_tlbr_float(const void *d_xywh, void *d_tlbr, int n, int cols, int dtype, void *stream);
 
 /* frame resize on device (replaces the host cv2.resize of inference.py:320-326): uint8
  * (src_h,src_w,3) -> (dst_h,dst_w,3) with OpenCV's 8-bit INTER_LINEAR arithmetic: per channel

@@ -466,6 +466,114 @@ __global__ void cxywh_to_tlbr_kernel(const long long *in, long long *out, int n,
   for (int c = 4; c < cols; ++c) o[c] = r[c];
 }
 
+// ------------------------------------------------------------------------------------------------
+// non_max_suppression / cxywh_to_tlbr on FLOATING-POINT boxes (round 5): the reference's public functions take any numeric
+// dtype (/root/reference/yolov3/inference.py:161-217, :269-283); its own inference() only ever passes integers (:353-355),
+// which is what detect_kernel above is built for.  For float32 / float64 boxes numpy computes every step in the ARRAY's
+// dtype -- area = ((x2 - x1) + 1) * ((y2 - y1) + 1), w = maximum(0, (min(x2) - max(x1)) + 1), inter = w * h,
+// union = (area_i + area_j) - inter, iou = inter / union, removed iff iou > thr with the threshold taken to that dtype
+// (a weak Python scalar) -- and so does this kernel, operation by operation (-ffp-contract=off).  Not a hot path: one
+// workgroup, bitonic sort of (class, score desc, index desc) in global memory, then one wavefront per class walks its
+// segment greedily, 64 later boxes per pass.  Scores arrive as float64 (exact for float32 / float64 inputs).
+template <typename F>
+__device__ __forceinline__ F np_maximum0(F x) { return (x != x) ? x : (x > (F)0 ? x : (F)0); }   // numpy.maximum(0, x): NaN propagates
+
+__device__ __forceinline__ bool nmsf_before(int ca, double pa, int ia, int cb, double pb, int ib) {
+  if (ca != cb) return ca < cb;
+  if (pa != pb) return pa > pb;
+  return ia > ib;
+}
+
+template <typename F>
+__global__ __launch_bounds__(kThreads) void nms_float_kernel(const F *box, const double *prob, const long long *cls, int n, int np2,
+                                                             double thr_d, int *order, volatile unsigned char *alive, long long *keep,
+                                                             int *keep_count) {
+  // (`alive` is volatile: a lane clears flags that other lanes of the same wave read in the next pass -- the accesses must
+  // reach memory in program order and not be served from a stale L1 line)
+  __shared__ int s_wave_tot[kWaves];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const F thr = (F)thr_d;
+  for (int i = tid; i < np2; i += kThreads) order[i] = i < n ? i : -1;
+  for (int i = tid; i < n; i += kThreads) alive[i] = 1;
+  __syncthreads();
+  // bitonic sort of `order` (padding entries -1 sort last)
+  auto before = [&](int a, int b) {
+    if (a < 0 || b < 0) return b < 0 && a >= 0;
+    return nmsf_before(cls ? (int)cls[a] : 0, prob[a], a, cls ? (int)cls[b] : 0, prob[b], b);
+  };
+  for (int k = 2; k <= np2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < np2; i += kThreads) {
+        const int l = i ^ j;
+        if (l > i) {
+          const int a = order[i], b = order[l];
+          const bool up = (i & k) == 0;
+          if (up ? before(b, a) : before(a, b)) { order[i] = b; order[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  // class segments, found by every wave on its own while it walks (all lanes read the same address: one request per wave);
+  // wave w owns segments w, w + 16, ...
+  int seg_index = -1;
+  for (int s = 0; s < n;) {
+    // find the end of the segment that starts at s (uniform across the workgroup: all threads scan alike)
+    const int c0 = cls ? (int)cls[order[s]] : 0;
+    int e = s + 1;
+    while (e < n && (cls ? (int)cls[order[e]] : 0) == c0) ++e;
+    ++seg_index;
+    if ((seg_index & (kWaves - 1)) == wave) {
+      for (int i = s; i < e; ++i) {
+        const int bi = order[i];
+        if (!alive[bi]) continue;                       // (written by this wave only, earlier in program order)
+        const F x1 = box[4 * bi], y1 = box[4 * bi + 1], x2 = box[4 * bi + 2], y2 = box[4 * bi + 3];
+        const F area_i = ((x2 - x1) + (F)1) * ((y2 - y1) + (F)1);
+        for (int j0 = i + 1; j0 < e; j0 += 64) {
+          const int j = j0 + lane;
+          if (j < e) {
+            const int bj = order[j];
+            if (alive[bj]) {
+              const F u1 = box[4 * bj], v1 = box[4 * bj + 1], u2 = box[4 * bj + 2], v2 = box[4 * bj + 3];
+              const F area_j = ((u2 - u1) + (F)1) * ((v2 - v1) + (F)1);
+              const F tlx = x1 > u1 ? x1 : u1, tly = y1 > v1 ? y1 : v1;      // numpy.maximum / minimum of two finite values
+              const F brx = x2 < u2 ? x2 : u2, bry = y2 < v2 ? y2 : v2;
+              const F w = np_maximum0<F>((brx - tlx) + (F)1), h = np_maximum0<F>((bry - tly) + (F)1);
+              const F inter = w * h;
+              const F uni = (area_i + area_j) - inter;
+              const F iou = inter / uni;
+              if (iou > thr) alive[bj] = 0;
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    s = e;
+  }
+  __syncthreads();
+  // ordered gather of the survivors (canonical order: class asc, score desc, index desc)
+  int running = 0;
+  for (int base = 0; base < n; base += kThreads) {
+    const int i = base + tid;
+    const bool flag = i < n && alive[order[i]];
+    const int slot = ordered_slot(flag, running, s_wave_tot);
+    if (flag) keep[slot] = order[i];
+  }
+  if (tid == 0) *keep_count = running;
+}
+
+template <typename F>
+__global__ void cxywh_to_tlbr_float_kernel(const F *in, F *out, int n, int cols) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const F *r = in + (long long)i * cols;
+  F *o = out + (long long)i * cols;
+  // numpy: wh // 2 on floats = floor(wh / 2) (division by two is exact)
+  const F cx = r[0], cy = r[1], hw = floor(r[2] / (F)2), hh = floor(r[3] / (F)2);
+  o[0] = cx - hw; o[1] = cy - hh; o[2] = cx + hw; o[3] = cy + hh;
+  for (int c = 4; c < cols; ++c) o[c] = r[c];
+}
+
 // record = 8 x int32: x1 y1 x2 y2 | score bits | class | row | 1
 __global__ void pack_records_kernel(const int *cnt, const long long *tlbr, const float *prob,
                                     const long long *cls, const int *row, int rows, int kmax,
@@ -590,6 +698,52 @@ extern "C" int y3_nms(const int64_t *d_tlbr, const float *d_prob, const int64_t 
   a.det_count = d_keep_count;
   a.keep_idx = reinterpret_cast<long long *>(d_keep);
   hipLaunchKernelGGL(detect_kernel<true>, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+extern "C" size_t y3_nms_float_workspace_bytes(int n) {
+  if (n <= 0) return 256;
+  return align_up((size_t)next_pow2(n) * sizeof(int)) + align_up((size_t)n);
+}
+
+extern "C" int y3_nms_float(const void *d_tlbr, int box_dtype, const double *d_prob, const int64_t *d_cls, int n, double iou_thresh,
+                            void *d_workspace, size_t workspace_bytes, int64_t *d_keep, int32_t *d_keep_count, void *stream) {
+  Y3_REQUIRE(n >= 0, "y3_nms_float: negative n");
+  Y3_REQUIRE(d_keep_count, "y3_nms_float: null d_keep_count");
+  Y3_REQUIRE(box_dtype == Y3_F32 || box_dtype == Y3_F64, "y3_nms_float: boxes must be Y3_F32 or Y3_F64");
+  if (n == 0) {
+    Y3_HIP_CHECK(hipMemsetAsync(d_keep_count, 0, sizeof(int32_t), static_cast<hipStream_t>(stream)));
+    return Y3_OK;
+  }
+  Y3_REQUIRE(d_tlbr && d_prob && d_workspace && d_keep, "y3_nms_float: null pointer argument");
+  Y3_REQUIRE(workspace_bytes >= y3_nms_float_workspace_bytes(n), "y3_nms_float: workspace too small");
+  const int np2 = next_pow2(n);
+  int *order = static_cast<int *>(d_workspace);
+  unsigned char *alive = reinterpret_cast<unsigned char *>(static_cast<char *>(d_workspace) + align_up((size_t)np2 * sizeof(int)));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (box_dtype == Y3_F32)
+    hipLaunchKernelGGL(nms_float_kernel<float>, dim3(1), dim3(kThreads), 0, s, static_cast<const float *>(d_tlbr), d_prob,
+                       reinterpret_cast<const long long *>(d_cls), n, np2, iou_thresh, order, alive, reinterpret_cast<long long *>(d_keep), d_keep_count);
+  else
+    hipLaunchKernelGGL(nms_float_kernel<double>, dim3(1), dim3(kThreads), 0, s, static_cast<const double *>(d_tlbr), d_prob,
+                       reinterpret_cast<const long long *>(d_cls), n, np2, iou_thresh, order, alive, reinterpret_cast<long long *>(d_keep), d_keep_count);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+extern "C" int y3_cxywh_to_tlbr_float(const void *d_xywh, void *d_tlbr, int n, int cols, int dtype, void *stream) {
+  Y3_REQUIRE(n >= 0 && cols >= 4, "y3_cxywh_to_tlbr_float: need n >= 0 and at least 4 columns");
+  Y3_REQUIRE(dtype == Y3_F32 || dtype == Y3_F64, "y3_cxywh_to_tlbr_float: dtype must be Y3_F32 or Y3_F64");
+  if (n == 0) return Y3_OK;
+  Y3_REQUIRE(d_xywh && d_tlbr, "y3_cxywh_to_tlbr_float: null pointer argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == Y3_F32)
+    hipLaunchKernelGGL(cxywh_to_tlbr_float_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const float *>(d_xywh),
+                       static_cast<float *>(d_tlbr), n, cols);
+  else
+    hipLaunchKernelGGL(cxywh_to_tlbr_float_kernel<double>, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const double *>(d_xywh),
+                       static_cast<double *>(d_tlbr), n, cols);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }

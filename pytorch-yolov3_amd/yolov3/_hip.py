@@ -41,7 +41,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # Y3_HIP_LIB: developer override (e.g. the diagnostic build with in-kernel phase stamps)
 LIB_PATH = os.environ.get("Y3_HIP_LIB") or os.path.join(_HERE, "..", "lib", "libyolov3_hip.so")
 
-Y3_F32, Y3_BF16, Y3_F16 = 0, 1, 2
+Y3_F32, Y3_BF16, Y3_F16, Y3_F64 = 0, 1, 2, 3
 OP_CONV, OP_MAXPOOL, OP_UPSAMPLE, OP_ADD, OP_COPY, OP_YOLO = 1, 2, 3, 4, 5, 6
 F_LEAKY, F_RESIDUAL, F_OUT_F32, F_IN_NCHW_F32, F_IN_NHWC_U8BGR, F_PLAN_INPUT, F_FUSE_NEXT = 1, 2, 4, 8, 16, 32, 64
 PATH_IGEMM, PATH_STEM, PATH_DIRECT, PATH_STEM_MFMA = 0, 1, 2, 3
@@ -116,6 +116,11 @@ PROTOTYPES = {
                               ctypes.c_void_p]),
     "y3_cxywh_to_tlbr": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_void_p]),
+    "y3_nms_float_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "y3_nms_float": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
+                                    ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "y3_cxywh_to_tlbr_float": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_void_p]),
     "y3_resize_bilinear_u8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "y3_copy_bytes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),

@@ -30,14 +30,32 @@ def _device(device=None):
     return torch.device(device)
 
 
+def _float_kind(dtype):
+    """numpy float dtype -> (C ABI element type, numpy dtype the kernel computes in): float32 stays float32 (numpy computes
+    float32 arrays in float32), float64 and wider / narrower floats go through float64 resp. float32."""
+    if dtype == np.float64 or dtype.itemsize > 8:
+        return _hip.Y3_F64, np.float64
+    return _hip.Y3_F32, np.float32
+
+
 def cxywh_to_tlbr(bbox_xywh):
-    """(n, >=4) integer array [cx, cy, w, h, ...] -> [x1, y1, x2, y2, ...] with
-    ``x1 = cx - w//2`` etc. (floor division; extra columns pass through)."""
+    """(n, >=4) array [cx, cy, w, h, ...] -> [x1, y1, x2, y2, ...] with ``x1 = cx - w//2`` etc. (floor division; extra
+    columns pass through).  Integer pixel boxes (what ``inference()`` uses) and float32 / float64 boxes, like the reference
+    (inference.py:269-283: ``//`` is numpy's floor division in the array's dtype)."""
     arr = np.asarray(bbox_xywh)
     if arr.ndim != 2 or arr.shape[1] < 4:
         raise ValueError("expected an (n, >=4) array")
+    if np.issubdtype(arr.dtype, np.floating):
+        if arr.shape[0] == 0:
+            return arr.copy()
+        code, work = _float_kind(arr.dtype)
+        dev = _device()
+        src = torch.from_numpy(np.ascontiguousarray(arr, dtype=work)).to(dev)
+        dst = torch.empty_like(src)
+        _hip.check(_hip.lib().y3_cxywh_to_tlbr_float(src.data_ptr(), dst.data_ptr(), arr.shape[0], arr.shape[1], code, _hip.stream_ptr()))
+        return dst.cpu().numpy().astype(arr.dtype, copy=False)
     if not np.issubdtype(arr.dtype, np.integer):
-        raise TypeError("cxywh_to_tlbr works on integer pixel boxes (the reference floor-divides ints)")
+        raise TypeError("cxywh_to_tlbr works on integer or floating-point boxes, got dtype {}".format(arr.dtype))
     if arr.shape[0] == 0:
         return arr.copy()
     dev = _device()
@@ -51,14 +69,16 @@ def cxywh_to_tlbr(bbox_xywh):
 def non_max_suppression(bbox_tlbr, class_prob, class_idx=None, iou_thresh=0.3):
     """Greedy NMS; per class when ``class_idx`` is given.  Returns a list of kept indices.
 
-    Same decision rule as the reference (areas with +1, IoU in float64, suppress iff
-    IoU > iou_thresh, highest score first).  ``bbox_tlbr`` must hold INTEGER pixel corners, which is what
-    ``inference()`` feeds it (inference.py:353-355): the device kernel works on int64 boxes, and float or
-    normalised boxes would be truncated silently, so they are rejected (``cxywh_to_tlbr`` does the same).
+    Same decision rule as the reference (areas with +1, suppress iff IoU > iou_thresh, highest score first).  INTEGER pixel
+    corners -- what ``inference()`` feeds it (inference.py:353-355) -- take the int64 device kernel (IoU = int / int in
+    float64, like numpy); float32 / float64 boxes (normalised or sub-pixel coordinates: any caller of the public function)
+    take ``y3_nms_float``, which computes every step in the array's dtype as numpy does (round 5).
     """
-    if np.asarray(bbox_tlbr).size and not np.issubdtype(np.asarray(bbox_tlbr).dtype, np.integer):
-        raise TypeError("non_max_suppression works on integer pixel boxes (got dtype {}); convert with "
-                        ".astype(int) as the reference's inference() does".format(np.asarray(bbox_tlbr).dtype))
+    barr = np.asarray(bbox_tlbr)
+    if barr.size and np.issubdtype(barr.dtype, np.floating):
+        return _nms_float(barr, class_prob, class_idx, iou_thresh)
+    if barr.size and not np.issubdtype(barr.dtype, np.integer):
+        raise TypeError("non_max_suppression works on integer or floating-point boxes, got dtype {}".format(barr.dtype))
     boxes = np.ascontiguousarray(np.asarray(bbox_tlbr)[:, :4] if np.asarray(bbox_tlbr).size else
                                  np.zeros((0, 4)), dtype=np.int64)
     prob = np.ascontiguousarray(class_prob, dtype=np.float32)
@@ -86,6 +106,32 @@ def non_max_suppression(bbox_tlbr, class_prob, class_idx=None, iou_thresh=0.3):
                           _hip.stream_ptr()))
     k = int(count.cpu()[0])
     return keep[:k].cpu().numpy().tolist()
+
+
+def _nms_float(barr, class_prob, class_idx, iou_thresh):
+    code, work = _float_kind(barr.dtype)
+    boxes = np.ascontiguousarray(barr[:, :4], dtype=work)
+    prob = np.ascontiguousarray(class_prob, dtype=np.float64)
+    n = boxes.shape[0]
+    if prob.shape[0] != n:
+        raise ValueError("bbox_tlbr and class_prob disagree on the number of boxes")
+    dev = _device()
+    lib = _hip.lib()
+    d_box = torch.from_numpy(boxes).to(dev)
+    d_prob = torch.from_numpy(prob).to(dev)
+    d_cls = None
+    if class_idx is not None:
+        cls = np.ascontiguousarray(class_idx, dtype=np.int64)
+        if cls.shape[0] != n:
+            raise ValueError("class_idx has the wrong length")
+        d_cls = torch.from_numpy(cls).to(dev)
+    ws_bytes = lib.y3_nms_float_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    keep = torch.empty(n, dtype=torch.int64, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    _hip.check(lib.y3_nms_float(d_box.data_ptr(), code, d_prob.data_ptr(), d_cls.data_ptr() if d_cls is not None else None, n,
+                                float(iou_thresh), ws.data_ptr(), ws_bytes, keep.data_ptr(), count.data_ptr(), _hip.stream_ptr()))
+    return keep[:int(count.cpu()[0])].cpu().numpy().tolist()
 
 
 class Detector(object):

@@ -70,6 +70,36 @@ def test_nms_cases_match_reference():
             assert sorted(got) == sorted(c["per_class"]), c["name"]
 
 
+
+def _float_cases():
+    with open(os.path.join(GOLDEN, "nms_float_cases.json")) as fh:
+        table = json.load(fh)
+    for c in table["nms"]:
+        dt, pdt = np.dtype(c["dtype"]), np.dtype(c["prob_dtype"])
+        boxes = np.array(c["boxes_bits"], dtype=np.uint32 if dt == np.float32 else np.uint64).view(dt).reshape(-1, 4)
+        prob = np.array(c["prob_bits"], dtype=np.uint32 if pdt == np.float32 else np.uint64).view(pdt)
+        yield c, boxes, prob, np.array(c["cls"], dtype=np.int64)
+    for t in table["cxywh_to_tlbr"]:
+        dt = np.dtype(t["dtype"])
+        u = np.uint32 if dt == np.float32 else np.uint64
+        yield t, np.array(t["xywh_bits"], dtype=u).view(dt).reshape(-1, t["cols"]), np.array(t["tlbr_bits"], dtype=u).view(dt).reshape(-1, t["cols"]), None
+
+
+def test_float_box_nms_and_tlbr_match_reference():
+    """G6f: the reference's public post-processing functions on float32 / float64 boxes (inference.py:161-283 take any numeric
+    dtype; numpy computes in the array's dtype).  The oracle's numpy restatement returns the reference's keep sets and corners."""
+    n_nms = n_tl = 0
+    for c, a, b, cls in _float_cases():
+        if cls is None:
+            assert np.array_equal(orc.cxywh_to_tlbr(a), b), c["dtype"]
+            n_tl += 1
+            continue
+        assert [int(i) for i in orc.non_max_suppression(a, b, iou_thresh=c["thr"])] == c["agnostic"], c["name"]
+        assert sorted(int(i) for i in orc.non_max_suppression(a, b, class_idx=cls, iou_thresh=c["thr"])) == sorted(c["per_class"]), c["name"]
+        n_nms += 1
+    assert n_nms >= 13 and n_tl == 2
+
+
 def test_nms_empty_and_survey_example():
     assert orc.non_max_suppression(np.zeros((0, 4), dtype=np.int64), np.zeros(0, dtype=np.float32),
                                    class_idx=np.zeros(0, dtype=np.int64)) == []

@@ -21,6 +21,7 @@ Golden sets:
   G4 yolo_layer.npz           YOLOLayer.forward on a small tensor + 1-hot probe
   G5 forward_<model>.npz      full Darknet.forward outputs
   G6 nms_cases.json           non_max_suppression cases (per-class, agnostic, edge cases)
+  G6f nms_float_cases.json    the same public functions on float32 / float64 boxes (normalised, sub-pixel) + cxywh_to_tlbr on floats
   G7 inference_<model>.npz    inference() end-to-end lists + fragility audit
   G7' inference_bench_regime_<model>.npz  inference() at the benchmarked regime (obj_bias -8.5) on all nine sample images
                                + audited-clean procedural frames (exact identity, no exemption)
@@ -552,6 +553,45 @@ def g6_nms():
     print("G6 ok", [(c["name"], len(c["per_class"] or []), len(c["agnostic"])) for c in cases])
 
 
+# ---------------------------------------------------------------- G6f (float boxes through the public post-processing API)
+def g6f_nms_float():
+    """The reference's non_max_suppression / cxywh_to_tlbr on FLOAT boxes (inference.py:161-283 take any numeric dtype; numpy
+    then computes in the array's dtype): normalised boxes, sub-pixel boxes, float32 and float64, per class and class-agnostic.
+    Stored as exact bit patterns.  tests/golden/nms_float_cases.json."""
+    cases = []
+    rs = np.random.RandomState(11)
+
+    def bits(a):
+        a = np.ascontiguousarray(a)
+        return [int(v) for v in a.view(np.uint32 if a.dtype == np.float32 else np.uint64).ravel()]
+
+    def add(name, boxes, prob, cls, thr):
+        per_class = [int(i) for i in ref.non_max_suppression(boxes, prob, class_idx=cls, iou_thresh=thr)]
+        agnostic = [int(i) for i in ref.non_max_suppression(boxes, prob, iou_thresh=thr)]
+        cases.append(dict(name=name, dtype=str(boxes.dtype), prob_dtype=str(prob.dtype), n=int(boxes.shape[0]), boxes_bits=bits(boxes),
+                          prob_bits=bits(prob), cls=[int(c) for c in cls], thr=thr, per_class=per_class, agnostic=agnostic))
+
+    for dt in (np.float32, np.float64):
+        for n, ncls, thr, scale in ((6, 2, 0.3, 1.0), (60, 3, 0.3, 1.0), (400, 5, 0.45, 1.0), (900, 80, 0.3, 1.0),
+                                    (250, 4, 0.3, 416.0), (500, 1, 0.5, 608.0)):
+            c = rs.rand(n, 2) * 0.8 + 0.1
+            wh = rs.rand(n, 2) * 0.3 + 0.01
+            boxes = (np.concatenate([c - wh / 2, c + wh / 2], axis=1) * scale).astype(dt)      # normalised / sub-pixel corners
+            prob = (rs.permutation(n).astype(np.float64) / n * 0.9 + 0.05).astype(np.float32 if dt == np.float32 else np.float64)
+            cls = rs.randint(0, ncls, size=n).astype(np.int64)
+            add("%s_n%d_c%d_x%g" % (np.dtype(dt).name, n, ncls, scale), boxes, prob, cls, thr)
+    # exact duplicates, touching boxes and a degenerate (zero-size) box
+    b = np.array([[0.5, 0.5, 2.5, 2.5], [0.5, 0.5, 2.5, 2.5], [2.5, 0.5, 4.5, 2.5], [1.0, 1.0, 1.0, 1.0], [10.25, 10.5, 12.75, 13.0]], dtype=np.float32)
+    add("edge_cases_f32", b, np.array([.9, .8, .7, .6, .5], dtype=np.float32), np.array([0, 0, 0, 0, 1]), 0.3)
+    tl = []
+    for dt in (np.float32, np.float64):
+        x = np.concatenate([rs.rand(40, 4) * 50 - 5, rs.rand(40, 3)], axis=1).astype(dt)      # negative and fractional sizes, extra columns
+        tl.append(dict(dtype=np.dtype(dt).name, cols=7, xywh_bits=bits(x), tlbr_bits=bits(ref.cxywh_to_tlbr(x))))
+    with open(os.path.join(GOLD, "nms_float_cases.json"), "w") as fh:
+        json.dump(dict(nms=cases, cxywh_to_tlbr=tl), fh)
+    print("G6f ok", [(c["name"], len(c["per_class"]), len(c["agnostic"])) for c in cases])
+
+
 # ---------------------------------------------------------------- G9
 def g9_coco_export():
     """Reference to_coco (inference.py:371-432) and match_ids (devtools/coco_util.py:110-150)."""
@@ -594,6 +634,8 @@ if __name__ == "__main__":
         g4_yolo_layer()
     if "g6" in which:
         g6_nms()
+    if "g6f" in which:
+        g6f_nms_float()
     if "g9" in which:
         g9_coco_export()
     if "g7p" in which:

@@ -17,7 +17,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OU
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $ARGS > $OUT/pmc_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py $ARGS > $OUT/pmc_sq.log 2>&1
 # the other single-GPU workloads of BASELINE.json: traffic passes only (bench.py other_configs[*].roofline.traffic)
-for W in "yolov3-tiny 416 8 float32" "yolov3-spp 608 16 bf16" "yolov3 608 16 float32"; do
+for W in "yolov3-tiny 416 8 float32" "yolov3-spp 608 16 bf16" "yolov3 608 16 float32" "yolov3 608 16 fp16"; do
   set -- $W
   KEY=$1_$2_b$3_$4
   WARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extras $TUNE --model $1 --dim $2 --batch $3 --dtype $4"
