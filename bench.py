@@ -173,9 +173,11 @@ def _cpu_busy(interval=0.3):
 
 
 def pick_quiet_cpus(n):
-    """``n`` CPUs for the CPU baseline: distinct physical cores of ONE NUMA node, the ones that were least busy over the last
-    0.3 s (the pool's hosts are shared: 256 hardware threads, a 16-CPU quota per tenant -- which cores the threads land on, and
-    who else is on them, is most of the 5x run-to-run spread rounds 1-4 saw).  Falls back to the first ``n`` allowed CPUs."""
+    """``n`` CPUs for the CPU baseline: distinct physical cores of ONE NUMA node, dealt ROUND-ROBIN OVER THE NODE'S L3 DOMAINS
+    (an EPYC 9575F socket is eight CCDs of eight cores with 32 MB of L3 each; sixteen threads on two neighbouring CCDs ran
+    this workload at 10 frames/s, spread over all eight at 16: profiles/r05_cpu_baseline.txt -- which cores the threads land on
+    was most of the 5x run-to-run spread rounds 1-4 saw), inside a domain the cores that were least busy over the last 0.3 s
+    (the pool's hosts are shared: 256 hardware threads, a 16-CPU quota per tenant).  Falls back to the first ``n`` allowed CPUs."""
     topo = cpu_topology()
     busy = _cpu_busy()
     cores = {}
@@ -183,14 +185,22 @@ def pick_quiet_cpus(n):
         cores.setdefault((node, core), []).append(c)
     by_node = {}
     for (node, core), cpus in cores.items():
-        by_node.setdefault(node, []).append((max(busy.get(c, 0.0) for c in cpus), min(cpus)))
+        first = min(cpus)
+        l3 = _read("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % first, "all")
+        by_node.setdefault(node, {}).setdefault(l3, []).append((max(busy.get(c, 0.0) for c in cpus), first))
     best = None
-    for node, lst in by_node.items():
-        lst.sort()
-        if len(lst) >= n:
-            cost = sum(b for b, _ in lst[:n])
-            if best is None or cost < best[0]:
-                best = (cost, node, [c for _, c in lst[:n]])
+    for node, domains in by_node.items():
+        if sum(len(v) for v in domains.values()) < n:
+            continue
+        queues = [sorted(v) for _, v in sorted(domains.items(), key=lambda kv: min(c for _, c in kv[1]))]
+        picked = []
+        while len(picked) < n:
+            for q in queues:
+                if q and len(picked) < n:
+                    picked.append(q.pop(0))
+        cost = sum(b for b, _ in picked)
+        if best is None or cost < best[0]:
+            best = (cost, node, [c for _, c in picked])
     if best is None:
         return sorted(topo)[:n], -1
     return sorted(best[2]), best[1]

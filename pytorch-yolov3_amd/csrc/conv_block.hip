@@ -393,8 +393,11 @@ __global__ __launch_bounds__(kNT) void conv_block_fused_kernel(BlockArgs p) {
       };
       if (p.res) write_out(std::true_type{});
       else write_out(std::false_type{});
-      // weights(it + 2) went out before the write-out's loads and stores: only the twelve stores may still fly
-      wait_vm<12>();
+      // weights(it + 2) went out before the write-out's loads and stores.  A counted wait ("only the twelve stores may still
+      // fly") would rest on how many stores the wave really issued -- they are predicated per lane, a wave whose pixels are
+      // all outside the frame issues none -- and was right only because the compiler's waits on the scale / bias loads, which
+      // return in order behind the weight pieces, happened to cover them.  One full drain per 18 K-steps instead.
+      wait_vm<0>();
     } else {
       wait_vm<0>();                                   // weights(it + 2) (and everything older) landed: ready for B(it + 1)
     }

@@ -211,6 +211,7 @@ class Darknet(object):
     def _device_weights(self, slot, path, dtype, dev):
         """Device copies of one conv's parameters in the layout of kernel family ``path``, weights rounded to the
         storage type ``dtype`` ("float32" / "bf16" / "fp16")."""
+        dtype = DTYPE_ALIASES[{True: "bf16", False: "float32"}.get(dtype, dtype)]      # (round 1-4 callers passed a bool: bf16 or not)
         key = (slot, path, dtype, str(dev))
         es, to_bits = DTYPES[dtype][1], DTYPES[dtype][3]
         if key in self._dev_weights:

@@ -178,12 +178,22 @@ def test_bench_prints_one_contract_json_line():
     assert d["use_graph"] is False
     assert d["resident"]["value"] > 0
     assert {o["workload"] for o in d["other_configs"]} == {"yolov3-tiny 416x416 batch=8 float32", "yolov3-spp 608x608 batch=16 bf16",
+                                                           "yolov3 608x608 batch=16 fp16", "yolov3 608x608 batch=16 bf16",
                                                            "yolov3 608x608 batch=16 float32"}
     for o in d["other_configs"]:
         assert o["value"] > 0 and abs(o["roofline"]["frac"] - o["roofline"]["achieved"] / o["roofline"]["peak"]) < 1e-3
     agree = d["bf16_agreement"]["thr_0.05_iou_0.3"]
     assert len(agree["keep_set_jaccard"]) == 3 and min(agree["keep_set_jaccard"]) > 0.4
     assert agree["score_abs_diff"]["median"] < 0.01
+    # round 5: the fp16 storage mode beside it (same kernels on the f16 MFMA): far closer to the reference's float32 lists
+    f16 = d["f16_agreement"]
+    assert min(f16["thr_0.05_iou_0.3"]["keep_set_jaccard"]) > 0.85 and f16["thr_0.05_iou_0.3"]["score_abs_diff"]["median"] < 1e-3
+    assert f16["bench_regime"]["thr_0.05_iou_0.3"]["keep_set_jaccard"] > 0.9
+    # R timed windows, the median is the value; the CPU baseline ran in a pinned child before any GPU call; phases
+    assert d["repeats"]["windows"] == 5 and d["repeats"]["ms_per_step_min"] <= d["ms_per_step"] <= d["repeats"]["ms_per_step_max"]
+    assert "child process" in c["process"] and len(c["pinned_cpus"]) == c["cores"] and len(c["loadavg_before"]) == 3
+    assert d["phases_s"]["total_s"] > 0 and "cpu_baseline_s" in d["phases_s"]
+    assert d["per_rank"]["placement"][0]["cpus"] >= 1
 
 
 @pytest.mark.gpu

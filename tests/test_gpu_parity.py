@@ -241,7 +241,8 @@ def test_inference_exact_identity_set_fp32(model):
     for dtype in ("float32", "fp16", "bf16"):
         net = yolov3.Darknet(MODELS[model], device="cuda", dtype=dtype)
         net.load_weights(golden_weights_path(model, obj_bias=float(g["obj_bias"]))).eval()
-        n_same = boxes = 0
+        n_same = boxes = n_rows_same = box_px = 0
+        score_d = 0.0
         for p in pairs:
             name, tag = p.rsplit("_", 1)
             pth, ith = g[tag + "_thresholds"]
@@ -255,10 +256,18 @@ def test_inference_exact_identity_set_fp32(model):
                 np.testing.assert_allclose(res[1][order], g[p + "_prob"][gorder], atol=SCORE_ATOL)
             n_same += int(same)
             boxes += len(g[p + "_rows"])
-        exact[dtype] = n_same
-        print("%s %s: %d of %d audited-clean pairs (%d kept boxes) reproduced EXACTLY" % (model, dtype, n_same, len(pairs), boxes))
-    assert exact["float32"] == len(pairs) >= 20 and boxes >= 200
-    assert exact["fp16"] >= exact["bf16"]
+            if len(order) == len(gorder) and np.array_equal(res[3][order], g[p + "_rows"][gorder]) and np.array_equal(res[2][order], g[p + "_cls"][gorder]):
+                n_rows_same += 1                          # identical box INDICES and CLASSES after NMS; how far are the boxes / scores?
+                if len(order):
+                    box_px = max(box_px, int(np.abs(res[0][order] - g[p + "_tlbr"][gorder]).max()))
+                    score_d = max(score_d, float(np.abs(res[1][order] - g[p + "_prob"][gorder]).max()))
+        exact[dtype] = (n_same, n_rows_same)
+        print("%s %s: of %d audited-clean pairs (%d kept boxes) %d reproduced EXACTLY; %d with identical kept indices and classes "
+              "(on those: boxes within %d px, scores within %.1e)" % (model, dtype, len(pairs), boxes, n_same, n_rows_same, box_px, score_d))
+    assert exact["float32"] == (len(pairs), len(pairs)) and len(pairs) >= 20 and boxes >= 200
+    # 16-bit storage cannot keep every truncated pixel (a deviation of 1e-4 of a 608-px frame is 0.06 px: one coordinate in
+    # ten crosses an integer), but fp16 keeps the reference's kept INDICES and CLASSES on most clean pairs, bf16 on few
+    assert exact["fp16"][1] >= exact["bf16"][1] and exact["fp16"][1] >= len(pairs) // 2
 
 
 @pytest.mark.parametrize("model", ["yolov3-tiny", "yolov3"])
@@ -604,8 +613,8 @@ def _resblock_plan(net, x, fuse, dev):
     from yolov3 import _hip
     lib = _hip.lib()
     b, h, w, _ = x.shape
-    w2 = net._device_weights(2, _hip.PATH_IGEMM, True, dev)
-    w3 = net._device_weights(3, _hip.PATH_IGEMM, True, dev)
+    w2 = net._device_weights(2, _hip.PATH_IGEMM, "bf16", dev)
+    w3 = net._device_weights(3, _hip.PATH_IGEMM, "bf16", dev)
     mid = torch.zeros((b, h, w, 32), dtype=torch.bfloat16, device=dev)
     out = torch.zeros((b, h, w, 64), dtype=torch.bfloat16, device=dev)
     zero = torch.zeros(4096, dtype=torch.uint8, device=dev)
@@ -653,8 +662,8 @@ def _first_two_convs_plan(net, frames, fuse, dev):
     from yolov3 import _hip
     lib = _hip.lib()
     b, h, w, _ = frames.shape
-    w0 = net._device_weights(0, _hip.PATH_STEM_MFMA, True, dev)
-    w1 = net._device_weights(1, _hip.PATH_IGEMM, True, dev)
+    w0 = net._device_weights(0, _hip.PATH_STEM_MFMA, "bf16", dev)
+    w1 = net._device_weights(1, _hip.PATH_IGEMM, "bf16", dev)
     mid = torch.zeros((b, h, w, 32), dtype=torch.bfloat16, device=dev)
     out = torch.zeros((b, h // 2, w // 2, 64), dtype=torch.bfloat16, device=dev)
     zero = torch.zeros(4096, dtype=torch.uint8, device=dev)
