@@ -504,10 +504,14 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     }
 #endif
   }
-  // ---- epilogue (the 512 consumer threads write out; the loaders only keep the barrier count) ----
+  // ---- epilogue: ALL twelve waves write out (round 5).  Until round 4 the four loader waves only kept the barrier count
+  // and the eight MFMA waves wrote the tile, eight (six) 8-channel items per lane; now a lane of any wave takes the items
+  // pl = (tid >> 4) + 48 j: 5.33 (4) per lane, and the loaders issue the scale / bias / shortcut loads of THEIR items while the
+  // MFMA waves are still parking their accumulators.  Same arithmetic per item, same bits.
   constexpr int SWZ = 15;
-  constexpr int OCT_PER_ROW = BN / 8;
-  constexpr int WR = BM * OCT_PER_ROW / NC;
+  constexpr int NT = NC + NL;                        // 768
+  constexpr int RPP = NT / 16;                       // pixel rows written per pass of the workgroup (48)
+  constexpr int WR = (BM + RPP - 1) / RPP;           // 6 passes at 256 pixels (the last one: rows 240 .. 255, the first 256 lanes), 4 at 192
   float *sC = reinterpret_cast<float *>(smem);
   const bool leaky = p.flags & Y3_F_LEAKY;
   const bool has_res = p.flags & Y3_F_RESIDUAL;
@@ -528,33 +532,32 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
         *reinterpret_cast<f32x4 *>(sC + pl * BN + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
       }
     }
-    // the epilogue's global reads go out AFTER the accumulators are on their way to LDS: eight waves x (4 + 8) 1-KiB loads
-    // keep the CU's address unit busy for ~1.5 k cycles, and issued before the barrier above (rounds 1-3: "so that they fly
-    // while the tile is parked") they held every wave back from it for that long (stamps: 1740 cycles from the end of the K
-    // loop to the barrier with a shortcut, 590 without); here the address unit and the LDS writes drain side by side
-    sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
-    sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
-    bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
-    bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
-    if (has_res) {
+  }
+  // the epilogue's global reads go out AFTER the accumulators are on their way to LDS (MFMA waves; the loaders start at once):
+  // issued before the barrier above (rounds 1-3) they held every wave back from it (stamps: 1740 cycles from the end of the K
+  // loop to the barrier with a shortcut, 590 without)
+  sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
+  sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+  bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
+  bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+  if (has_res) {
 #pragma unroll
-      for (int j = 0; j < WR; ++j) {
-        const int m = m0 + (tid >> 4) + j * (NC / 16);
-        const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
-        if constexpr (sizeof(T) == 2) {
-          resv[j] = m < p.M ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
-        }
+    for (int j = 0; j < WR; ++j) {
+      const int pl = (tid >> 4) + j * RPP;
+      const int m = m0 + pl;
+      const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
+      if constexpr (sizeof(T) == 2) {
+        resv[j] = (pl < BM && m < p.M) ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
       }
     }
   }
   __syncthreads();
   Y3_EPI(5);
-  if (loader) return;
 #pragma unroll
   for (int j = 0; j < WR; ++j) {
-    const int pl = (tid >> 4) + j * (NC / 16);
+    const int pl = (tid >> 4) + j * RPP;
     const int m = m0 + pl;
-    if (m >= p.M) continue;
+    if (pl >= BM || m >= p.M) continue;
     const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
     const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * BN + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
     float v[8];
