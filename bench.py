@@ -174,10 +174,11 @@ def _cpu_busy(interval=0.3):
 
 def pick_quiet_cpus(n):
     """``n`` CPUs for the CPU baseline: distinct physical cores of ONE NUMA node, dealt ROUND-ROBIN OVER THE NODE'S L3 DOMAINS
-    (an EPYC 9575F socket is eight CCDs of eight cores with 32 MB of L3 each; sixteen threads on two neighbouring CCDs ran
-    this workload at 10 frames/s, spread over all eight at 16: profiles/r05_cpu_baseline.txt -- which cores the threads land on
-    was most of the 5x run-to-run spread rounds 1-4 saw), inside a domain the cores that were least busy over the last 0.3 s
-    (the pool's hosts are shared: 256 hardware threads, a 16-CPU quota per tenant).  Falls back to the first ``n`` allowed CPUs."""
+    (an EPYC 9575F socket is eight CCDs of eight cores with 32 MB of L3 each: sixteen threads then always get two cores of
+    every CCD -- the SAME share of cache and memory links in every run, whichever cores happen to be idle; three consecutive
+    runs: 10.3 / 11.2 / 9.5 frames/s, profiles/r05_cpu_baseline.txt), inside a domain the cores that were least busy over the
+    last 0.3 s (the pool's hosts are shared: 256 hardware threads, a 16-CPU quota per tenant; rounds 1-4 ran unpinned and read
+    2.9 .. 14.9).  Falls back to the first ``n`` allowed CPUs."""
     topo = cpu_topology()
     busy = _cpu_busy()
     cores = {}

@@ -7,7 +7,7 @@
 // STATUS (round 4): correct and bit-identical to the two separate launches, but only LEVEL with them --
 // 0.067-0.075 ms against 0.069-0.072 ms per pair at batch 16, 6194-6229 against 6202-6216 frames/s end to end
 // (profiles/r04_block_fused_AB.txt) -- so it is OFF by default (y3_options.fuse_block = 0; 1 = where it fills the chip,
-// 2 = wherever supported: tests).  Why it does not win is recorded there and in DESIGN.md 3.1d: one workgroup per CU with
+// 2 = wherever supported: tests).  Why it does not win is recorded there and in profiles/HISTORY.md 3.1d: one workgroup per CU with
 // all 160 KiB of LDS means (a) the chip reads x, computes, and writes z in lock step, so the 16 us of HBM time of a pair
 // overlap with nothing, and (b) the weight ring has three slots, i.e. one K-step of lead, for tiles that all 256
 // workgroups want in the same K-step.

@@ -21,7 +21,7 @@
 // conv_patch_wsp_kernel (persistent, 8 x 32 output tiles with a 2-D input patch and no fragment masking; default for
 // wider rows, where the strip's halo outgrows LDS).  Measured slower and removed (history keeps them): schedules where
 // every wave loads and computes in lock step, ping-pong wave groups, 32-channel chunks with a deeper ring
-// (profiles/r01_convbench_*.txt); two workgroups per CU with 128 x 128 tiles; two persistent forms of
+// (profiles/r01_convbench_*.txt); two workgroups per CU with 128 x 128 tiles (profiles/HISTORY.md 3.1c); two persistent forms of
 // the strip kernel, the second with the epilogue in registers and the finished tile drained by the loader waves
 // (profiles/r03b_persistent_halo_wsq_investigation.txt).
 #include "common.h"
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
     // Border taps (zero padding, row wrap of the raster strip) are not cleared in registers: the fragment's LDS address
     // is redirected to the all-zero row `hr` of halo buffer 0 instead -- one select per fragment of K-half 0; K-half 1
     // of the same tap is the same address with bit 6 flipped (the XOR swizzle), for the zero row as well.  (The K loop
-    // is VALU-issue bound: PMC)
+    // is VALU-issue bound: PMC, profiles/HISTORY.md section 6.)
     // (absolute LDS byte addresses, so that nothing but the immediate is added per read; the workgroup's LDS block and
     // the halo buffers are 128-byte aligned, which the bit-6 flip relies on)
     typedef const __attribute__((address_space(3))) u32x4 lds_u32x4;

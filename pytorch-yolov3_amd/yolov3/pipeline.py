@@ -80,7 +80,7 @@ class Pipeline(object):
                               in_flight, in_flight + 2, "has" if sure else "was probably initialised with", nq), RuntimeWarning)
         self.copy_blocks = int(copy_blocks)
         # several batches in flight: CU time counts, not one launch's tail -> the strip kernel's 256-pixel tiles
-        # (include/yolov3_hip.h: Y3_AM_HALO_TILE256).  Explicit ``options`` win.
+        # (include/yolov3_hip.h: Y3_AM_HALO_TILE256; profiles/HISTORY.md 3.1c).  Explicit ``options`` win.
         if options is None and self.in_flight > 1:
             base = dict(net.options or {})
             base["auto_mask"] = int(base.get("auto_mask", _hip.options().auto_mask)) | _hip.AM_HALO_TILE256

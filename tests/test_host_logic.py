@@ -182,7 +182,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     with pytest.raises(KeyError):
         _hip.options(no_such_option=1)
     assert lib.y3_detect_workspace_bytes(2, 1000) > 0 and lib.y3_nms_workspace_bytes(10) > 0
-    assert opt.fuse_block == 0               # the fused bottleneck block is opt-in (level with the two launches: DESIGN.md 3.1d)
+    assert opt.fuse_block == 0               # the fused bottleneck block is opt-in (level with the two launches: profiles/HISTORY.md 3.1d)
     # the product library has no "debug" tuning key: a benchmark line cannot come from kernels that skip work
     assert lib.y3_set_tuning(b"debug", 1) != 0 and b"unknown key" in lib.y3_last_error()
     assert lib.y3_set_tuning(b"fuse_block", 0) == 0

@@ -3,7 +3,7 @@
 
 cycles(instr, addr[64]) -> (LDS-array cycles, conflict-free cycles).  A group of lanes is serviced in one cycle when no
 bank sees two DIFFERENT dword addresses; every extra distinct address on a bank adds a cycle.  Used to design the LDS
-layouts of the kernels; `python tools/lds_conflicts.py` prints the table for the layouts in use.
+layouts of the kernels (profiles/HISTORY.md section 6); `python tools/lds_conflicts.py` prints the table for the layouts in use.
 """
 
 def _groups(instr):

@@ -21,39 +21,48 @@ from collections import defaultdict
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
+DT = {"DF16b": "bf16", "__bf16": "bf16", "DF16_": "f16", "_Float16": "f16", "f": "f32", "float": "f32"}
+_T = r"(DF16b|DF16_|f)"                      # Itanium-mangled element type: __bf16, _Float16, float
+
+
 def plan_name(kernel):
-    """rocprofv3's demangled kernel name -> the name the plan executor reports (y3_plan_op_kernel)."""
+    """rocprofv3's kernel name -> the name the plan executor reports (y3_plan_op_kernel).  rocprofv3 leaves the template
+    kernels of anonymous namespaces mangled (...conv_halo_ws_kernelIDF16bLi4ELi4EEEv...); since round 5 every 16-bit kernel
+    is a template on its element type (DF16b = bf16, DF16_ = fp16)."""
     k = kernel.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"conv_halo_ws_kernel<(__bf16|float), \d+, (\d+)>", k)
+    m = re.match(r"conv_halo_ws_kernel<(__bf16|_Float16|float), \d+, (\d+)>", k)
     if m:
-        return "conv_halo_ws_%s_%dx128" % ("bf16" if m.group(1) == "__bf16" else "f32", 64 * int(m.group(2)))
-    # rocprofv3 leaves the template kernels of anonymous namespaces mangled: ...conv_halo_ws_kernelIDF16bLi4ELi4EEEv...
-    m = re.search(r"conv_halo_ws_kernelI(DF16b|f)Li\d+ELi(\d+)E", k)
+        return "conv_halo_ws_%s_%dx128" % (DT[m.group(1)], 64 * int(m.group(2)))
+    m = re.search(r"conv_halo_ws_kernelI" + _T + r"Li\d+ELi(\d+)E", k)
     if m:
-        return "conv_halo_ws_%s_%dx128" % ("bf16" if m.group(1) == "DF16b" else "f32", 64 * int(m.group(2)))
-    dt = lambda t: "bf16" if t in ("DF16b", "__bf16") else "f32"
-    m = re.search(r"conv_igemm2_kernelI(DF16b|f)Li64ELi256ELi1ELi4ELi0ELb1E", k)
+        return "conv_halo_ws_%s_%dx128" % (DT[m.group(1)], 64 * int(m.group(2)))
+    m = re.search(r"conv_igemm2_kernelI" + _T + r"Li64ELi256ELi1ELi4ELi0ELb1E", k)
     if m:
-        return "conv_head_decode_bf16_64x256"
-    m = re.search(r"conv_igemm(2|3|)_kernelI(DF16b|f)Li(\d+)ELi(\d+)E", k)
+        return "conv_head_decode_%s_64x256" % DT[m.group(1)]
+    m = re.search(r"conv_igemm(2|3|)_kernelI" + _T + r"Li(\d+)ELi(\d+)E", k)
     if m:
-        return "conv_igemm%s_%s_%sx%s" % (m.group(1), dt(m.group(2)), m.group(3), m.group(4))
-    m = re.match(r"conv_igemm(2|3|)_kernel<(float|__bf16), (\d+), (\d+)", k)     # demangled form
+        return "conv_igemm%s_%s_%sx%s" % (m.group(1), DT[m.group(2)], m.group(3), m.group(4))
+    m = re.match(r"conv_igemm(2|3|)_kernel<(float|__bf16|_Float16), (\d+), (\d+)", k)     # demangled form
     if m:
-        return "conv_igemm%s_%s_%sx%s" % (m.group(1), dt(m.group(2)), m.group(3), m.group(4))
-    m = re.match(r"conv_patch_wsp_kernel<(float|__bf16)", k)
+        return "conv_igemm%s_%s_%sx%s" % (m.group(1), DT[m.group(2)], m.group(3), m.group(4))
+    m = re.match(r"conv_patch_wsp_kernel<(float|__bf16|_Float16)", k)
     if m:
-        return "conv_patch_wsp_%s_8x32x128" % dt(m.group(1))
-    m = re.search(r"conv_patch_wsp_kernelI(DF16b|f)", k)
+        return "conv_patch_wsp_%s_8x32x128" % DT[m.group(1)]
+    m = re.search(r"conv_patch_wsp_kernelI" + _T, k)
     if m:
-        return "conv_patch_wsp_%s_8x32x128" % dt(m.group(1))
-    m = re.match(r"conv1x1_wres_kernel<(\d+)>", k)
+        return "conv_patch_wsp_%s_8x32x128" % DT[m.group(1)]
+    m = re.search(r"conv1x1_wres_kernelI" + _T + r"Li(\d+)E", k)
     if m:
-        return "conv1x1_wres_bf16_128x%s" % m.group(1)
-    if k.startswith("conv_stem_s2_ws_kernel") or k.startswith("conv_stem_s2_fused_kernel"):
-        return "conv_stem_s2_fused_u8_bf16"
-    if k.startswith("conv_resblock_fused_kernel"):
-        return "conv_resblock_fused_bf16_64_32_64"
+        return "conv1x1_wres_%s_128x%s" % (DT[m.group(1)], m.group(2))
+    m = re.search(r"conv_stem_s2_(ws|fused)_kernelI" + _T, k)
+    if m:
+        return "conv_stem_s2_fused_u8_%s" % DT[m.group(2)]
+    m = re.search(r"conv_resblock_fused_kernelI" + _T, k)
+    if m:
+        return "conv_resblock_fused_%s_64_32_64" % DT[m.group(1)]
+    m = re.search(r"conv_block_fused_kernelI" + _T, k)
+    if m:
+        return "conv_block_fused_%s_x128" % DT[m.group(1)]
     m = re.search(r"\d+(conv_[a-z0-9_]+_kernel|[a-z_]+_kernel)I", k)
     if m:
         return m.group(1) + k[k.index(m.group(1)) + len(m.group(1)):].split("EvN")[0]
@@ -72,7 +81,8 @@ def per_launch(path, counter):
     return {k: (acc[k] / n[k], n[k]) for k in acc}
 
 
-WORKLOADS = ["yolov3_608_b16_bf16", "yolov3-tiny_416_b8_float32", "yolov3-spp_608_b16_bf16", "yolov3_608_b16_float32"]
+WORKLOADS = ["yolov3_608_b16_bf16", "yolov3-tiny_416_b8_float32", "yolov3-spp_608_b16_bf16", "yolov3_608_b16_float32",
+             "yolov3_608_b16_fp16"]
 
 
 def kernels_of(prof, suffix):
