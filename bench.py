@@ -925,6 +925,23 @@ def main(argv=None):
     t_gpu0 = time.perf_counter()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # was the sysfs guess the GPU this rank really runs on?  (torch exposes the PCI address once the device is initialised.)  If
+    # not -- an enumeration order this code does not know -- bind again, to the node of the GPU the runtime reports, before any
+    # pinned buffer is allocated
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        real = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        placement["gpu_bdf_runtime"] = real
+        placement["gpu_bdf_verified"] = (placement.get("gpu_bdf") == real) if placement.get("gpu_bdf") else None
+        if placement["gpu_bdf_verified"] is False and os.environ.get("Y3_BENCH_NO_BIND") != "1":
+            cpus = _parse_cpulist(_read("/sys/bus/pci/devices/%s/local_cpulist" % real))
+            node = _read("/sys/bus/pci/devices/%s/numa_node" % real)
+            if cpus:
+                os.sched_setaffinity(0, cpus)
+                placement.update(numa_node=int(node) if node not in (None, "") else -1, cpus=len(os.sched_getaffinity(0)), bound=True,
+                                 rebound_after_init=True)
+    except Exception:
+        placement.setdefault("gpu_bdf_verified", None)
     ranks_seen = 1
     if distributed:
         ranks_seen = init_group("nccl", dev)
@@ -960,13 +977,6 @@ def main(argv=None):
     phases["warmup_and_timed_s"] = round(time.perf_counter() - t_timed0, 1)
     windows_ms = sorted(w / args.steps * 1e3 for w in wl.windows_s)
     kept = wl.kept_per_frame()
-    # was the sysfs guess the GPU this rank really runs on?  (torch exposes the PCI address once the device is initialised)
-    try:
-        pr = torch.cuda.get_device_properties(local_rank)
-        real = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
-        placement["gpu_bdf_verified"] = (placement.get("gpu_bdf") == real) if placement.get("gpu_bdf") else None
-    except Exception:
-        placement["gpu_bdf_verified"] = None
     if distributed:      # every rank's placement in rank 0's line
         gathered = [None] * dist.get_world_size()
         dist.all_gather_object(gathered, placement)
@@ -1011,6 +1021,9 @@ def main(argv=None):
                        "collective": ("1 x all_gather_into_tensor(%d x %d x 8 int32 records) per step, side stream" % (
                            b, args.kmax)) if distributed else "none"},
             "use_graph": bool(use_graph),
+            # hardware queues the HIP runtime maps this rank's five streams onto (yolov3/_hip.py sets 8 before HIP initialises;
+            # `certain` is False when the runtime was up before the package was imported: then probably its default of 4)
+            "gpu_max_hw_queues": {"value": _hip.hw_queues()[0], "certain": _hip.hw_queues()[1]},
             # a library other than the in-tree product build (Y3_HIP_LIB: stamps / experiment variants) or a debug knob:
             # the line then is a diagnostic, not a result
             "diagnostic_build": bool(os.environ.get("Y3_HIP_LIB") or os.environ.get("Y3_BENCH_DEBUG_AFTER_WARMUP")),
