@@ -412,6 +412,8 @@ def plumbing_main(args, backend):
         raise SystemExit(3)
     if os.environ.get("Y3_BENCH_HANG_RANK") == str(rank):      # tests: a rank that never reaches the rendezvous
         time.sleep(1e6)
+    # (the same pre-GPU placement step as the real run: on a box without a KFD topology it reports "not bound")
+    placement = bind_rank_to_gpu_node(int(os.environ.get("LOCAL_RANK", "0")))
     ranks_seen = init_group(backend)
     if os.environ.get("Y3_BENCH_DIE_AFTER_INIT") == str(rank):  # tests: a rank that dies once the group exists
         sys.stderr.write("rank %d: dying after init (test hook)\n" % rank)
@@ -427,18 +429,30 @@ def plumbing_main(args, backend):
     rec = torch.from_numpy(pack_records_host(dets, args.kmax))
     for _ in range(args.warmup):
         all_gather_records(rec, world)
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = all_gather_records(rec, world)
-    host_enqueue = time.perf_counter() - t0
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
+    windows = []                              # R windows of exactly K steps, each between barriers; max over ranks; the median counts
+    for _ in range(max(1, args.repeats)):
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = all_gather_records(rec, world)
+        host_enqueue = time.perf_counter() - t0
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        windows.append((float(t.item()), host_enqueue))
+    order = sorted(range(len(windows)), key=lambda k: windows[k][0])
+    elapsed, host_enqueue = windows[order[(len(order) - 1) // 2]]
     stats = rank_stats(elapsed, host_enqueue, args.steps, world, None)
+    allp = [None] * world
+    dist.all_gather_object(allp, placement)
+    stats["placement"] = allp
     if rank == 0:
         total = sum(frames_per_rank(args, r, world) for r in range(world))
         print(json.dumps({"metric": "frames/sec (608x608)", "value": None, "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "plumbing_only": True, "scaling": args.scaling,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                          "repeats": {"windows": len(windows), "ms_per_step_min": round(min(w[0] for w in windows) / args.steps * 1e3, 4),
+                                      "ms_per_step_max": round(max(w[0] for w in windows) / args.steps * 1e3, 4)},
                           "ranks_seen_by_collective": ranks_seen,
                           "frames_gathered_per_step": int(counts_of(out).shape[0]), "per_rank": stats,
                           "config": {"global_batch": total, "frames_per_gpu": [frames_per_rank(args, r, world) for r in range(world)],
@@ -977,11 +991,14 @@ def main(argv=None):
     phases["warmup_and_timed_s"] = round(time.perf_counter() - t_timed0, 1)
     windows_ms = sorted(w / args.steps * 1e3 for w in wl.windows_s)
     kept = wl.kept_per_frame()
-    if distributed:      # every rank's placement in rank 0's line
-        gathered = [None] * dist.get_world_size()
-        dist.all_gather_object(gathered, placement)
-    else:
-        gathered = [placement]
+    gathered = [placement]
+    if distributed:      # every rank's placement in rank 0's line (best effort: a diagnostic must not cost the run)
+        try:
+            allp = [None] * dist.get_world_size()
+            dist.all_gather_object(allp, placement)
+            gathered = allp
+        except Exception as exc:
+            gathered = [dict(placement, gather_error=repr(exc))]
 
     per_rank = rank_stats(wl.rank_elapsed_s, wl.host_enqueue_s, args.steps, world, dev) if distributed else \
         rank_stats(wl.rank_elapsed_s, wl.host_enqueue_s, args.steps, 1, None)

@@ -192,6 +192,10 @@ def test_bench_self_launch_starts_n_ranks(world):
     pr = line["per_rank"]      # a slow or starved rank must be visible in the line, not only in the maximum
     assert len(pr["ms_per_step_by_rank"]) == world == len(pr["host_enqueue_ms_per_step_by_rank"])
     assert pr["ms_per_step_min"] <= pr["ms_per_step_max"] and pr["usable_cpus_per_rank"] >= 0
+    # round 5: R timed windows (the median is reported, min / max alongside) and every rank's CPU placement in the line
+    assert line["repeats"]["windows"] == 5
+    assert line["repeats"]["ms_per_step_min"] <= line["ms_per_step"] <= line["repeats"]["ms_per_step_max"]
+    assert len(pr["placement"]) == world and all("bound" in p and p["cpus"] >= 1 for p in pr["placement"])
 
 
 def test_bench_strong_scaling_splits_128_frames_over_8_ranks():
