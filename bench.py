@@ -1103,6 +1103,12 @@ def main(argv=None):
     # ---- CPU baseline: the oracle (reference "-d cpu" op sequence) timed on the host cores, measured in a child process
     # BEFORE this process touched the GPU (top of main)
     if rank == 0 and cpu_base is not None:
+        if "error" in cpu_base:
+            # the child could not run (no fork, a sandbox without sched_setaffinity ...): measure in this process, after the GPU
+            # work, as rounds 1-4 did -- a noisier number is better than none -- and say so
+            why = cpu_base["error"]
+            cpu_base = cpu_baseline(wl.cfg, params, args.model, args.dim, args.cpu_budget)
+            cpu_base["process"] = "in-process fallback AFTER the GPU work (the pinned child process failed: %s)" % why
         line["cpu_baseline"] = cpu_base
 
     if rank == 0:
