@@ -98,6 +98,21 @@ def test_mini_bf16_uint8_stem_matches_bf16_float_stem():
     assert (a["class_idx"] == b["class_idx"]).float().mean() > 0.97
 
 
+def test_mini_fp16_close_to_fp32_and_its_two_stems_agree():
+    """fp16 mode (round 5): the float-input first layer (VALU stem, what ``forward(x)`` runs) and the uint8 MFMA stem
+    (``forward_frames``) on the same network: both within the fp16 storage error of the float32 golden, and of each other."""
+    g = np.load(os.path.join(GOLDEN, "mini_blocks.npz"))
+    net = _net("mini", dtype="fp16")
+    a = net.forward(torch.from_numpy(g["input"]))
+    b = net.forward_frames(g["frames"])
+    assert np.isfinite(a["bbox_xywh"].cpu().numpy()).all()
+    dp = np.abs(a["class_prob"].cpu().numpy() - g["class_prob"])
+    assert np.median(dp) < 6e-4 and dp.max() < 0.04                       # (bf16: 5e-3 / 0.3)
+    d = (a["class_prob"] - b["class_prob"]).abs().cpu().numpy()
+    assert np.median(d) < 3e-4 and d.max() < 0.02
+    assert (a["class_idx"] == b["class_idx"]).float().mean() > 0.99
+
+
 DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 157, "fuse_stem": 1, "decode_lanes": 4, "use_graph": 0, "fuse_head": 1, "fuse_spp": 1}
 
 
@@ -485,8 +500,9 @@ def test_nms_large_matches_oracle(n, ncls):
 @pytest.mark.parametrize("model,dim,batch", [(m, d, b) for m in ("yolov3", "yolov3-tiny", "yolov3-spp")
                                              for d in (320, 416, 608) for b in (1, 2)])
 def test_shape_sweep_bf16(model, dim, batch):
-    """The reference's own 18-case smoke sweep (tests/test_darknet.py:10-27), plus shape asserts."""
-    net = _net(model, dtype="bf16")
+    """The reference's own 18-case smoke sweep (tests/test_darknet.py:10-27), plus shape asserts; bf16 at batch 1, fp16 at
+    batch 2 (the two 16-bit modes share every kernel template)."""
+    net = _net(model, dtype="bf16" if batch == 1 else "fp16")
     x = torch.rand(batch, 3, dim, dim, generator=torch.Generator().manual_seed(dim + batch))
     out = net.forward(x)
     cells = sum((dim // s) ** 2 for s in ((32, 16) if model == "yolov3-tiny" else (32, 16, 8)))
@@ -518,7 +534,7 @@ def test_halo_kernels_match_goldens_on_yolov3_fp32():
         lib.y3_set_tuning(b"auto_mask", DEFAULT_KNOBS["auto_mask"])
 
 
-@pytest.mark.parametrize("dtype", ["float32", "bf16"])
+@pytest.mark.parametrize("dtype", ["float32", "bf16", "fp16"])
 def test_kernel_choice_does_not_change_a_bit(dtype):
     """Every MFMA conv kernel sums a layer in the same K order (channel chunk outermost, tap innermost), so which of them
     the launcher picks -- by grid size, i.e. by batch -- changes speed only: yolov3 on the implicit GEMM everywhere, on
@@ -963,7 +979,7 @@ def test_plan_options_are_per_plan():
     assert float((o_plain["class_prob"] - o_dflt["class_prob"]).abs().median()) < 2e-3
 
 
-@pytest.mark.parametrize("dtype,dim,batch", [("bf16", 608, 2), ("float32", 416, 1), ("bf16", 320, 3)])
+@pytest.mark.parametrize("dtype,dim,batch", [("bf16", 608, 2), ("float32", 416, 1), ("bf16", 320, 3), ("fp16", 416, 2)])
 def test_spp_pyramid_kernel_is_bit_identical_to_three_pools(dtype, dim, batch):
     """yolov3-spp's three stride-1 max-pools (5 / 9 / 13, zero pad right / bottom) as ONE LDS-staged cascade launch
     against the three separate gather kernels: max is exact, so every output bit must agree."""

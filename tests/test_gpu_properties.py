@@ -21,7 +21,7 @@ def _net(dtype, model="yolov3", options=None):
     return net.eval()
 
 
-@pytest.mark.parametrize("model,dtype,batch,dim", [("yolov3", "bf16", 16, 608), ("yolov3", "float32", 16, 608),
+@pytest.mark.parametrize("model,dtype,batch,dim", [("yolov3", "bf16", 16, 608), ("yolov3", "float32", 16, 608), ("yolov3", "fp16", 16, 608),
                                                     ("yolov3-spp", "bf16", 16, 608), ("yolov3-tiny", "float32", 8, 416)])
 def test_frames_are_independent_at_full_size(model, dtype, batch, dim):
     """Row b of a full batch == the same frame run alone or in another position, BIT FOR BIT, with the default kernel
