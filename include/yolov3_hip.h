@@ -40,9 +40,9 @@ extern "C" {
 /* element types of activations / weights */
 #define Y3_F32 0
 #define Y3_BF16 1
-#define Y3_F64 3   /* float64: box coordinates handed to y3_nms_float / y3_cxywh_to_tlbr_float only (no network runs in it) */
 #define Y3_F16 2   /* IEEE half storage, float32 accumulation: every kernel of the bf16 mode instantiated on
                       v_mfma_f32_16x16x32_f16 (same rate, same bytes, 11 instead of 8 significand bits) */
+#define Y3_F64 3   /* float64: box coordinates handed to y3_nms_float / y3_cxywh_to_tlbr_float only (no network runs in it) */
 
 /* op kinds of a plan (one per Darknet block that does work) */
 #define Y3_OP_CONV 1      /* conv -> (BN as per-channel scale/bias) -> LeakyReLU -> (+residual)  darknet.py:236-264, :376-379 */
