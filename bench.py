@@ -1080,7 +1080,7 @@ def main(argv=None):
             # enough steps for a steady state: a step of yolov3-tiny is 0.6 ms (filling and draining three streams would be a
             # quarter of a 20-step run), one of float32 yolov3 18 ms
             steps = 100 if model == "yolov3-tiny" else max(6, min(args.steps, 20 if dtype == "float32" else args.steps))
-            e = w2.timed(steps, 2 * nstream, False)
+            e = w2.timed(steps, 2 * nstream, False, repeats=3)             # median of three windows, like the headline's five
             e_res = w2.timed(steps, 2 * nstream, False, resident=True)      # rounds 1-3 reported this one
             rep = w2.kernel_report(2)
             f = batch * steps / e
