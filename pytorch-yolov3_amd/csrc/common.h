@@ -20,6 +20,17 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define Y3_WAVE 64
+// cache policy of the LDS-DMA loads (the builtin's last argument: gfx940+ CPol bits, 1 = sc0, 2 = nt, 16 = sc1): 0 in the
+// product; experiment builds set them per operand (`make variant FLAGS="-DY3_AUX_W=2"`: weight tiles non-temporal, i.e. past L1)
+#ifndef Y3_AUX_W
+#define Y3_AUX_W 0
+#endif
+#ifndef Y3_AUX_A
+#define Y3_AUX_A 0
+#endif
+#ifndef Y3_AUX_H
+#define Y3_AUX_H 0        // strip kernel: the halo (pixel) slices
+#endif
 #define Y3_LEAKY_SLOPE 0.1f
 
 // diagnostic builds only (y3_set_tuning("debug", v)): 0 in the product

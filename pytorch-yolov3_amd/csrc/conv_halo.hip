@@ -171,7 +171,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       const bool ok = live && pass >= pass_lo && pass <= pass_hi;   // other rows stay zero: row hr is the consumers' zero row
       const char *src = ok ? hsrc0 + (pass * pass_step + (long long)chunk * (BKE * ES)) : p.zero;
       char *dst = sA + (chunk & 1) * p.a_bytes + pass * (NL * 16) + lwave * 1024;
-      __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, Y3_AUX_H);
     };
     const bool has_res = (p.flags & Y3_F_RESIDUAL) != 0;
     // 4 KiB slice `sl` of this tile's 256 x 128-channel shortcut operand (row = pixel, 128 * ES bytes per row)
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
         const long long koff = ((long long)tap * p.Cin + (long long)chunk * BKE) * ES;
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
-          __builtin_amdgcn_global_load_lds((gbl_void *)(b_tile + (koff + i * b_pass) + b_lane), (lds_void *)(dst + i * (NL * 16)), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_void *)(b_tile + (koff + i * b_pass) + b_lane), (lds_void *)(dst + i * (NL * 16)), 16, 0, Y3_AUX_W);
       } else {
         // past the last K-step: the instruction count per step stays (counted waits) but the pieces read the zero page --
         // a real weight tile here is 16 KiB nobody uses, and the epilogue's barrier waits for it to land

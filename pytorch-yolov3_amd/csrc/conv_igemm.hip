@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
 #endif
 #pragma unroll
     for (int i = 0; i < A_CH; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void *)src[i], (lds_void *)(sA + wave * 1024 + i * (NT * 16)), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void *)src[i], (lds_void *)(sA + wave * 1024 + i * (NT * 16)), 16, 0, Y3_AUX_A);
     long long koff = (long long)kt * RB;
     if constexpr (KMODE == 0) {
       const int chunk = kt / p.n_taps;
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void *)(b_base[i] + koff), (lds_void *)(sB + wave * 1024 + i * (NT * 16)), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void *)(b_base[i] + koff), (lds_void *)(sB + wave * 1024 + i * (NT * 16)), 16, 0, Y3_AUX_W);
   };
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -755,11 +755,11 @@ void conv_igemm3_kernel(IgemmArgs p) {
         if ((p.flags & 0x40000000u) && p.stride == 2 && tap != 0) ok = false;
 #endif
         const char *src = ok ? a_base[i] + tap_off : p.zero;
-        __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(sA + lwave * 1024 + i * (NC * 16)), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(sA + lwave * 1024 + i * (NC * 16)), 16, 0, Y3_AUX_A);
       }
 #pragma unroll
       for (int i = 0; i < B_CH; ++i)
-        __builtin_amdgcn_global_load_lds((gbl_void *)(b_base[i] + koff), (lds_void *)(sB + lwave * 1024 + i * (NC * 16)), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void *)(b_base[i] + koff), (lds_void *)(sB + lwave * 1024 + i * (NC * 16)), 16, 0, Y3_AUX_W);
     };
     int stage_next = 0;                               // stage that receives the next issued tile
     for (int t = 0; t < NS - 1 && t < n_kt; ++t) {
