@@ -182,6 +182,12 @@ def test_bench_prints_one_contract_json_line():
                                                            "yolov3 608x608 batch=16 float32"}
     for o in d["other_configs"]:
         assert o["value"] > 0 and abs(o["roofline"]["frac"] - o["roofline"]["achieved"] / o["roofline"]["peak"]) < 1e-3
+    # the headline workload at the reference test's thresholds and in a heavy regime (more candidates, all kept
+    # boxes still inside the records)
+    regimes = d["detection_regimes"]
+    assert [(g["prob_thresh"], g["nms_iou_thresh"]) for g in regimes] == [(0.2, 0.3), (0.05, 0.3)]
+    assert all(g["value"] > 0 and g["candidates_per_frame"] >= g["kept_per_frame"] for g in regimes)
+    assert regimes[1]["candidates_per_frame"] > regimes[0]["candidates_per_frame"] and regimes[1]["kept_per_frame"] <= regimes[1]["kmax"]
     agree = d["bf16_agreement"]["thr_0.05_iou_0.3"]
     assert len(agree["keep_set_jaccard"]) == 3 and min(agree["keep_set_jaccard"]) > 0.4
     assert agree["score_abs_diff"]["median"] < 0.01
