@@ -65,6 +65,7 @@ struct y3_plan {
   std::vector<char> fuse;   // per op: 0 = launch normally, 1 / 3 / 4 / 6 = launch fused with the next op (stem pair /
                             // 64-32-64 residual block / head conv + decode / 128-channel bottleneck block), 5 = SPP
                             // pyramid with the next TWO ops, 2 = nothing (fused into a previous op)
+  std::vector<void *> frag_w;   // per op: the plan's fragment-order copy of a conv's weights (direct-weights strip kernel), or null
   std::vector<hipEvent_t> events;
   // hipGraph replay (one graph launch per forward instead of ~80 kernel launches): executable graphs keyed by the
   // input pointer they were captured with; the first run of a plan is always eager (one-time function attributes)
@@ -86,7 +87,7 @@ int conv_path(const y3_op &op) {
 }
 
 int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream_t s, const char **name,
-             bool dry_run) {
+             bool dry_run, const void *frag_w = nullptr) {
   const void *in = (op.flags & Y3_F_PLAN_INPUT) ? d_input : op.d_in;
   if (!dry_run) {
     Y3_REQUIRE(in != nullptr, "op for block %d has no input pointer", op.block_idx);
@@ -132,6 +133,10 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
             // (Which kernel runs changes speed only: every MFMA conv kernel sums in the same K order.)
             const long long halo_tiles = (long long)y3_ceil_div(op.batch * op.in_h * op.in_w, 192) * (op.out_c / 128);
             const bool small_grid = !(am & Y3_AM_NO_SMALL_GRID) && k3 && halo_tiles < (3 * y3_device_cus()) / 4;
+            // direct-weights strip kernel (192 x 256 tiles) where its tile count fills the chip better (csrc/conv_halo.hip)
+            if (k3 && !small_grid && halo_ok && (((am & Y3_AM_HALO_DW) && y3_conv_halo_dw_pays(op)) ||
+                                                 ((am & Y3_AM_HALO_DW_ALWAYS) && y3_conv_halo_dw_fits(op))))
+              return y3_launch_conv_halo_dw(op, in, d_zero, s, name, dry_run, frag_w);
             if (small_grid && y3_is16(op.dtype)) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
             if (want_halo && halo_ok && !small_grid) return y3_launch_conv_halo(op, in, d_zero, s, name, dry_run);
             if (want_ws) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
@@ -172,7 +177,7 @@ int run_op(y3_plan *plan, size_t i, const void *d_input, hipStream_t s, const ch
     Y3_REQUIRE(in != nullptr, "op for block %d has no input pointer", op0.block_idx);
     return y3_launch_conv_fused_stem_s2(op0, plan->ops[i + 1], in, s, name, false);
   }
-  return dispatch(plan->ops[i], d_input, plan->d_zero, s, name, false);
+  return dispatch(plan->ops[i], d_input, plan->d_zero, s, name, false, plan->frag_w[i]);
 }
 
 }  // namespace
@@ -218,6 +223,8 @@ int y3_plan_create_ex(const y3_op *ops, int n_ops, const void *d_zero, const y3_
   OptScope scope(&p->opt);
   p->ops.assign(ops, ops + n_ops);
   p->kernel.assign(n_ops, "");
+  p->frag_w.assign(n_ops, nullptr);
+  bool made_weights = false;
   p->d_zero = d_zero;
   p->fuse.assign(n_ops, 0);
   for (int i = 0; i + 2 < n_ops; ++i)
@@ -265,9 +272,31 @@ int y3_plan_create_ex(const y3_op *ops, int n_ops, const void *d_zero, const y3_
     }
     const int rc = dispatch(p->ops[i], nullptr, d_zero, nullptr, &p->kernel[i], true);
     if (rc != Y3_OK) {
-      delete p;
+      y3_plan_destroy(p);
       return rc;
     }
+    if (strncmp(p->kernel[i], "conv_halo_dw_", 13) == 0) {
+      // this kernel reads its weights in MFMA-fragment order: the plan keeps its own copy (made once, here; the plan is
+      // destroyed with the parameters it was compiled for)
+      void *w = nullptr;
+      if (hipMalloc(&w, y3_conv_halo_dw_weight_bytes(p->ops[i])) != hipSuccess) {
+        y3_set_error("y3_plan_create: no memory for the fragment-order weights of block %d", p->ops[i].block_idx);
+        y3_plan_destroy(p);
+        return Y3_ERR_HIP;
+      }
+      p->frag_w[i] = w;
+      const int rc2 = y3_conv_halo_dw_make_weights(p->ops[i], w, nullptr);
+      if (rc2 != Y3_OK) {
+        y3_plan_destroy(p);
+        return rc2;
+      }
+      made_weights = true;
+    }
+  }
+  if (made_weights && hipStreamSynchronize(nullptr) != hipSuccess) {
+    y3_set_error("y3_plan_create: fragment-order weights: %s", hipGetErrorString(hipGetLastError()));
+    y3_plan_destroy(p);
+    return Y3_ERR_HIP;
   }
   *out_plan = p;
   return Y3_OK;
@@ -277,6 +306,8 @@ void y3_plan_destroy(y3_plan *plan) {
   if (!plan) return;
   for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
   for (auto &g : plan->graphs) (void)hipGraphExecDestroy(g.exec);
+  for (void *w : plan->frag_w)
+    if (w) (void)hipFree(w);
   delete plan;
 }
 

@@ -347,6 +347,12 @@ int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d
                                const char **kernel_name, bool dry_run);
 // halo-reuse 3x3 kernel (conv_halo.hip): whether it can take this conv, and its launcher
 bool y3_conv_halo_ws_fits(const y3_op &op);
+bool y3_conv_halo_dw_fits(const y3_op &op);
+bool y3_conv_halo_dw_pays(const y3_op &op);
+size_t y3_conv_halo_dw_weight_bytes(const y3_op &op);
+int y3_conv_halo_dw_make_weights(const y3_op &op, void *dst, hipStream_t s);
+int y3_launch_conv_halo_dw(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
+                           const char **kernel_name, bool dry_run, const void *frag_w);
 int y3_launch_conv_halo(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
                         const char **kernel_name, bool dry_run);
 // 1x1 conv with LDS-resident weights, persistent workgroups (conv_1x1.hip)

@@ -879,6 +879,258 @@ __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Direct-weights strip kernel (round 5 experiment; 16-bit storage modes): a workgroup owns 256 raster pixels x 256 output
+// channels.  Eight waves, two per SIMD, no roles: each computes 128 pixels x 64 channels (128 accumulator registers),
+// reads its pixel fragments from the halo image in LDS exactly like conv_halo_ws_kernel (tap = row offset, border taps
+// redirected to the zero row) and takes its WEIGHT fragments straight from global memory into registers: a lane's eight
+// K-elements of one channel row are 16 contiguous bytes of the [Cout][K] weight matrix, so one global_load_dwordx4 per
+// fragment delivers the MFMA operand layout as it is.  No weight ring, no per-step barrier (one barrier per channel chunk,
+// when the halo buffers swap), half the LDS fragment reads per MFMA of the 64 x 64 wave tile, and the halo is staged once
+// for 256 channels instead of once per 128.  Per K-step (64 channels of one tap) a wave issues 64 MFMAs, 16 ds_read_b128,
+// 8 global_load_dwordx4 (one K-step ahead, three register sets of four fragments in rotation) and ONE 1-KiB LDS-DMA piece
+// of the next chunk's halo.  Same K order (chunk outermost, tap innermost, K-halves in order) as every other MFMA conv
+// kernel here: same bits.
+template <int N, typename V>
+__device__ __forceinline__ void dw_wait_vm(V (&w)[4]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N) : "memory");
+}
+
+template <typename T, int NA>
+__global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
+  static_assert(sizeof(T) == 2 && NA >= 4 && NA <= 6, "16-bit storage modes only; 4 .. 6 halo passes per chunk");
+  constexpr int MI = 6, NI = 4;                       // wave tile: 6 x 16 pixels, 4 x 16 channels (8 x 16 pixels needs 256+ VGPRs: spills)
+  constexpr int WM = MI * 16, MH = MI / 2;
+  constexpr int BM = 2 * WM, BN = 256;
+  constexpr int NT = 512;
+  constexpr int ES = 2, BKE = 64;
+  constexpr int RPL = NT / 8;                         // halo rows filled per pass of the workgroup (64)
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *sA = smem;                                    // [2][hr_pad][128]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
+  const int grp = tile / (p.m_tiles * p.ngrp_w), rem = tile - grp * (p.m_tiles * p.ngrp_w);
+  const int m0 = (rem / p.ngrp_w) * BM;
+  const int n0 = (grp * p.ngrp_w + rem % p.ngrp_w) * BN;
+  const int wm = wave >> 2, wn = wave & 3;            // waves w and w + 4 share a SIMD and a channel slice
+  const int fr = lane & 15, fq = lane >> 4;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- halo image: every thread fills its 16 bytes of each 64-row pass (see conv_halo_ws_kernel's loader) ----
+  const int slot = tid & 7;
+  const int row0 = tid >> 3;
+  const int kc = slot ^ (row0 & 7);
+  const long long qr = (long long)m0 - p.W - 1 + row0;
+  const int hi_rows = (p.hr - 1 - row0) >> 6;
+  const long long hi_px = qr < p.M ? (p.M - 1 - qr) >> 6 : -1;
+  const int pass_lo = qr >= 0 ? 0 : (int)((-qr + 63) >> 6);
+  const int pass_hi = hi_px < hi_rows ? (int)hi_px : hi_rows;
+  const char *hsrc0 = p.in + (qr * p.in_ld) * ES + kc * 16;
+  const long long pass_step = (long long)RPL * p.in_ld * ES;
+  auto issue_halo_pass = [&](int chunk, int pass, bool live) {
+    const bool ok = live && pass >= pass_lo && pass <= pass_hi;
+    const char *src = ok ? hsrc0 + (pass * pass_step + (long long)chunk * (BKE * ES)) : p.zero;
+    char *dst = sA + (chunk & 1) * p.a_bytes + pass * (NT * 16) + wave * 1024;
+    __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, Y3_AUX_H);
+  };
+
+  // ---- weight fragments, from the FRAGMENT-ORDER copy of the weights (y3_conv_halo_dw_layout): the 1 KiB that the 64 lanes
+  // of a wave need for 16 channels x 32 K-elements is contiguous, lane l's 16 bytes at l * 16 -- a fully coalesced load (the
+  // [Cout][K] layout makes every four lanes touch four different rows: measured 1.5x slower end of K-step, r05s).  Block
+  // (channel block cb, K block kb of 64 bytes) sits at ((cb * KB + kb) << 10), KB = k_ld / 32.
+  const uint32_t kblocks = (uint32_t)p.k_ld / 32u;
+  const uint32_t b_voff = (uint32_t)lane * 16;
+  const char *b_base[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) b_base[ni] = p.wgt + (((long long)((n0 + wn * 64) / 16 + ni) * kblocks) << 10);
+  auto load_w0 = [&](u32x4 (&w)[NI], uint32_t voff) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[ni]) : "v"(voff), "s"(b_base[ni]));
+  };
+  auto load_w1 = [&](u32x4 (&w)[NI], uint32_t voff) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(w[ni]) : "v"(voff), "s"(b_base[ni]));
+  };
+
+  // ---- pixel fragments ----
+  // nine-bit tap masks of the wave's eight fragments, three per register
+  uint32_t tm[(MI + 2) / 3] = {};
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const uint32_t m = (uint32_t)(m0 + wm * WM + mi * 16 + fr);
+    const uint32_t img = (__umulhi(m, p.mul_hw) + m) >> p.sh_hw;
+    const uint32_t r = m - img * (uint32_t)p.HW;
+    const uint32_t oy = (__umulhi(r, p.mul_w) + r) >> p.sh_w;
+    const uint32_t ox = r - oy * (uint32_t)p.W;
+    const uint32_t vx = (ox >= 1u ? 1u : 0u) | 2u | (ox + 1u < (uint32_t)p.W ? 4u : 0u);
+    const uint32_t t9 = (oy >= 1u ? vx : 0u) | (vx << 3) | (oy + 1u < (uint32_t)p.H ? vx << 6 : 0u);
+    tm[mi / 3] |= t9 << (9 * (mi % 3));
+  }
+  typedef const __attribute__((address_space(3))) u32x4 lds_u32x4;
+  const int sA_lds = (int)(size_t)(lds_void *)sA;
+  const int zbase = sA_lds + p.hr * 128;              // rows hr, hr + 1 of buffer 0: always zero
+  const int a_lane_row = wm * WM + fr;
+  int sel[MI];
+  // K-half 0 of tap `tap`: fragment addresses (border taps redirected to the zero row) for all eight fragments, then the
+  // reads of fragments [lo, lo + 4)
+  auto frag_addrs = [&](auto tapc, int a_off) {
+    constexpr int tap = decltype(tapc)::value, ky = tap / 3, kx = tap % 3;
+    const int r0 = a_lane_row + ky * p.W + kx;
+    const int ap = ((r0 << 7) + (a_off + sA_lds)) + ((fq ^ (r0 & 7)) << 4);
+    const int zoff = (ap & 255) | zbase;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      int off = ap + mi * 2048;
+      if constexpr (tap != 4) off = ((tm[mi / 3] >> (9 * (mi % 3) + tap)) & 1u) ? off : zoff;
+      sel[mi] = off;
+    }
+  };
+  auto read_half = [&](u32x4 (&xf)[MI], int lo, int flip) {
+#pragma unroll
+    for (int mi = 0; mi < MH; ++mi) xf[lo + mi] = *reinterpret_cast<lds_u32x4 *>(sel[lo + mi] ^ flip);
+  };
+  auto mma_half = [&](const u32x4 (&xf)[MI], int lo, const u32x4 (&wf)[NI]) {
+#pragma unroll
+    for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[lo + mi][ni] = y3_mfma16<T>(wf[ni], xf[lo + mi], acc[lo + mi][ni]);
+  };
+
+  // ---- prologue: halo of chunk 0, both K-halves of step 0's weights, step 0's first pixel fragments ----
+  u32x4 wf[3][NI];
+  u32x4 xf[MI];
+  for (int pass = 0; pass < p.na; ++pass) issue_halo_pass(0, pass, true);
+  load_w0(wf[0], b_voff);
+  load_w1(wf[2], b_voff);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);       // the younger wave of each SIMD (see conv_halo_ws_kernel)
+  frag_addrs(TapC<0>{}, 0);
+  read_half(xf, 0, 0);
+  read_half(xf, MH, 0);
+
+  // One K-step.  Weight register sets: the step with index S = tap % 3 multiplies K-half 0 with wf[S] and K-half 1 with
+  // wf[(S + 2) % 3]; the next step's K-half 0 is loaded into wf[(S + 1) % 3] at the top, its K-half 1 into wf[S] once this
+  // step's K-half 0 MFMAs are issued.  VMEM order per step: 4 loads, at most 1 halo piece, 4 loads -- the counted waits rely on it.
+  // Pixel fragments: eight registers sets of one fragment; a half (four fragments) is re-read for the next K-half as soon as
+  // the sixteen MFMAs that use it are issued, so every read has sixteen MFMAs (256+ cycles) to land.
+  auto kstep = [&](auto tapc, int chunk) {
+    constexpr int tap = decltype(tapc)::value, S = tap % 3, tap_n = tap == 8 ? 0 : tap + 1;
+    const int chunk_n = tap == 8 ? chunk + 1 : chunk;
+    const uint32_t voff_n = b_voff + ((uint32_t)(tap_n * (p.Cin / 32) + chunk_n * 2) << 10);
+    load_w0(wf[(S + 1) % 3], voff_n);
+    // one 64-row pass of the next chunk's halo per step while there are any (4-6 of the 9 steps; a piece costs the issuing
+    // wave 60-185 cycles: without them the launch is 10-15 % shorter, so none is issued that is not needed)
+    // (NA = the number of passes, a template parameter: 4 .. 6 covers every map the wave-specialised kernel takes, rows of up
+    // to 94 pixels; as a run-time test the branch costs registers the kernel does not have -- 96 bytes of scratch, 15 % slower)
+    if constexpr (tap < NA) issue_halo_pass(chunk + 1, tap, chunk + 1 < p.nchunks);
+    // younger than wf[S]'s loads: 4 loads of the previous step + 4 of this one for certain, up to two halo pieces maybe --
+    // the count that is always safe is 8
+    dw_wait_vm<8>(wf[S]);
+    mma_half(xf, 0, wf[S]);
+    read_half(xf, 0, 64);
+    mma_half(xf, MH, wf[S]);
+    read_half(xf, MH, 64);
+    __builtin_amdgcn_sched_barrier(0);
+    load_w1(wf[S], voff_n);
+    dw_wait_vm<8>(wf[(S + 2) % 3]);                   // younger for certain: 4 + 4 loads of this step
+    mma_half(xf, 0, wf[(S + 2) % 3]);
+    if constexpr (tap == 8) {
+      // chunk boundary: the next step reads the other halo buffer.  Its pieces (the youngest was issued before the last
+      // four loads) have landed for this wave ... and, after the barrier, for all; the barrier also tells that everyone
+      // is done with the buffer that the next chunk's pieces will overwrite -- EXCEPT the second half of this K-half's
+      // fragments, which are in registers already
+      mma_half(xf, MH, wf[(S + 2) % 3]);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      frag_addrs(TapC<tap_n>{}, (chunk_n & 1) * p.a_bytes);
+      read_half(xf, 0, 0);
+      read_half(xf, MH, 0);
+    } else {
+      frag_addrs(TapC<tap_n>{}, (chunk_n & 1) * p.a_bytes);
+      read_half(xf, 0, 0);
+        mma_half(xf, MH, wf[(S + 2) % 3]);
+        read_half(xf, MH, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#pragma unroll 1
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    kstep(TapC<0>{}, chunk); kstep(TapC<1>{}, chunk); kstep(TapC<2>{}, chunk);
+    kstep(TapC<3>{}, chunk); kstep(TapC<4>{}, chunk); kstep(TapC<5>{}, chunk);
+    kstep(TapC<6>{}, chunk); kstep(TapC<7>{}, chunk); kstep(TapC<8>{}, chunk);
+  }
+  __builtin_amdgcn_s_setprio(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead loads of the step after the last, the last halo pieces
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();                       // nobody reads the halo any more: LDS holds the output tile
+
+  // ---- epilogue: two channel halves of 128; the four waves that own a half park it, all 512 threads write it out ----
+  constexpr int SWZ = 15;
+  constexpr int RPP = NT / 16;                        // 32 pixel rows per pass
+  constexpr int WR = BM / RPP;                        // 8
+  float *sC = reinterpret_cast<float *>(smem);
+  const bool leaky = p.flags & Y3_F_LEAKY;
+  const bool has_res = p.flags & Y3_F_RESIDUAL;
+  const int oc_mine = tid & 15;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if ((wn >> 1) == h) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int cl = (wn & 1) * 64 + ni * 16 + fq * 4;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int pl = wm * WM + mi * 16 + fr;
+          *reinterpret_cast<f32x4 *>(sC + pl * 128 + (((cl >> 2) ^ (pl & SWZ)) << 2)) = acc[mi][ni];
+        }
+      }
+    }
+    // (both halves' scale / bias / shortcut reads issued up front, under the first half's write-out, need 48 more registers
+    // than the kernel has: 96 bytes of scratch and a K loop that drains vmcnt for every reload -- measured 15 % slower)
+    const int co = n0 + h * 128 + oc_mine * 8;
+    const f32x4 sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
+    const f32x4 sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+    const f32x4 bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
+    const f32x4 bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+    u32x4 resv[WR];
+    if (has_res) {
+#pragma unroll
+      for (int j = 0; j < WR; ++j) {
+        const int m = m0 + (tid >> 4) + j * RPP;
+        const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
+        resv[j] = m < p.M ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WR; ++j) {
+      const int pl = (tid >> 4) + j * RPP;
+      const int m = m0 + pl;
+      if (m >= p.M) continue;
+      const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * 128 + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
+      const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * 128 + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
+      float v[8];
+      y3_bn_leaky8(v, lo, hi, sc_lo, sc_hi, bi_lo, bi_hi, leaky);
+      if (has_res) y3_add8<T>(v, resv[j]);
+      T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
+      *reinterpret_cast<u32x4 *>(op) = y3_pack8<T>(v);
+    }
+    if (h == 0) __syncthreads();                      // the first half is out of LDS before the second is parked
+  }
+}
+
 // n / d == (umulhi(n, mul) + n) >> sh for 0 <= n < 2^31 (round-up method, d >= 1)
 void fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
   if (d <= 1) { mul = 0; sh = 0; return; }
@@ -975,6 +1227,69 @@ int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
   return Y3_OK;
 }
 
+// [Cout_pad][k_ld] 16-bit weights -> fragment order: 1-KiB blocks of 16 channels x 32 K-elements, lane l = fq * 16 + fr of a
+// wave holds channel fr, K-elements [8 fq, 8 fq + 8) of the block at l * 16 (the MFMA operand layout of y3_mfma16's first
+// operand); block (cb, kb) at (cb * (k_ld / 32) + kb) << 10.  One thread per 16 bytes.
+__global__ __launch_bounds__(256) void weights_to_fragment_order_kernel(const u32x4 *src, u32x4 *dst, int kblocks, long long n16) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n16) return;
+  const int l = (int)(i & 63);
+  const long long blk = i >> 6;
+  const long long cb = blk / kblocks;
+  const int kb = (int)(blk - cb * kblocks);
+  const int fr = l & 15, fq = l >> 4;
+  dst[i] = src[((cb * 16 + fr) * kblocks + kb) * 4 + fq];   // row (cb * 16 + fr): kblocks * 4 pieces of 16 bytes
+}
+
+constexpr int DW_BM = 192;
+
+template <typename T>
+int launch_halo_dw(const HaloArgs &a0, hipStream_t s) {
+  HaloArgs a = a0;
+  static Y3DeviceOnce once;
+  int n_cu = 256;
+  {
+    const int rc = once.run([]() -> int {
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_dw_kernel<T, 4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_dw_kernel<T, 5>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_dw_kernel<T, 6>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      return Y3_OK;
+    }, &n_cu);
+    if (rc != Y3_OK) return rc;
+  }
+  a.hr = DW_BM + 2 * a.W + 2;
+  a.na = y3_ceil_div(a.hr + 2, 64);                   // + the two zero rows
+  a.hr_pad = a.na * 64;
+  a.a_bytes = a.hr_pad * 128;
+  size_t lds = (size_t)2 * a.a_bytes;
+  if (lds < (size_t)DW_BM * 128 * 4) lds = (size_t)DW_BM * 128 * 4;
+  Y3_REQUIRE(a.na >= 4 && a.na <= 6 && lds <= 160 * 1024, "direct-weights halo kernel: row width %d does not fit", a.W);
+  a.m_tiles = y3_ceil_div(a.M, DW_BM);
+  a.n_tiles = a.Cout / 256;
+  {
+    // tile order over the XCDs: as launch_halo_ws
+    const double in_b = (double)a.M * a.Cin, w_b = 9.0 * a.Cin * a.Cout;
+    int best = 1;
+    double best_cost = 0;
+    for (int pn = 1; pn <= 8; pn <<= 1) {
+      if (a.n_tiles % pn) break;
+      const double cost = pn * in_b + (8.0 / pn) * w_b;
+      if (pn == 1 || cost < 0.9 * best_cost) { best = pn; best_cost = cost; }
+    }
+    a.ngrp_w = a.n_tiles / best;
+  }
+  const dim3 grid(a.m_tiles * a.n_tiles);
+  // halo passes per chunk: 4 (rows of up to 30 pixels), 5 (up to 62), 6 (up to 94)
+  if (a.na <= 4) hipLaunchKernelGGL((conv_halo_dw_kernel<T, 4>), grid, dim3(512), lds, s, a);
+  else if (a.na == 5) hipLaunchKernelGGL((conv_halo_dw_kernel<T, 5>), grid, dim3(512), lds, s, a);
+  else hipLaunchKernelGGL((conv_halo_dw_kernel<T, 6>), grid, dim3(512), lds, s, a);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
 template <typename T>
 int launch_patch_wsp(const HaloArgs &a0, hipStream_t s) {
   HaloArgs a = a0;
@@ -1022,6 +1337,87 @@ bool y3_conv_halo_ws_fits(const y3_op &op) {
   if (!y3_conv_halo_eligible(op)) return false;
   const int na = y3_ceil_div(256 + 2 * op.in_w + 4, 32);
   return na <= 14 && (size_t)3 * 128 * 128 + (size_t)2 * na * 32 * 128 <= 160 * 1024;
+}
+
+// direct-weights strip kernel (round 5): 16-bit modes, Cout a multiple of 256, rows of up to 94 pixels (four to six 64-row halo
+// passes per chunk; the same maps the wave-specialised kernel takes)
+bool y3_conv_halo_dw_fits(const y3_op &op) {
+  if (!y3_conv_halo_eligible(op) || !y3_is16(op.dtype) || op.out_c % 256 != 0 || op.cout_pad % 16 != 0 || op.k_ld % 32 != 0) return false;
+  const int na = y3_ceil_div(DW_BM + 2 * op.in_w + 4, 64);
+  return na >= 4 && na <= 6 && y3_conv_halo_ws_fits(op);
+}
+
+// Where it is the better kernel.  Per workgroup the two strip kernels do the same work per cycle (PMC, profiles/r05s: 64 % of
+// the matrix pipe over a workgroup's life either way), so what decides is how the tile count fills the chip: rounds of
+// workgroups x time per tile (K-steps x cycles per step + cycles outside the loop; stamps / PMC of both kernels).  yolov3 @ 608,
+// batch 16: 256 -> 512 at 38^2 is 364 tiles of 256 x 128 in two rounds against 242 of 192 x 256 in one: 58.5 -> 49.5 us,
+// 930 -> 1100 TFLOP/s per launch (profiles/r05s_halo_dw.txt).  Layers with fewer than four channel chunks stay on the
+// wave-specialised kernel (76^2: its shorter prologue / epilogue wins), and so does everything the model puts within 7 %.
+bool y3_conv_halo_dw_pays(const y3_op &op) {
+  if (!y3_conv_halo_dw_fits(op)) return false;
+  const int es = y3_elem_size(op.dtype);
+  const int nchunks = op.in_c / (128 / es), n_cu = y3_device_cus();
+  if (nchunks < 4) return false;
+  const int M = op.batch * op.in_h * op.in_w;
+  const int mi = halo_tile_fragments(M, op.out_c / 128, nchunks, n_cu);
+  const long long t_ws = (long long)y3_ceil_div(M, 64 * mi) * (op.out_c / 128), t_dw = (long long)y3_ceil_div(M, DW_BM) * (op.out_c / 256);
+  const double c_ws = (double)((t_ws + n_cu - 1) / n_cu) * (nchunks * 9.0 * (256.0 * mi + 300.0) + 13000.0);
+  const double c_dw = (double)((t_dw + n_cu - 1) / n_cu) * (nchunks * 9.0 * 1920.0 + 17000.0);
+  return c_dw < 0.93 * c_ws;
+}
+
+size_t y3_conv_halo_dw_weight_bytes(const y3_op &op) { return (size_t)op.cout_pad * op.k_ld * 2; }
+
+// the fragment-order copy of op's weights into `dst` (y3_conv_halo_dw_weight_bytes), on `s`
+int y3_conv_halo_dw_make_weights(const y3_op &op, void *dst, hipStream_t s) {
+  const long long n16 = (long long)op.cout_pad * op.k_ld * 2 / 16;
+  hipLaunchKernelGGL(weights_to_fragment_order_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s,
+                     static_cast<const u32x4 *>(op.d_weight), static_cast<u32x4 *>(dst), op.k_ld / 32, n16);
+  Y3_HIP_CHECK(hipGetLastError());
+  return Y3_OK;
+}
+
+// `frag_w`: the plan's fragment-order copy of the weights; nullptr (single-op calls, unit tests): made here, stream-ordered
+int y3_launch_conv_halo_dw(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,
+                           const char **kernel_name, bool dry_run, const void *frag_w) {
+  Y3_REQUIRE(y3_conv_halo_dw_fits(op), "conv block %d: shape not supported by the direct-weights halo kernel", op.block_idx);
+  *kernel_name = Y3_KNAME(op.dtype, "conv_halo_dw_", "_192x256");
+  if (dry_run) return Y3_OK;
+  void *tmp = nullptr;
+  if (!frag_w) {
+    Y3_HIP_CHECK(hipMallocAsync(&tmp, y3_conv_halo_dw_weight_bytes(op), s));
+    const int rc = y3_conv_halo_dw_make_weights(op, tmp, s);
+    if (rc != Y3_OK) { (void)hipFreeAsync(tmp, s); return rc; }
+    frag_w = tmp;
+  }
+  HaloArgs a;
+  a.in = static_cast<const char *>(d_in);
+  a.wgt = static_cast<const char *>(frag_w);
+  a.scale = op.d_scale; a.bias = op.d_bias;
+  a.res = static_cast<const char *>(op.d_res);
+  a.out = static_cast<char *>(op.d_out);
+  a.zero = static_cast<const char *>(d_zero);
+  a.H = op.in_h; a.W = op.in_w; a.Cin = op.in_c; a.in_ld = op.in_ld;
+  a.Cout = op.out_c; a.out_ld = op.out_ld; a.res_ld = op.res_ld;
+  a.HW = op.in_h * op.in_w;
+  a.M = op.batch * a.HW;
+  a.k_ld = op.k_ld;
+  a.nchunks = op.in_c / 64;
+  a.n_tiles = op.out_c / 256;
+  a.hr = a.hr_pad = a.na = a.a_bytes = 0;
+  a.ngrp_w = a.n_tiles; a.m_tiles = 0;
+  fast_div((uint32_t)a.HW, a.mul_hw, a.sh_hw);
+  fast_div((uint32_t)a.W, a.mul_w, a.sh_w);
+  a.flags = op.flags;
+  int rc = Y3_OK;
+  if ((long long)op.batch * a.HW >= (1ll << 31)) {
+    y3_set_error("conv block %d: too many pixels for the 32-bit tile index", op.block_idx);
+    rc = Y3_ERR_INVALID;
+  } else {
+    rc = y3_by_dtype16(op.dtype, [&](auto tag) { return launch_halo_dw<decltype(tag)>(a, s); });
+  }
+  if (tmp) (void)hipFreeAsync(tmp, s);
+  return rc;
 }
 
 // 2-D patch kernel: same layer class, any number (>= 1) of channel chunks, any row width

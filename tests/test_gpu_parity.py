@@ -113,7 +113,7 @@ def test_mini_fp16_close_to_fp32_and_its_two_stems_agree():
     assert (a["class_idx"] == b["class_idx"]).float().mean() > 0.99
 
 
-DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 157, "fuse_stem": 1, "decode_lanes": 4, "use_graph": 0, "fuse_head": 1, "fuse_spp": 1}
+DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 0x409d, "fuse_stem": 1, "decode_lanes": 4, "use_graph": 0, "fuse_head": 1, "fuse_spp": 1}
 
 
 def test_tuning_knobs_do_not_change_results():
@@ -548,12 +548,44 @@ def test_kernel_choice_does_not_change_a_bit(dtype):
     for opts in ({"auto_mask": _hip.AM_IGEMM_ONLY}, {"auto_mask": halo | _hip.AM_PATCH_WIDE}, {"auto_mask": halo | _hip.AM_HALO_TILE256},
                  {"auto_mask": _hip.AM_IGEMM_ONLY, "igemm_version": 3, "igemm_ns": 3},
                  {"auto_mask": _hip.AM_IGEMM_ONLY, "igemm_bm": 96},           # 96 x 64 tiles wherever Cout is a multiple of 64
+                 {"auto_mask": halo | _hip.AM_HALO_DW_ALWAYS},                # direct-weights strip kernel wherever it fits (16-bit)
                  None):
         net = _net("yolov3", dtype=dtype, options=opts)
         outs.append({k: v.clone() for k, v in net.forward_frames(frames).items()})
+        if opts and opts.get("auto_mask", 0) & _hip.AM_HALO_DW_ALWAYS and dtype != "float32":
+            assert sum("conv_halo_dw" in r["kernel"] for r in net.plan_report()) >= 25, [r["kernel"] for r in net.plan_report()]
     for o in outs[1:]:
         for k in ("bbox_xywh", "class_prob", "class_idx"):
             assert torch.equal(o[k], outs[0][k]), k
+
+
+@pytest.mark.parametrize("model", ["yolov3", "yolov3-spp"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_direct_weights_kernel_is_chosen_at_batch16_and_changes_no_bit(model, dtype):
+    """BASELINE configs[2] / [3] (608 x 608, batch 16): the 256 -> 512 layers at 38^2 are 364 tiles of 256 x 128 -- two rounds of
+    workgroups on 256 CUs, the second 42 % full -- against 242 of 192 x 256 in one round; the launcher picks the direct-weights
+    strip kernel for them (its weights in MFMA-fragment order: a copy the plan makes), and forbidding it gives the same bits.  Also
+    at an input size whose maps have other halo heights than the three instantiated ones (352 x 480: the run-time form)."""
+    from yolov3 import _hip
+    frames = synth_frames(43, 16, 608, 608)
+    a = _net(model, dtype=dtype)
+    oa = {k: v.clone() for k, v in a.forward_frames(frames).items()}
+    names = [r["kernel"] for r in a.plan_report()]
+    assert sum("conv_halo_dw" in n for n in names) >= 8, names
+    b = _net(model, dtype=dtype, options={"auto_mask": _hip.AM_DEFAULT & ~_hip.AM_HALO_DW})
+    ob = b.forward_frames(frames)
+    assert not any("conv_halo_dw" in r["kernel"] for r in b.plan_report())
+    for k in ("bbox_xywh", "class_prob", "class_idx"):
+        assert torch.equal(oa[k], ob[k]), k
+    small = synth_frames(44, 3, 352, 480)
+    halo = _hip.AM_HALO_ALL | _hip.AM_NO_SMALL_GRID
+    c = _net(model, dtype=dtype, options={"auto_mask": halo | _hip.AM_HALO_DW_ALWAYS})
+    oc = {k: v.clone() for k, v in c.forward_frames(small).items()}
+    assert sum("conv_halo_dw" in r["kernel"] for r in c.plan_report()) >= 20
+    d = _net(model, dtype=dtype, options={"auto_mask": halo})
+    od = d.forward_frames(small)
+    for k in ("bbox_xywh", "class_prob", "class_idx"):
+        assert torch.equal(oc[k], od[k]), k
 
 
 @pytest.mark.parametrize("dtype", ["float32"])

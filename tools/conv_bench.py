@@ -2,7 +2,7 @@
 """Micro-benchmark of the conv kernels on the Darknet-53 layer shapes (runs ON THE GPU BOX).
 
 For every (layer shape, kernel variant) it launches the single op through the C ABI (y3_op_run),
-times it with HIP events over many iterations on random data, and checks that all variants agree
+times it (a one-op plan, y3_plan_run) with HIP events over many iterations on random data, and checks that all variants agree
 with variant 0.  Interleaved rounds in one process (cdna_hip_programming.md rule 24).
 Usage: python tools/conv_bench.py [--batch 16] [--dtype bf16] [--iters 20] [--out file]
 """
@@ -56,6 +56,8 @@ VARIANTS = [
     ("igemm_v3_bm64_ns3", dict(BASE, igemm_version=3, igemm_ns=3, igemm_bm=64)),
     ("halo_ws_256", dict(BASE, auto_mask=AM.AM_HALO_ALL | AM.AM_HALO_TILE256)),
     ("igemm_v2_bn128", dict(BASE, auto_mask=AM.AM_NO_BN_SHRINK)),
+    ("halo_dw", dict(BASE, auto_mask=AM.AM_HALO_ALL | AM.AM_HALO_DW_ALWAYS)),   # direct-weights strip kernel (192 x 256 tiles) wherever it fits
+    ("halo_dw_auto", dict(BASE, auto_mask=AM.AM_HALO_ALL | AM.AM_HALO_TILE256 | AM.AM_HALO_DW)),   # ... where the launcher's model says it pays
     ("wres_1x1", dict(BASE, auto_mask=AM.AM_WRES_ALWAYS)),           # weights-resident persistent 1x1 kernel wherever it is supported
 ]
 
@@ -130,20 +132,26 @@ def main():
         flops = 2.0 * kk * cout * ho * ho * B
         nbytes = (x.numel() + (r.numel() if res else 0)) * es + outs[0].numel() * outs[0].element_size() + kk * cout * es
         best = [1e9] * len(VARIANTS)
+        kernel_of = [""] * len(VARIANTS)
         stream = _hip.stream_ptr()
         for rnd in range(args.rounds):
             for vi, (vname, knobs) in enumerate(VARIANTS):
                 for key, val in knobs.items():
                     _hip.check(lib.y3_set_tuning(key.encode(), val))
                 op.d_out = outs[vi].data_ptr()
+                # a one-op plan: the product path (a plan makes its kernel's private weight layout once, at creation)
+                handle = ctypes.c_void_p()
+                _hip.check(lib.y3_plan_create((_hip.Y3Op * 1)(op), 1, zero.data_ptr(), ctypes.byref(handle)))
+                kernel_of[vi] = lib.y3_plan_op_kernel(handle, 0).decode()
                 for _ in range(2):
-                    _hip.check(lib.y3_op_run(ctypes.byref(op), None, zero.data_ptr(), stream))
+                    _hip.check(lib.y3_plan_run(handle, None, stream))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.iters):
-                    _hip.check(lib.y3_op_run(ctypes.byref(op), None, zero.data_ptr(), stream))
+                    _hip.check(lib.y3_plan_run(handle, None, stream))
                 e1.record()
                 torch.cuda.synchronize()
+                lib.y3_plan_destroy(handle)
                 best[vi] = min(best[vi], e0.elapsed_time(e1) / args.iters)
                 if args.stamps and rnd == args.rounds - 1:
                     import ctypes as C
@@ -160,8 +168,9 @@ def main():
         for vi, (vname, _) in enumerate(VARIANTS):
             diff = float((outs[vi].float() - ref).abs().max())
             tf = flops / best[vi] / 1e9
-            row[vname] = dict(ms=best[vi], tflops=tf, gbps=nbytes / best[vi] / 1e6, maxdiff_vs_v0=diff)
-            line += " %s %.4f ms %6.1f TF %6.0f GB/s d=%.1e |" % (vname, best[vi], tf, nbytes / best[vi] / 1e6, diff)
+            row[vname] = dict(ms=best[vi], tflops=tf, gbps=nbytes / best[vi] / 1e6, maxdiff_vs_v0=diff, kernel=kernel_of[vi])
+            line += " %s [%s] %.4f ms %6.1f TF %6.0f GB/s d=%.1e |" % (vname, kernel_of[vi].replace("conv_", ""), best[vi], tf,
+                                                                    nbytes / best[vi] / 1e6, diff)
         print(line, flush=True)
         results.append(row)
     if args.out:
