@@ -1024,7 +1024,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
   // wf[(S + 2) % 3]; the next step's K-half 0 is loaded into wf[(S + 1) % 3] at the top, its K-half 1 into wf[S] once this
   // step's K-half 0 MFMAs are issued.  VMEM order per step: 4 loads, at most 1 halo piece, 4 loads -- the counted waits rely on it.
   // Pixel fragments: eight registers sets of one fragment; a half (four fragments) is re-read for the next K-half as soon as
-  // the sixteen MFMAs that use it are issued, so every read has sixteen MFMAs (256+ cycles) to land.
+  // the MFMAs that use it are issued.  (A second register set with every read a whole K-half ahead measured 2 % slower: the
+  // SIMD's other wave covers the read latency already, r05s.)
   auto kstep = [&](auto tapc, int chunk) {
     constexpr int tap = decltype(tapc)::value, S = tap % 3, tap_n = tap == 8 ? 0 : tap + 1;
     const int chunk_n = tap == 8 ? chunk + 1 : chunk;

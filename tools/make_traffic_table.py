@@ -36,6 +36,9 @@ def plan_name(kernel):
     m = re.search(r"conv_halo_ws_kernelI" + _T + r"Li\d+ELi(\d+)E", k)
     if m:
         return "conv_halo_ws_%s_%dx128" % (DT[m.group(1)], 64 * int(m.group(2)))
+    m = re.search(r"conv_halo_dw_kernelI" + _T, k) or re.match(r"conv_halo_dw_kernel<(__bf16|_Float16)", k)
+    if m:
+        return "conv_halo_dw_%s_192x256" % DT[m.group(1)]
     m = re.search(r"conv_igemm2_kernelI" + _T + r"Li64ELi256ELi1ELi4ELi0ELb1E", k)
     if m:
         return "conv_head_decode_%s_64x256" % DT[m.group(1)]
