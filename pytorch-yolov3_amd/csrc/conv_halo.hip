@@ -898,7 +898,7 @@ __device__ __forceinline__ void dw_wait_vm(V (&w)[4]) {
 
 template <typename T, int NA>
 __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
-  static_assert(sizeof(T) == 2 && NA >= 4 && NA <= 6, "16-bit storage modes only; 4 .. 6 halo passes per chunk");
+  static_assert(sizeof(T) == 2 && NA >= 4 && NA <= 5, "16-bit storage modes only; 4 or 5 halo passes per chunk");
   constexpr int MI = 6, NI = 4;                       // wave tile: 6 x 16 pixels, 4 x 16 channels (8 x 16 pixels needs 256+ VGPRs: spills)
   constexpr int WM = MI * 16, MH = MI / 2;
   constexpr int BM = 2 * WM, BN = 256;
@@ -1033,8 +1033,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
     load_w0(wf[(S + 1) % 3], voff_n);
     // one 64-row pass of the next chunk's halo per step while there are any (4-6 of the 9 steps; a piece costs the issuing
     // wave 60-185 cycles: without them the launch is 10-15 % shorter, so none is issued that is not needed)
-    // (NA = the number of passes, a template parameter: 4 .. 6 covers every map the wave-specialised kernel takes, rows of up
-    // to 94 pixels; as a run-time test the branch costs registers the kernel does not have -- 96 bytes of scratch, 15 % slower)
+    // (NA = the number of passes, a template parameter: 4 or 5 = rows of up to 62 pixels; as a run-time test the branch costs
+    // registers the kernel does not have -- 96 bytes of scratch, 15 % slower.  NOT 6 (rows of 63 .. 94 pixels, Darknet's 76^2
+    // maps): with six passes the halo buffers fill the 96 KiB exactly and the sixth in-loop piece -- LDS bytes 90112 .. 98303
+    // -- ends the process with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION as soon as another kernel (the upload's copy
+    // kernel) runs beside this one; alone, and in every parity test, that instantiation computed the right bits.  Not
+    // understood (a larger LDS request does not help, the same piece issued a step later faults too, skipping it does not):
+    // profiles/r05s_halo_dw.txt.  The launcher's model never picked those maps anyway (two channel chunks per tile).)
     if constexpr (tap < NA) issue_halo_pass(chunk + 1, tap, chunk + 1 < p.nchunks);
     // younger than wf[S]'s loads: 4 loads of the previous step + 4 of this one for certain, up to two halo pieces maybe --
     // the count that is always safe is 8
@@ -1074,17 +1079,37 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
   }
   __builtin_amdgcn_s_setprio(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead loads of the step after the last, the last halo pieces
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_s_barrier();                       // nobody reads the halo any more: LDS holds the output tile
 
-  // ---- epilogue: two channel halves of 128; the four waves that own a half park it, all 512 threads write it out ----
+  // ---- epilogue: two channel halves of 128; the four waves that own a half park it, all 512 threads write it out.  A half's
+  // scale / bias / shortcut reads are issued one stage ahead: the first half's before the barrier that ends the K loop, the
+  // second half's before the first half's write-out (all at once, before the loop's end, they cost 48 registers: spills) ----
   constexpr int SWZ = 15;
   constexpr int RPP = NT / 16;                        // 32 pixel rows per pass
-  constexpr int WR = BM / RPP;                        // 8
+  constexpr int WR = BM / RPP;                        // 6
   float *sC = reinterpret_cast<float *>(smem);
   const bool leaky = p.flags & Y3_F_LEAKY;
   const bool has_res = p.flags & Y3_F_RESIDUAL;
   const int oc_mine = tid & 15;
+  f32x4 sc_lo[2], sc_hi[2], bi_lo[2], bi_hi[2];
+  u32x4 resv[2][WR];
+  auto epi_loads = [&](int h) {
+    const int co = n0 + h * 128 + oc_mine * 8;
+    sc_lo[h] = *reinterpret_cast<const f32x4 *>(p.scale + co);
+    sc_hi[h] = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+    bi_lo[h] = *reinterpret_cast<const f32x4 *>(p.bias + co);
+    bi_hi[h] = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+    if (has_res) {
+#pragma unroll
+      for (int j = 0; j < WR; ++j) {
+        const int m = m0 + (tid >> 4) + j * RPP;
+        const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
+        resv[h][j] = m < p.M ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  epi_loads(0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();                       // nobody reads the halo any more: LDS holds the output tile
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if ((wn >> 1) == h) {
@@ -1098,22 +1123,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
         }
       }
     }
-    // (both halves' scale / bias / shortcut reads issued up front, under the first half's write-out, need 48 more registers
-    // than the kernel has: 96 bytes of scratch and a K loop that drains vmcnt for every reload -- measured 15 % slower)
+    if (h == 0) epi_loads(1);
     const int co = n0 + h * 128 + oc_mine * 8;
-    const f32x4 sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co);
-    const f32x4 sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
-    const f32x4 bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co);
-    const f32x4 bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
-    u32x4 resv[WR];
-    if (has_res) {
-#pragma unroll
-      for (int j = 0; j < WR; ++j) {
-        const int m = m0 + (tid >> 4) + j * RPP;
-        const char *rp = p.res + ((long long)m * p.res_ld + co) * ES;
-        resv[j] = m < p.M ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
-      }
-    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < WR; ++j) {
@@ -1123,8 +1134,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
       const f32x4 lo = *reinterpret_cast<const f32x4 *>(sC + pl * 128 + (((2 * oc_mine) ^ (pl & SWZ)) << 2));
       const f32x4 hi = *reinterpret_cast<const f32x4 *>(sC + pl * 128 + (((2 * oc_mine + 1) ^ (pl & SWZ)) << 2));
       float v[8];
-      y3_bn_leaky8(v, lo, hi, sc_lo, sc_hi, bi_lo, bi_hi, leaky);
-      if (has_res) y3_add8<T>(v, resv[j]);
+      y3_bn_leaky8(v, lo, hi, sc_lo[h], sc_hi[h], bi_lo[h], bi_hi[h], leaky);
+      if (has_res) y3_add8<T>(v, resv[h][j]);
       T *op = reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co;
       *reinterpret_cast<u32x4 *>(op) = y3_pack8<T>(v);
     }
@@ -1255,8 +1266,6 @@ int launch_halo_dw(const HaloArgs &a0, hipStream_t s) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_dw_kernel<T, 5>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_dw_kernel<T, 6>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       return Y3_OK;
     }, &n_cu);
     if (rc != Y3_OK) return rc;
@@ -1267,7 +1276,7 @@ int launch_halo_dw(const HaloArgs &a0, hipStream_t s) {
   a.a_bytes = a.hr_pad * 128;
   size_t lds = (size_t)2 * a.a_bytes;
   if (lds < (size_t)DW_BM * 128 * 4) lds = (size_t)DW_BM * 128 * 4;
-  Y3_REQUIRE(a.na >= 4 && a.na <= 6 && lds <= 160 * 1024, "direct-weights halo kernel: row width %d does not fit", a.W);
+  Y3_REQUIRE(a.na >= 4 && a.na <= 5 && lds <= 160 * 1024, "direct-weights halo kernel: row width %d does not fit", a.W);
   a.m_tiles = y3_ceil_div(a.M, DW_BM);
   a.n_tiles = a.Cout / 256;
   {
@@ -1283,10 +1292,9 @@ int launch_halo_dw(const HaloArgs &a0, hipStream_t s) {
     a.ngrp_w = a.n_tiles / best;
   }
   const dim3 grid(a.m_tiles * a.n_tiles);
-  // halo passes per chunk: 4 (rows of up to 30 pixels), 5 (up to 62), 6 (up to 94)
-  if (a.na <= 4) hipLaunchKernelGGL((conv_halo_dw_kernel<T, 4>), grid, dim3(512), lds, s, a);
-  else if (a.na == 5) hipLaunchKernelGGL((conv_halo_dw_kernel<T, 5>), grid, dim3(512), lds, s, a);
-  else hipLaunchKernelGGL((conv_halo_dw_kernel<T, 6>), grid, dim3(512), lds, s, a);
+  // halo passes per chunk: 4 (rows of up to 30 pixels) or 5 (up to 62)
+  if (a.na == 4) hipLaunchKernelGGL((conv_halo_dw_kernel<T, 4>), grid, dim3(512), lds, s, a);
+  else hipLaunchKernelGGL((conv_halo_dw_kernel<T, 5>), grid, dim3(512), lds, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -1340,12 +1348,12 @@ bool y3_conv_halo_ws_fits(const y3_op &op) {
   return na <= 14 && (size_t)3 * 128 * 128 + (size_t)2 * na * 32 * 128 <= 160 * 1024;
 }
 
-// direct-weights strip kernel (round 5): 16-bit modes, Cout a multiple of 256, rows of up to 94 pixels (four to six 64-row halo
-// passes per chunk; the same maps the wave-specialised kernel takes)
+// direct-weights strip kernel (round 5): 16-bit modes, Cout a multiple of 256, rows of up to 62 pixels (four or five 64-row halo
+// passes per chunk; see the kernel for why not six)
 bool y3_conv_halo_dw_fits(const y3_op &op) {
   if (!y3_conv_halo_eligible(op) || !y3_is16(op.dtype) || op.out_c % 256 != 0 || op.cout_pad % 16 != 0 || op.k_ld % 32 != 0) return false;
   const int na = y3_ceil_div(DW_BM + 2 * op.in_w + 4, 64);
-  return na >= 4 && na <= 6 && y3_conv_halo_ws_fits(op);
+  return na >= 4 && na <= 5 && y3_conv_halo_ws_fits(op);
 }
 
 // Where it is the better kernel.  Per workgroup the two strip kernels do the same work per cycle (PMC, profiles/r05s: 64 % of

@@ -553,7 +553,7 @@ def test_kernel_choice_does_not_change_a_bit(dtype):
         net = _net("yolov3", dtype=dtype, options=opts)
         outs.append({k: v.clone() for k, v in net.forward_frames(frames).items()})
         if opts and opts.get("auto_mask", 0) & _hip.AM_HALO_DW_ALWAYS and dtype != "float32":
-            assert sum("conv_halo_dw" in r["kernel"] for r in net.plan_report()) >= 25, [r["kernel"] for r in net.plan_report()]
+            assert sum("conv_halo_dw" in r["kernel"] for r in net.plan_report()) >= 18, [r["kernel"] for r in net.plan_report()]
     for o in outs[1:]:
         for k in ("bbox_xywh", "class_prob", "class_idx"):
             assert torch.equal(o[k], outs[0][k]), k
@@ -581,11 +581,60 @@ def test_direct_weights_kernel_is_chosen_at_batch16_and_changes_no_bit(model, dt
     halo = _hip.AM_HALO_ALL | _hip.AM_NO_SMALL_GRID
     c = _net(model, dtype=dtype, options={"auto_mask": halo | _hip.AM_HALO_DW_ALWAYS})
     oc = {k: v.clone() for k, v in c.forward_frames(small).items()}
-    assert sum("conv_halo_dw" in r["kernel"] for r in c.plan_report()) >= 20
+    assert sum("conv_halo_dw" in r["kernel"] for r in c.plan_report()) >= 20   # 352 x 480: maps 44 x 60, 22 x 30, 11 x 15 -- all within 62 pixels
     d = _net(model, dtype=dtype, options={"auto_mask": halo})
     od = d.forward_frames(small)
     for k in ("bbox_xywh", "class_prob", "class_idx"):
         assert torch.equal(oc[k], od[k]), k
+
+
+@pytest.mark.parametrize("h,cin,cout", [(38, 256, 512), (19, 512, 1024), (62, 128, 256)])
+def test_direct_weights_kernel_beside_a_copy_kernel(h, cin, cout):
+    """Regression guard (round 5): the six-pass instantiation of the direct-weights kernel (rows of 63 .. 94 pixels; removed)
+    computed the right bits alone and ended the process with a memory-aperture violation as soon as the upload's copy kernel ran
+    on another stream.  The two instantiations that ship, at their widest maps, back to back beside that copy kernel: same bits
+    as alone, every time."""
+    import ctypes
+    from yolov3 import _hip
+    lib = _hip.lib()
+    dev = torch.device("cuda:0")
+    B = 16
+    g = torch.Generator().manual_seed(h)
+    zero = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    x = (torch.rand((B, h, h, cin), generator=g) - 0.5).to(torch.bfloat16).to(dev)
+    k_ld = 9 * cin
+    w = ((torch.rand((cout, k_ld), generator=g) - 0.5) * 0.05).to(torch.bfloat16).to(dev)
+    sc, bi = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+    out = torch.zeros((B, h, h, cout), dtype=torch.bfloat16, device=dev)
+    op = _hip.Y3Op()
+    op.kind, op.dtype, op.flags = _hip.OP_CONV, _hip.Y3_BF16, _hip.F_LEAKY
+    op.batch, op.in_h, op.in_w, op.in_c, op.in_ld = B, h, h, cin, cin
+    op.out_h, op.out_w, op.out_c, op.out_ld, op.res_ld = h, h, cout, cout, cout
+    op.ksize, op.stride, op.pad, op.k_ld, op.cout_pad = 3, 1, 1, k_ld, cout
+    op.d_in, op.d_out = x.data_ptr(), out.data_ptr()
+    op.d_weight, op.d_scale, op.d_bias = w.data_ptr(), sc.data_ptr(), bi.data_ptr()
+    opts = _hip.options()
+    opts.auto_mask = _hip.AM_HALO_ALL | _hip.AM_HALO_DW_ALWAYS | _hip.AM_NO_SMALL_GRID
+    handle = ctypes.c_void_p()
+    _hip.check(lib.y3_plan_create_ex((_hip.Y3Op * 1)(op), 1, zero.data_ptr(), ctypes.byref(opts), ctypes.byref(handle)))
+    try:
+        assert lib.y3_plan_op_kernel(handle, 0).decode().startswith("conv_halo_dw_")
+        _hip.check(lib.y3_plan_run(handle, None, None))
+        torch.cuda.synchronize()
+        alone = out.clone()
+        host = torch.zeros(16 * 608 * 608 * 3, dtype=torch.uint8).pin_memory()
+        dst = torch.zeros(16 * 608 * 608 * 3, dtype=torch.uint8, device=dev)
+        cs, st = torch.cuda.Stream(), torch.cuda.Stream()
+        for i in range(20):
+            _hip.check(lib.y3_copy_bytes(host.data_ptr(), dst.data_ptr(), host.numel(), 8, _hip.stream_ptr(cs)))
+            for j in range(6):
+                _hip.check(lib.y3_plan_run(handle, None, _hip.stream_ptr(st)))
+            if i % 5 == 4:
+                torch.cuda.synchronize()
+                assert torch.equal(out, alone), i
+        torch.cuda.synchronize()
+    finally:
+        lib.y3_plan_destroy(handle)
 
 
 @pytest.mark.parametrize("dtype", ["float32"])
