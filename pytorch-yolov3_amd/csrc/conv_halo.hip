@@ -898,7 +898,7 @@ __device__ __forceinline__ void dw_wait_vm(V (&w)[4]) {
 
 template <typename T, int NA>
 __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
-  static_assert(sizeof(T) == 2 && NA >= 4 && NA <= 5, "16-bit storage modes only; 4 or 5 halo passes per chunk");
+  static_assert(sizeof(T) == 2 && NA >= 4 && NA <= 6, "16-bit storage modes only; 4 .. 6 halo passes per chunk");
   constexpr int MI = 6, NI = 4;                       // wave tile: 6 x 16 pixels, 4 x 16 channels (8 x 16 pixels needs 256+ VGPRs: spills)
   constexpr int WM = MI * 16, MH = MI / 2;
   constexpr int BM = 2 * WM, BN = 256;
@@ -1033,13 +1033,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
     load_w0(wf[(S + 1) % 3], voff_n);
     // one 64-row pass of the next chunk's halo per step while there are any (4-6 of the 9 steps; a piece costs the issuing
     // wave 60-185 cycles: without them the launch is 10-15 % shorter, so none is issued that is not needed)
-    // (NA = the number of passes, a template parameter: 4 or 5 = rows of up to 62 pixels; as a run-time test the branch costs
-    // registers the kernel does not have -- 96 bytes of scratch, 15 % slower.  NOT 6 (rows of 63 .. 94 pixels, Darknet's 76^2
-    // maps): with six passes the halo buffers fill the 96 KiB exactly and the sixth in-loop piece -- LDS bytes 90112 .. 98303
-    // -- ends the process with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION as soon as another kernel (the upload's copy
-    // kernel) runs beside this one; alone, and in every parity test, that instantiation computed the right bits.  Not
-    // understood (a larger LDS request does not help, the same piece issued a step later faults too, skipping it does not):
-    // profiles/r05s_halo_dw.txt.  The launcher's model never picked those maps anyway (two channel chunks per tile).)
+    // (NA = the number of passes, a template parameter: 4 .. 6 covers every map the wave-specialised kernel takes, rows of up
+    // to 94 pixels; as a run-time test the branch costs registers the kernel does not have -- 96 bytes of scratch, 15 % slower)
     if constexpr (tap < NA) issue_halo_pass(chunk + 1, tap, chunk + 1 < p.nchunks);
     // younger than wf[S]'s loads: 4 loads of the previous step + 4 of this one for certain, up to two halo pieces maybe --
     // the count that is always safe is 8
@@ -1078,7 +1073,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
     kstep(TapC<6>{}, chunk); kstep(TapC<7>{}, chunk); kstep(TapC<8>{}, chunk);
   }
   __builtin_amdgcn_s_setprio(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the run-ahead loads of the step after the last, the last halo pieces
+  // The run-ahead loads of the step after the last are still in flight and nobody uses their data: without the register ties
+  // below the compiler considers their destination registers free from here on and may place the epilogue's pointer arithmetic
+  // in them BEFORE the wait -- a load that lands late (memory contention: another kernel beside this one) then overwrites an
+  // address, and the epilogue reads from nowhere (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION; profiles/r05s_halo_dw.txt).
+  dw_wait_vm<0>(wf[0]);
+  dw_wait_vm<0>(wf[1]);
+  dw_wait_vm<0>(wf[2]);
 
   // ---- epilogue: two channel halves of 128; the four waves that own a half park it, all 512 threads write it out.  A half's
   // scale / bias / shortcut reads are issued one stage ahead: the first half's before the barrier that ends the K loop, the
@@ -1266,6 +1267,8 @@ int launch_halo_dw(const HaloArgs &a0, hipStream_t s) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_dw_kernel<T, 5>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_halo_dw_kernel<T, 6>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       return Y3_OK;
     }, &n_cu);
     if (rc != Y3_OK) return rc;
@@ -1276,7 +1279,7 @@ int launch_halo_dw(const HaloArgs &a0, hipStream_t s) {
   a.a_bytes = a.hr_pad * 128;
   size_t lds = (size_t)2 * a.a_bytes;
   if (lds < (size_t)DW_BM * 128 * 4) lds = (size_t)DW_BM * 128 * 4;
-  Y3_REQUIRE(a.na >= 4 && a.na <= 5 && lds <= 160 * 1024, "direct-weights halo kernel: row width %d does not fit", a.W);
+  Y3_REQUIRE(a.na >= 4 && a.na <= 6 && lds <= 160 * 1024, "direct-weights halo kernel: row width %d does not fit", a.W);
   a.m_tiles = y3_ceil_div(a.M, DW_BM);
   a.n_tiles = a.Cout / 256;
   {
@@ -1292,9 +1295,10 @@ int launch_halo_dw(const HaloArgs &a0, hipStream_t s) {
     a.ngrp_w = a.n_tiles / best;
   }
   const dim3 grid(a.m_tiles * a.n_tiles);
-  // halo passes per chunk: 4 (rows of up to 30 pixels) or 5 (up to 62)
+  // halo passes per chunk: 4 (rows of up to 30 pixels), 5 (up to 62), 6 (up to 94)
   if (a.na == 4) hipLaunchKernelGGL((conv_halo_dw_kernel<T, 4>), grid, dim3(512), lds, s, a);
-  else hipLaunchKernelGGL((conv_halo_dw_kernel<T, 5>), grid, dim3(512), lds, s, a);
+  else if (a.na == 5) hipLaunchKernelGGL((conv_halo_dw_kernel<T, 5>), grid, dim3(512), lds, s, a);
+  else hipLaunchKernelGGL((conv_halo_dw_kernel<T, 6>), grid, dim3(512), lds, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -1348,12 +1352,12 @@ bool y3_conv_halo_ws_fits(const y3_op &op) {
   return na <= 14 && (size_t)3 * 128 * 128 + (size_t)2 * na * 32 * 128 <= 160 * 1024;
 }
 
-// direct-weights strip kernel (round 5): 16-bit modes, Cout a multiple of 256, rows of up to 62 pixels (four or five 64-row halo
-// passes per chunk; see the kernel for why not six)
+// direct-weights strip kernel (round 5): 16-bit modes, Cout a multiple of 256, rows of up to 94 pixels (four to six 64-row halo
+// passes per chunk: the maps the wave-specialised kernel takes)
 bool y3_conv_halo_dw_fits(const y3_op &op) {
   if (!y3_conv_halo_eligible(op) || !y3_is16(op.dtype) || op.out_c % 256 != 0 || op.cout_pad % 16 != 0 || op.k_ld % 32 != 0) return false;
   const int na = y3_ceil_div(DW_BM + 2 * op.in_w + 4, 64);
-  return na >= 4 && na <= 5 && y3_conv_halo_ws_fits(op);
+  return na >= 4 && na <= 6 && y3_conv_halo_ws_fits(op);
 }
 
 // Where it is the better kernel.  Per workgroup the two strip kernels do the same work per cycle (PMC, profiles/r05s: 64 % of

@@ -553,7 +553,7 @@ def test_kernel_choice_does_not_change_a_bit(dtype):
         net = _net("yolov3", dtype=dtype, options=opts)
         outs.append({k: v.clone() for k, v in net.forward_frames(frames).items()})
         if opts and opts.get("auto_mask", 0) & _hip.AM_HALO_DW_ALWAYS and dtype != "float32":
-            assert sum("conv_halo_dw" in r["kernel"] for r in net.plan_report()) >= 18, [r["kernel"] for r in net.plan_report()]
+            assert sum("conv_halo_dw" in r["kernel"] for r in net.plan_report()) >= 25, [r["kernel"] for r in net.plan_report()]
     for o in outs[1:]:
         for k in ("bbox_xywh", "class_prob", "class_idx"):
             assert torch.equal(o[k], outs[0][k]), k
@@ -588,12 +588,14 @@ def test_direct_weights_kernel_is_chosen_at_batch16_and_changes_no_bit(model, dt
         assert torch.equal(oc[k], od[k]), k
 
 
-@pytest.mark.parametrize("h,cin,cout", [(38, 256, 512), (19, 512, 1024), (62, 128, 256)])
+@pytest.mark.parametrize("h,cin,cout", [(38, 256, 512), (19, 512, 1024), (62, 128, 256), (76, 128, 256), (94, 256, 256)])
 def test_direct_weights_kernel_beside_a_copy_kernel(h, cin, cout):
-    """Regression guard (round 5): the six-pass instantiation of the direct-weights kernel (rows of 63 .. 94 pixels; removed)
-    computed the right bits alone and ended the process with a memory-aperture violation as soon as the upload's copy kernel ran
-    on another stream.  The two instantiations that ship, at their widest maps, back to back beside that copy kernel: same bits
-    as alone, every time."""
+    """Regression (round 5): the direct-weights kernel loads its weights with inline-asm global loads, one K-step ahead.  The
+    loads of the step AFTER the last one are still in flight at the end of the K loop and nobody reads their data, so the
+    compiler took their destination registers for the epilogue's pointer arithmetic; alone the loads always landed first, beside
+    the upload's copy kernel (memory contention) some landed late, overwrote an address, and the process ended with
+    HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION (first seen on the six-pass instantiation: 76^2 maps).  The final wait now keeps
+    those registers allocated.  Every instantiation at its widest map, back to back beside that copy kernel: same bits as alone."""
     import ctypes
     from yolov3 import _hip
     lib = _hip.lib()
