@@ -880,17 +880,20 @@ __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Direct-weights strip kernel (round 5 experiment; 16-bit storage modes): a workgroup owns 256 raster pixels x 256 output
-// channels.  Eight waves, two per SIMD, no roles: each computes 128 pixels x 64 channels (128 accumulator registers),
-// reads its pixel fragments from the halo image in LDS exactly like conv_halo_ws_kernel (tap = row offset, border taps
-// redirected to the zero row) and takes its WEIGHT fragments straight from global memory into registers: a lane's eight
-// K-elements of one channel row are 16 contiguous bytes of the [Cout][K] weight matrix, so one global_load_dwordx4 per
-// fragment delivers the MFMA operand layout as it is.  No weight ring, no per-step barrier (one barrier per channel chunk,
-// when the halo buffers swap), half the LDS fragment reads per MFMA of the 64 x 64 wave tile, and the halo is staged once
-// for 256 channels instead of once per 128.  Per K-step (64 channels of one tap) a wave issues 64 MFMAs, 16 ds_read_b128,
-// 8 global_load_dwordx4 (one K-step ahead, three register sets of four fragments in rotation) and ONE 1-KiB LDS-DMA piece
-// of the next chunk's halo.  Same K order (chunk outermost, tap innermost, K-halves in order) as every other MFMA conv
-// kernel here: same bits.
+// Direct-weights strip kernel (round 5; 16-bit storage modes): a workgroup owns 192 raster pixels x 256 output channels.
+// Eight waves, two per SIMD, no roles: each computes 96 pixels x 64 channels (96 accumulator registers), reads its pixel
+// fragments from the halo image in LDS exactly like conv_halo_ws_kernel (tap = row offset, border taps redirected to the
+// zero row) and takes its WEIGHT fragments straight from global memory into registers, out of a FRAGMENT-ORDER copy of the
+// weights (the plan makes it once: 1-KiB blocks of 16 channels x 32 K-elements in the MFMA operand layout, so that one
+// coalesced global_load_dwordx4 per fragment delivers the operand as it is).  No weight ring, no per-step barrier (one
+// barrier per channel chunk, when the halo buffers swap), half the LDS fragment reads per MFMA of the 64 x 64 wave tile,
+// and the halo is staged once for 256 channels instead of once per 128.  Per K-step (64 channels of one tap) a wave issues
+// 48 MFMAs, 12 ds_read_b128, 8 global_load_dwordx4 (one K-step ahead, three register sets of four fragments in rotation)
+// and at most one 1-KiB LDS-DMA piece of the next chunk's halo.  Same K order (chunk outermost, tap innermost, K-halves
+// in order) as every other MFMA conv kernel here: same bits.  Development, measurements and the one hard bug
+// (inline-asm loads the compiler cannot see in flight): profiles/r05s_halo_dw.txt.
+// dw_wait_vm: s_waitcnt vmcnt(N) that NAMES the four registers it waits for -- the tie is what keeps the compiler from
+// moving their uses above the wait, and from re-using them while the load is in flight.
 template <int N, typename V>
 __device__ __forceinline__ void dw_wait_vm(V (&w)[4]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N) : "memory");
