@@ -588,6 +588,25 @@ def test_direct_weights_kernel_is_chosen_at_batch16_and_changes_no_bit(model, dt
         assert torch.equal(oc[k], od[k]), k
 
 
+def test_new_parameters_replace_the_plans_private_weight_copies():
+    """The direct-weights kernel reads a fragment-order COPY of a layer's weights that the plan made when it was compiled.
+    ``set_params`` on a network that has already run must not leave a plan with the old copy: the outputs equal those of a
+    fresh network built with the new parameters."""
+    frames = synth_frames(47, 16, 608, 608)
+    net = _net("yolov3", dtype="bf16")
+    first = {k: v.clone() for k, v in net.forward_frames(frames).items()}
+    assert any("conv_halo_dw" in r["kernel"] for r in net.plan_report())
+    other = W.synth_params(net.blocks, net.net_info, seed=3, obj_bias=-5.0, calib=W.load_calibration("yolov3"))
+    net.set_params(other)
+    second = net.forward_frames(frames)
+    fresh = yolov3.Darknet(MODELS["yolov3"], device="cuda", dtype="bf16").eval()
+    fresh.set_params(other)
+    want = fresh.forward_frames(frames)
+    assert not torch.equal(second["class_prob"], first["class_prob"])
+    for k in ("bbox_xywh", "class_prob", "class_idx"):
+        assert torch.equal(second[k], want[k]), k
+
+
 @pytest.mark.parametrize("h,cin,cout", [(38, 256, 512), (19, 512, 1024), (62, 128, 256), (76, 128, 256), (94, 256, 256)])
 def test_direct_weights_kernel_beside_a_copy_kernel(h, cin, cout):
     """Regression (round 5): the direct-weights kernel loads its weights with inline-asm global loads, one K-step ahead.  The
