@@ -51,7 +51,7 @@ import torch  # noqa: E402
 HEAVY_OBJ_BIAS = -6.9          # objectness bias of the procedural weights that leaves ~4000 candidates / frame at threshold 0.05
 PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "float32": 157.3}   # /opt/skills/guides/MI355X_MICROARCH.md (dense MFMA; F16 = BF16 rate)
 MODEL_FLOPS_PER_FRAME = {("yolov3", 608): 140.692e9, ("yolov3-tiny", 416): 5.565e9, ("yolov3-spp", 608): 141.449e9}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_traffic.json")
 
 
 def parse_args(argv=None):
@@ -74,7 +74,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true",
                     help="skip pcie_inclusive / other_configs / bf16_agreement (A/B runs, profiling)")
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU-baseline work (bounded sample)")
-    ap.add_argument("--profile-passes", type=int, default=3)
+    ap.add_argument("--profile-passes", type=int, default=24,
+                    help="serial passes of the per-kernel report (median per op), right after --sustain seconds of the timed loop")
+    ap.add_argument("--sustain", type=float, default=2.0, help="seconds of sustained load before the per-kernel passes")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency / video-loop section")
     ap.add_argument("--dump-ops", default=None, help="write the per-op timing table (text) to this file")
     ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: step i runs on HIP stream i %% streams with its own arena, so "
@@ -268,6 +271,72 @@ def bind_rank_to_gpu_node(local_rank):
             pass
     info["cpus"] = len(os.sched_getaffinity(0))
     return info
+
+
+class GpuTelemetry(object):
+    """Shader clock and socket power of ONE GPU, sampled from a side thread while a measurement runs: plain reads of the amdgpu
+    hwmon files of the PCI device (``freq1_input`` = sclk in Hz, ``power1_input`` = PPT in microwatts; found with
+    tools/smi_probe.py) -- no other program is started, nothing is re-executed.  The MI355X holds ~2.0-2.15 GHz under this
+    load at its 1.4 kW cap, not the 2.4 GHz the 2.5 PFLOP/s peak is quoted at (profiles/r05i_power_bf16_vs_fp16.txt), and how
+    far it sags differs by box and by what ran in the seconds before: a roofline fraction without the clock it was measured
+    at cannot be compared between runs."""
+
+    def __init__(self, bdf, interval=0.01):
+        import glob
+        self.interval = interval
+        self.freq = self.power = None
+        for hw in sorted(glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf)) if bdf else []:
+            if os.path.exists(os.path.join(hw, "freq1_input")):
+                self.freq = os.path.join(hw, "freq1_input")
+            for name in ("power1_input", "power1_average"):
+                if self.power is None and os.path.exists(os.path.join(hw, name)):
+                    self.power = os.path.join(hw, name)
+        self.samples = []
+        self._stop = None
+        self._thread = None
+
+    @property
+    def available(self):
+        return self.freq is not None
+
+    def _read(self):
+        try:
+            f = int(_read(self.freq)) / 1e6 if self.freq else None
+            w = int(_read(self.power)) / 1e6 if self.power else None
+            return f, w
+        except (TypeError, ValueError):
+            return None, None
+
+    def __enter__(self):
+        import threading
+        self.samples = []
+        if not self.available:
+            return self
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append(self._read())
+                self._stop.wait(self.interval)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+            self._thread = None
+        return False
+
+    def summary(self):
+        """{"sclk_mhz": median, "sclk_mhz_min" / "_max", "power_w": median, "samples": n} of the last ``with`` block."""
+        f = [a for a, _ in self.samples if a]
+        w = [b for _, b in self.samples if b]
+        if not f:
+            return {"sclk_mhz": None, "power_w": None, "samples": 0}
+        return {"sclk_mhz": round(float(np.median(f)), 1), "sclk_mhz_min": round(min(f), 1), "sclk_mhz_max": round(max(f), 1),
+                "power_w": round(float(np.median(w)), 1) if w else None, "samples": len(f)}
 
 
 def cpu_model():
@@ -549,20 +618,42 @@ class Workload(object):
         out = self.net.forward_frames(self.frames, fresh=False)
         return int((out["class_prob"] >= self.prob_thresh).sum().item()) // self.batch
 
-    def kernel_report(self, passes, dump_ops=None):
-        """Per-kernel device time with HIP events around every launch, serial passes on the launch stream (inside the
-        timed region several batches overlap and a launch's duration would include its neighbours')."""
+    def kernel_report(self, passes, dump_ops=None, telemetry=None, sustain_steps=0):
+        """Per-kernel device time, serial passes on the launch stream (inside the timed region several batches overlap and a
+        launch's duration would include its neighbours').
+
+        Protocol: ``sustain_steps`` steps of the timed loop itself first (>= 2 s: the chip is at the
+        clock it HOLDS under this load, not at the boost clock of a cold start), then at once ``passes`` serial passes
+        back to back; per op the MEDIAN over the passes counts (the minimum is carried alongside), and ``telemetry``
+        samples sclk / power during the passes.  Two timings per pass type:
+          kernel   y3_plan_run_profiled: a start / stop event pair bound to every DISPATCH (hipExtLaunchKernel) -- the
+                   kernel's own begin -> end on the device, the figure rocprofv3's kernel trace reports;
+          bracket  y3_plan_run_timed: an event recorded on the stream before and after every launch (rounds 1-5) -- that
+                   interval also holds the dispatch and the two barrier packets, ~5 us per launch (the whole 52.5 us by
+                   rocprofv3 against 57.6-60.6 us by events of round 5: profiles/r06_timing_methods.txt)."""
         net = self.net
-        per_op = None
-        for _ in range(passes):
-            net._run(self.frames, "u8", timed=True, fresh=False, options=self.options)   # the plan the timed steps ran
-            ms = np.array(net.last_op_ms)
-            per_op = ms if per_op is None else np.minimum(per_op, ms)
+        for i in range(sustain_steps):
+            self.step(i, resident=True)
+        torch.cuda.synchronize()
+        kern, brack = [], []
+        tel = telemetry if telemetry is not None else GpuTelemetry(None)
+        with tel:
+            for k in range(passes):
+                net._run(self.frames, "u8", timed="kernel", fresh=False, options=self.options)   # the plan the timed steps ran
+                kern.append(np.array(net.last_op_ms))
+                if k % 3 == 2:
+                    net._run(self.frames, "u8", timed=True, fresh=False, options=self.options)
+                    brack.append(np.array(net.last_op_ms))
+        per_op = np.median(np.stack(kern), axis=0)
+        per_op_min = np.min(np.stack(kern), axis=0)
+        per_op_brk = np.median(np.stack(brack), axis=0) if brack else per_op
         plan = net.plan_report()
         by_kernel = {}
-        for op, ms in zip(plan, per_op):
-            k = by_kernel.setdefault(op["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        for op, ms, ms_min, ms_b in zip(plan, per_op, per_op_min, per_op_brk):
+            k = by_kernel.setdefault(op["kernel"], dict(ms=0.0, ms_min=0.0, ms_bracket=0.0, flops=0.0, bytes=0.0, launches=0))
             k["ms"] += float(ms)
+            k["ms_min"] += float(ms_min)
+            k["ms_bracket"] += float(ms_b)
             k["flops"] += op["flops"]
             k["bytes"] += op["bytes"]
             k["launches"] += 1
@@ -570,31 +661,50 @@ class Workload(object):
         if dump_ops:
             desc = net._last_plan.desc["ops"]
             with open(dump_ops, "w") as fh:
-                fh.write("%4s %5s %-28s %-34s %9s %9s %9s\n" % ("op", "block", "kernel", "shape", "ms", "TFLOP/s", "GB/s"))
-                for i, (op, ms, od) in enumerate(zip(plan, per_op, desc)):
+                fh.write("%4s %5s %-28s %-34s %9s %9s %9s %9s\n" % ("op", "block", "kernel", "shape", "ms", "TFLOP/s", "GB/s", "bracket"))
+                for i, (op, ms, od, mb) in enumerate(zip(plan, per_op, desc, per_op_brk)):
                     ti, to = od["inp"], od.get("out")
                     shape = "%dx%dx%d" % (ti.h, ti.w, ti.c) + ("->%dx%dx%d k%d s%d" % (to.h, to.w, to.c, od.get("ksize", 0), od.get("stride", 0)) if to is not None else "")
-                    fh.write("%4d %5d %-28s %-34s %9.4f %9.1f %9.1f\n" % (
-                        i, op["block"], op["kernel"], shape, ms, op["flops"] / max(ms, 1e-9) / 1e9, op["bytes"] / max(ms, 1e-9) / 1e6))
+                    fh.write("%4d %5d %-28s %-34s %9.4f %9.1f %9.1f %9.4f\n" % (
+                        i, op["block"], op["kernel"], shape, ms, op["flops"] / max(ms, 1e-9) / 1e9, op["bytes"] / max(ms, 1e-9) / 1e6, mb))
         dominant = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
-        return dict(by_kernel=by_kernel, dominant=dominant, plan_ms=float(per_op.sum()))
+        return dict(by_kernel=by_kernel, dominant=dominant, plan_ms=float(per_op.sum()), plan_ms_bracket=float(per_op_brk.sum()),
+                    passes=len(kern), bracket_passes=len(brack), sustain_steps=sustain_steps, telemetry=tel.summary())
 
     def roofline(self, report, traffic_table=None):
         dk = report["by_kernel"][report["dominant"]]
         achieved = dk["flops"] / (dk["ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[self.dtype]
-        traffic = None
+        traffic = rocprof_us = None
         if traffic_table:                                 # per workload: a kernel's mean traffic depends on the layers it runs
             key = "%s_%d_b%d_%s" % (self.model, self.dim, self.batch, self.dtype)
             kern = traffic_table.get("workloads", {}).get(key, {}).get("kernels", {})
             traffic = kern.get(report["dominant"], {}).get("traffic_bytes_per_launch")
-        return {"bound": "mfma", "kernel": report["dominant"], "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": round(dk["bytes"] / dk["launches"]),
-                "algorithmic_flops_per_launch": round(dk["flops"] / dk["launches"]),
-                "timing": "HIP events around every launch, serial passes on the launch stream",
-                "launches_per_step": dk["launches"], "kernel_ms_per_step": round(dk["ms"], 4),
-                "all_kernels_ms_per_step": round(report["plan_ms"], 4)}
+            rocprof_us = kern.get(report["dominant"], {}).get("rocprof_avg_us")
+        tel = report.get("telemetry") or {}
+        sclk = tel.get("sclk_mhz")
+        out = {"bound": "mfma", "kernel": report["dominant"], "achieved": round(achieved, 2), "peak": peak,
+               "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+               "algorithmic_bytes_per_launch": round(dk["bytes"] / dk["launches"]),
+               "algorithmic_flops_per_launch": round(dk["flops"] / dk["launches"]),
+               "timing": "HIP events bound to every dispatch (hipExtLaunchKernel start / stop: the kernel's own begin -> end, what "
+                         "rocprofv3 reports), %d serial passes on the launch stream right after %d steps of sustained load; MEDIAN "
+                         "per op" % (report.get("passes", 0), report.get("sustain_steps", 0)),
+               "launches_per_step": dk["launches"], "kernel_ms_per_step": round(dk["ms"], 4),
+               "avg_us": round(dk["ms"] / dk["launches"] * 1e3, 2), "min_us": round(dk["ms_min"] / dk["launches"] * 1e3, 2),
+               "frac_from_min": round(dk["flops"] / (dk["ms_min"] * 1e-3) / 1e12 / peak, 4),
+               # the same launches bracketed by two stream events (the method of rounds 1-5): + dispatch / barrier packets
+               "event_bracket_avg_us": round(dk["ms_bracket"] / dk["launches"] * 1e3, 2),
+               # mean of the same kernel in the committed rocprofv3 kernel trace of this binary (hash-checked like `traffic`)
+               "rocprof_avg_us": rocprof_us,
+               "sclk_mhz": sclk, "sclk_mhz_range": [tel.get("sclk_mhz_min"), tel.get("sclk_mhz_max")] if sclk else None,
+               "power_w": tel.get("power_w"), "telemetry_samples": tel.get("samples", 0),
+               # the peak is quoted at 2400 MHz; the chip holds less under this load (power cap): the share of the matrix
+               # pipes' rate AT THE CLOCK THEY RAN AT
+               "frac_at_held_clock": round(achieved / (peak * sclk / 2400.0), 4) if sclk else None,
+               "all_kernels_ms_per_step": round(report["plan_ms"], 4),
+               "all_kernels_ms_per_step_event_bracket": round(report["plan_ms_bracket"], 4)}
+        return out
 
 
 def lib_sha256():
@@ -656,7 +766,7 @@ def device_code_sha256(path=None):
 
 def load_traffic_table():
     """HBM-side traffic per launch comes from separate rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a
-    pass and counters cannot be read from inside this process): tools/profile_gpu.sh -> TRAFFIC_FILE (profiles/r05_traffic.json),
+    pass and counters cannot be read from inside this process): tools/profile_gpu.sh -> TRAFFIC_FILE (profiles/r06_traffic.json),
     which records the sha256 of the library it measured and of its device code objects.  A table measured on other
     kernels is not used."""
     try:
@@ -709,6 +819,9 @@ def cpu_baseline_in_child(args):
     out["numa_node"] = node
     out["loadavg_before"] = [round(v, 2) for v in load0]
     out["loadavg_after"] = [round(v, 2) for v in os.getloadavg()]
+    # a host whose run queue is longer than the cores this job may use: the wall-clock `value` is then a statement about the
+    # neighbours; `value_cpu_time` is the figure to compare between runs
+    out["noisy"] = bool(load0[0] > cores)
     out["wall_s"] = round(time.perf_counter() - t0, 1)
     return out
 
@@ -747,12 +860,12 @@ def cpu_baseline(cfg, params, model, dim, budget_s):
     for batch, share in ((1, 0.6), (16, 1.0)):
         leg_budget = budget_s * share - spent          # batch 16: everything batch 1 left
         t_leg = 0.0
-        times, warm = [], 0
+        times, cpus, warm = [], [], 0
         want_warm, want_timed = 3, 10
         while len(times) < want_timed:
-            c0 = time.perf_counter()
+            c0, p0 = time.perf_counter(), time.process_time()
             orc.inference(onet, frames[:batch], 0.05, 0.3)
-            dt = time.perf_counter() - c0
+            dt, dcpu = time.perf_counter() - c0, time.process_time() - p0
             spent += dt
             t_leg += dt
             if warm == 1 and not times and (leg_budget - t_leg) / dt < want_warm - 2 + want_timed:
@@ -762,14 +875,28 @@ def cpu_baseline(cfg, params, model, dim, budget_s):
                 warm += 1
                 continue
             times.append(dt)
+            cpus.append(dcpu)
             if t_leg + dt > leg_budget and len(times) >= 2:
                 break
         med = float(np.median(times))
+        cpu_med = float(np.median(cpus))
         legs[batch] = dict(fps=round(batch / med, 3), fps_min=round(batch / max(times), 3), fps_max=round(batch / min(times), 3),
                            median_s=round(med, 4), min_s=round(min(times), 4), max_s=round(max(times), 4), warmup=warm,
-                           timed=len(times), truncated=bool(warm < 3 or len(times) < 10))
+                           timed=len(times), truncated=bool(warm < 3 or len(times) < 10),
+                           # CPU seconds (user + system, all threads of the process) per call: what a neighbour on the same
+                           # host cannot take away -- wall time it can (2.6 .. 15.6 frames/s by wall
+                           # clock over seven runs of one protocol)
+                           cpu_s_median=round(cpu_med, 4), cpu_s_min=round(min(cpus), 4), cpu_s_max=round(max(cpus), 4),
+                           frames_per_core_second=round(batch / max(cpu_med, 1e-9), 4),
+                           busy_cores=round(cpu_med / max(med, 1e-9), 2))
     best = max(legs, key=lambda b_: legs[b_]["fps"])
+    fpcs = legs[best]["frames_per_core_second"]
     return dict(value=legs[best]["fps"], unit="frames/s", cores=cores, cpu_model=cpu_model(), kind="port",
+                # contention-proof companion of `value`: frames per CPU-second of the process (time.process_time: user + system
+                # over all threads), and that rate on `cores` fully owned cores.  `value` is wall clock and moves with the
+                # neighbours' load on the shared host; this one does not (much: shared caches and SMT siblings still count)
+                frames_per_core_second=fpcs, value_cpu_time=round(fpcs * cores, 3),
+                value_cpu_time_kind="frames per process CPU-second x cores (best leg)",
                 value_kind="best_of_batch1_batch16_median", value_min=legs[best]["fps_min"], value_max=legs[best]["fps_max"],
                 best_batch=best, batch1=legs[1], batch16=legs[16], truncated=legs[best]["truncated"],
                 sample="%s %dx%d float32, torch-CPU conv/BN/leaky + numpy NMS (oracle/), %d threads; batch 1 (the reference CLI's "
@@ -908,6 +1035,75 @@ def lowp_agreement(dev, dtype="bf16"):
     return out
 
 
+def latency_report(dev, model, dim, params, n_calls=200, n_video=300):
+    """The mode a drop-in user hits first (VERDICT r05 missing item 4): the reference's command line runs ONE frame per
+    ``inference()`` call (/root/reference/yolov3/__main__.py:157-165, "TODO: batch images") and its video loop one frame per
+    iteration (inference.py:527-530).  Reported here: wall time of ``yolov3.inference(net, one net-sized uint8 frame)`` --
+    upload, 75 launches, detect, records back, unpack: p50 / p99 / mean over ``n_calls`` calls per storage type, eager and with
+    the plan replayed as one hipGraph (use_graph=1 on a non-default stream) -- and frames/s of the package's batched loops over
+    ``n_video`` frames at --batch-size 1 and 16: ``detect_in_frames`` on decoded frames in memory (the loop itself) and
+    ``detect_in_video`` on a YUV4MPEG2 file (the same loop + the numpy 4:2:0 decoder + draw_boxes: host-bound)."""
+    import tempfile
+    import yolov3
+    from yolov3 import stream as ystream
+    from yolov3 import videoio
+    from yolov3.synthdata import synth_frames
+    cfg = os.path.join(ROOT, "pytorch-yolov3_amd", "models", model + ".cfg")
+    frame = synth_frames(321, 1, dim, dim)[0]
+    out = {"what": "%s %dx%d, one frame per call: yolov3.inference() wall time in ms (upload + forward + detect + records back "
+                   "+ unpack), %d calls after 10 warm-up" % (model, dim, dim, n_calls), "inference_ms": {}}
+    side = torch.cuda.Stream(device=dev)
+    nets = {}
+    for dtype in ("float32", "fp16", "bf16"):
+        for graph in (0, 1):
+            net = yolov3.Darknet(cfg, device=str(dev), dtype=dtype, options={"use_graph": 1} if graph else None).eval()
+            net.set_params(params)
+            ts = []
+            with torch.cuda.stream(side if graph else torch.cuda.current_stream(dev)):
+                for _ in range(10):
+                    yolov3.inference(net, frame, device=str(dev))
+                for _ in range(n_calls):
+                    t0 = time.perf_counter()
+                    yolov3.inference(net, frame, device=str(dev))
+                    ts.append((time.perf_counter() - t0) * 1e3)
+            ts = np.array(ts)
+            out["inference_ms"]["%s%s" % (dtype, "_graph" if graph else "")] = {
+                "p50": round(float(np.percentile(ts, 50)), 3), "p99": round(float(np.percentile(ts, 99)), 3),
+                "mean": round(float(ts.mean()), 3), "frames_per_s": round(1e3 / float(ts.mean()), 1)}
+            if not graph:
+                nets[dtype] = net
+            else:
+                del net
+    # the batched loops, bf16 (the benchmarked storage type)
+    net = nets["bf16"]
+    frames = synth_frames(555, n_video, dim, dim)
+    loops = {}
+    for bs in (1, 16):
+        list(ystream.detect_in_frames(net, (f for f in frames[:2 * bs]), batch_size=bs))          # pipeline set-up, plans
+        t0 = time.perf_counter()
+        n = sum(1 for _ in ystream.detect_in_frames(net, (f for f in frames), batch_size=bs))
+        dt = time.perf_counter() - t0
+        loops["detect_in_frames_batch%d" % bs] = {"frames": n, "frames_per_s": round(n / dt, 1), "ms_per_frame": round(dt / n * 1e3, 3)}
+    with tempfile.TemporaryDirectory(prefix="y3_bench_video_") as tmp:
+        path = os.path.join(tmp, "clip.y4m")
+        videoio.write_y4m(path, (f for f in frames), fps=25)
+        t0 = time.perf_counter()
+        n = sum(1 for _ in videoio.open_video(path)[1])
+        decode_ms = (time.perf_counter() - t0) / max(n, 1) * 1e3
+        for bs in (1, 16):
+            t0 = time.perf_counter()
+            res = ystream.detect_in_video(net, path, device=str(dev), batch_size=bs)
+            dt = time.perf_counter() - t0
+            loops["detect_in_video_y4m_batch%d" % bs] = {"frames": len(res), "frames_per_s": round(len(res) / dt, 1),
+                                                         "ms_per_frame": round(dt / max(len(res), 1) * 1e3, 3)}
+        loops["y4m_decode_alone_ms_per_frame"] = round(decode_ms, 3)
+    out["loops_bf16"] = loops
+    out["note"] = ("batch 1 is launch- and round-trip-bound, not kernel-bound (75 launches + one synchronising copy per call); "
+                   "use_graph=1 replays the forward as one hipGraph launch; detect_in_video's rate is the numpy YUV decoder's "
+                   "and draw_boxes' (host), compare y4m_decode_alone_ms_per_frame")
+    return out
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -1019,7 +1215,9 @@ def main(argv=None):
     line = None
     if rank == 0:
         traffic_table, traffic_note = load_traffic_table()
-        report = wl.kernel_report(args.profile_passes, args.dump_ops)
+        telemetry = GpuTelemetry(placement.get("gpu_bdf_runtime") or placement.get("gpu_bdf"))
+        sustain_steps = int(args.sustain / max(elapsed / args.steps, 1e-4)) if args.sustain > 0 else 0
+        report = wl.kernel_report(args.profile_passes, args.dump_ops, telemetry=telemetry, sustain_steps=sustain_steps)
         b, dim = my_frames, args.dim
         fps = sum(all_frames) * args.steps / elapsed
         flops_frame = MODEL_FLOPS_PER_FRAME.get((args.model, dim))
@@ -1057,13 +1255,17 @@ def main(argv=None):
             "roofline": roof,
             "per_rank": per_rank,
             "cpu_baseline": None,
+            "cpu_baseline_why": None if world == 1 and not args.no_cpu_baseline else (
+                "--no-cpu-baseline" if world == 1 else
+                "measured on rank 0 at N = 1 only (the host cores are busy feeding N ranks; see the N = 1 line)"),
             "lib_sha256": lib_sha256()[:16],
             "device_code_sha256": (device_code_sha256() or "")[:16],
         }
         if flops_frame:
             line["end_to_end_tflops"] = round(fps * flops_frame / 1e12, 2)
             line["end_to_end_frac_of_peak"] = round(fps * flops_frame / 1e12 / (PEAK_TFLOPS[args.dtype] * world), 4)
-        line["kernels"] = {k: {"ms": round(v["ms"], 4), "launches": v["launches"],
+        line["kernels"] = {k: {"ms": round(v["ms"], 4), "ms_min": round(v["ms_min"], 4), "ms_event_bracket": round(v["ms_bracket"], 4),
+                               "launches": v["launches"],
                                "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2),
                                "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
                            for k, v in report["by_kernel"].items()}
@@ -1092,7 +1294,8 @@ def main(argv=None):
             steps = 100 if model == "yolov3-tiny" else max(6, min(args.steps, 20 if dtype == "float32" else args.steps))
             e = w2.timed(steps, 2 * nstream, False, repeats=3)             # median of three windows, like the headline's five
             e_res = w2.timed(steps, 2 * nstream, False, resident=True)      # rounds 1-3 reported this one
-            rep = w2.kernel_report(2)
+            rep = w2.kernel_report(9, telemetry=GpuTelemetry(placement.get("gpu_bdf_runtime") or placement.get("gpu_bdf")),
+                                   sustain_steps=int(0.5 / max(e / steps, 1e-4)))
             f = batch * steps / e
             ff = MODEL_FLOPS_PER_FRAME.get((model, dim))
             others.append({"workload": "%s %dx%d batch=%d %s" % (model, dim, dim, batch, dtype), "value": round(f, 2),
@@ -1120,6 +1323,13 @@ def main(argv=None):
             del w2
             torch.cuda.empty_cache()
         line["detection_regimes"] = regimes
+        if not args.no_latency:
+            t_lat = time.perf_counter()
+            try:
+                line["latency"] = latency_report(dev, args.model, args.dim, params)
+            except Exception as exc:         # a diagnostic section must not void the bench line
+                line["latency"] = {"error": repr(exc)}
+            phases["latency_s"] = round(time.perf_counter() - t_lat, 1)
         for key, dt in (("bf16_agreement", "bf16"), ("f16_agreement", "fp16")):
             try:
                 line[key] = lowp_agreement(dev, dt)

@@ -9,8 +9,10 @@
  *
  * Conventions
  *   - plain C types only; every pointer named d_* is a DEVICE address (hipMalloc'd by the
- *     caller, e.g. torch tensor .data_ptr()); the library never allocates or frees
- *     caller-visible memory and never synchronises the device;
+ *     caller, e.g. torch tensor .data_ptr()); the library never allocates or frees caller-visible memory and never
+ *     synchronises the device.  One exception, for callers that do not pass y3_op.d_weight_frag: a plan then makes and owns a
+ *     private fragment-order copy of the weights of every layer it gives to the direct-weights strip kernel (hipMalloc at
+ *     y3_plan_create on the device that owns d_weight, one stream synchronisation there, hipFree at y3_plan_destroy);
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
  *   - every function returns 0 on success, a negative Y3_ERR_* code otherwise, and
  *     y3_last_error() then returns a human-readable message (thread-local);
@@ -29,7 +31,7 @@
 extern "C" {
 #endif
 
-#define Y3_ABI_VERSION 5
+#define Y3_ABI_VERSION 6
 
 /* error codes */
 #define Y3_OK 0
@@ -99,6 +101,10 @@ typedef struct y3_op {
   int64_t *d_cls;                 /* (B, rows_total)                                       */
   int32_t block_idx;              /* Darknet block this op implements (diagnostics)        */
   int32_t reserved;
+  /* ABI 6: the conv's weights in MFMA-fragment order (y3_conv_make_fragment_weights), y3_conv_fragment_weight_bytes() bytes,
+   * for the layers the direct-weights strip kernel takes; shared by every plan of the network.  NULL: a plan that needs the
+   * copy makes a private one (see the conventions above).                                                              */
+  const void *d_weight_frag;
 } y3_op;
 
 typedef struct y3_plan y3_plan;
@@ -175,6 +181,11 @@ int y3_plan_run(y3_plan *plan, const void *d_input, void *stream);
 /* same, bracketing every op with HIP events; after the call ms_per_op[i] holds op i's device
  * time in milliseconds (synchronises the stream; for bench.py / profiling only)              */
 int y3_plan_run_timed(y3_plan *plan, const void *d_input, void *stream, float *ms_per_op);
+/* same run, but every kernel is launched with a start / stop event pair bound to its DISPATCH (hipExtLaunchKernel):
+ * kernel_ms_per_op[i] is the device time of op i's kernel(s) from begin to end -- what rocprofv3's kernel trace reports --
+ * without the dispatch / barrier-packet handling between two stream events that y3_plan_run_timed's figure includes
+ * (~5 us per launch on an MI355X).  Synchronises the stream; for bench.py / profiling only.                       */
+int y3_plan_run_profiled(y3_plan *plan, const void *d_input, void *stream, float *kernel_ms_per_op);
 /* name of the kernel an op dispatches to, e.g. "conv_igemm_bf16_128x128" (static string)     */
 const char *y3_plan_op_kernel(const y3_plan *plan, int op_index);
 /* algorithmic FLOPs (2*k*k*Cin*Cout*Hout*Wout*B for convs, else 0) and compulsory bytes      */
@@ -187,6 +198,14 @@ double y3_plan_op_bytes(const y3_plan *plan, int op_index);
  * byte-channel, zero padded; scale/bias 32 floats); -1 if `op` is not a conv.  The host lays weights
  * out accordingly.                                                                              */
 int y3_conv_path(const y3_op *op);
+
+/* Fragment-order weights of the direct-weights strip kernel (csrc/conv_halo.hip: 1-KiB blocks of 16 output channels x 32
+ * K-elements in the MFMA operand layout).  y3_conv_fragment_weight_bytes: size of the copy if a plan created with `options`
+ * (NULL = the current defaults) runs `op` on that kernel, else 0 -- the host makes ONE copy per layer and device with
+ * y3_conv_make_fragment_weights (reads op->d_weight, [cout_pad][k_ld]; stream-ordered on `stream`) and passes it to every
+ * plan in y3_op.d_weight_frag.  No reference counterpart (a layout of the parameters darknet.py:415-476 loads).          */
+size_t y3_conv_fragment_weight_bytes(const y3_op *op, const y3_options *options);
+int y3_conv_make_fragment_weights(const y3_op *op, void *d_dst, void *stream);
 
 /* A/B measurements only (tools/conv_bench.py, bench.py --tuning): changes ONE field of the process-wide DEFAULT
  * options by name ("auto_mask", "igemm_version", "igemm_ns", "igemm_bm", "use_graph", "fuse_stem",

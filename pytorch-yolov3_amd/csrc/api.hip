@@ -9,7 +9,7 @@
 
 #include "common.h"
 
-static_assert(sizeof(y3_op) == 240, "y3_op layout is part of the ABI (ctypes mirror in yolov3/_hip.py)");
+static_assert(sizeof(y3_op) == 248, "y3_op layout is part of the ABI (ctypes mirror in yolov3/_hip.py)");
 
 namespace {
 thread_local char g_err[512] = "";
@@ -21,6 +21,8 @@ static y3_options g_y3_defaults = {/*auto_mask*/ (int32_t)Y3_AM_DEFAULT, /*unuse
                                    /*decode_lanes*/ 4, /*fuse_block*/ 0, {0, 0, 0, 0, 0}};
 static thread_local const y3_options *tl_y3_opt = nullptr;
 const y3_options &y3_opt() { return tl_y3_opt ? *tl_y3_opt : g_y3_defaults; }
+static thread_local Y3KernelTimer *tl_y3_timer = nullptr;
+Y3KernelTimer *y3_kernel_timer() { return tl_y3_timer; }
 // y3_set_tuning("debug", v): exists in DIAGNOSTIC builds only (`make variant FLAGS=-DY3_X_...`, `make stamps`); the product
 // library rejects the key, so a benchmark line can never come from kernels that skip work
 #if defined(Y3_X_NOEPI) || defined(Y3_X_S2BOUND) || defined(Y3_X_DEBUG) || defined(Y3_STAMPS)
@@ -65,8 +67,10 @@ struct y3_plan {
   std::vector<char> fuse;   // per op: 0 = launch normally, 1 / 3 / 4 / 6 = launch fused with the next op (stem pair /
                             // 64-32-64 residual block / head conv + decode / 128-channel bottleneck block), 5 = SPP
                             // pyramid with the next TWO ops, 2 = nothing (fused into a previous op)
-  std::vector<void *> frag_w;   // per op: the plan's fragment-order copy of a conv's weights (direct-weights strip kernel), or null
+  std::vector<void *> frag_w;   // per op: fragment-order copy of a conv's weights (direct-weights strip kernel), or null
+  std::vector<char> frag_own;   // ... and whether the plan made (and frees) it: callers of ABI 6 pass a shared copy in the op
   std::vector<hipEvent_t> events;
+  std::vector<hipEvent_t> kstart, kstop;   // y3_plan_run_profiled: event pairs bound to the dispatches (two per op)
   // hipGraph replay (one graph launch per forward instead of ~80 kernel launches): executable graphs keyed by the
   // input pointer they were captured with; the first run of a plan is always eager (one-time function attributes)
   struct GraphEntry { const void *input; hipGraphExec_t exec; };
@@ -136,7 +140,7 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
             // direct-weights strip kernel (192 x 256 tiles) where its tile count fills the chip better (csrc/conv_halo.hip)
             if (k3 && !small_grid && halo_ok && (((am & Y3_AM_HALO_DW) && y3_conv_halo_dw_pays(op)) ||
                                                  ((am & Y3_AM_HALO_DW_ALWAYS) && y3_conv_halo_dw_fits(op))))
-              return y3_launch_conv_halo_dw(op, in, d_zero, s, name, dry_run, frag_w);
+              return y3_launch_conv_halo_dw(op, in, d_zero, s, name, dry_run, frag_w ? frag_w : op.d_weight_frag);
             if (small_grid && y3_is16(op.dtype)) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
             if (want_halo && halo_ok && !small_grid) return y3_launch_conv_halo(op, in, d_zero, s, name, dry_run);
             if (want_ws) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
@@ -180,6 +184,40 @@ int run_op(y3_plan *plan, size_t i, const void *d_input, hipStream_t s, const ch
   return dispatch(plan->ops[i], d_input, plan->d_zero, s, name, false, plan->frag_w[i]);
 }
 
+// A private fragment-order copy of op i's weights (callers that pass no y3_op.d_weight_frag).  Made on the device that OWNS
+// the weights -- not on whichever device happens to be current (a network on cuda:1 compiled while device 0 is
+// current put the copy on GPU 0) -- and on a stream of its own, so that neither the legacy null stream's implicit
+// synchronisation nor a stream capture in progress elsewhere in the process is touched.
+int make_private_fragment_weights(y3_plan *p, size_t i) {
+  const y3_op &op = p->ops[i];
+  int prev = -1, owner = -1;
+  Y3_HIP_CHECK(hipGetDevice(&prev));
+  hipPointerAttribute_t attr;
+  if (op.d_weight && hipPointerGetAttributes(&attr, op.d_weight) == hipSuccess) owner = attr.device;
+  else (void)hipGetLastError();
+  if (owner >= 0 && owner != prev) Y3_HIP_CHECK(hipSetDevice(owner));
+  int rc = Y3_OK;
+  void *w = nullptr;
+  hipStream_t s = nullptr;
+  do {
+    if (hipMalloc(&w, y3_conv_halo_dw_weight_bytes(op)) != hipSuccess) {
+      (void)hipGetLastError();
+      y3_set_error("y3_plan_create: no memory for the fragment-order weights of block %d", op.block_idx);
+      rc = Y3_ERR_HIP;
+      break;
+    }
+    p->frag_w[i] = w;
+    p->frag_own[i] = 1;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { s = nullptr; rc = Y3_ERR_HIP; }
+    if (rc == Y3_OK) rc = y3_conv_halo_dw_make_weights(op, w, s);
+    if (rc == Y3_OK && hipStreamSynchronize(s) != hipSuccess) rc = Y3_ERR_HIP;
+    if (rc == Y3_ERR_HIP) y3_set_error("y3_plan_create: fragment-order weights of block %d: %s", op.block_idx, hipGetErrorString(hipGetLastError()));
+  } while (0);
+  if (s) (void)hipStreamDestroy(s);
+  if (owner >= 0 && owner != prev) (void)hipSetDevice(prev);
+  return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -206,6 +244,21 @@ int y3_conv_path(const y3_op *op) {
   return conv_path(*op);
 }
 
+size_t y3_conv_fragment_weight_bytes(const y3_op *op, const y3_options *options) {
+  if (!op || op->kind != Y3_OP_CONV || conv_path(*op) != 0) return 0;
+  y3_options o = options ? *options : g_y3_defaults;
+  OptScope scope(&o);
+  const char *name = "";
+  if (dispatch(*op, nullptr, nullptr, nullptr, &name, true) != Y3_OK) return 0;
+  return strncmp(name, "conv_halo_dw_", 13) == 0 ? y3_conv_halo_dw_weight_bytes(*op) : 0;
+}
+
+int y3_conv_make_fragment_weights(const y3_op *op, void *d_dst, void *stream) {
+  Y3_REQUIRE(op && d_dst && op->d_weight, "y3_conv_make_fragment_weights: bad arguments");
+  Y3_REQUIRE(y3_conv_halo_dw_fits(*op), "conv block %d: not a layer of the direct-weights strip kernel", op->block_idx);
+  return y3_conv_halo_dw_make_weights(*op, d_dst, static_cast<hipStream_t>(stream));
+}
+
 void y3_options_default(y3_options *options) {
   if (options) *options = g_y3_defaults;
 }
@@ -224,7 +277,7 @@ int y3_plan_create_ex(const y3_op *ops, int n_ops, const void *d_zero, const y3_
   p->ops.assign(ops, ops + n_ops);
   p->kernel.assign(n_ops, "");
   p->frag_w.assign(n_ops, nullptr);
-  bool made_weights = false;
+  p->frag_own.assign(n_ops, 0);
   p->d_zero = d_zero;
   p->fuse.assign(n_ops, 0);
   for (int i = 0; i + 2 < n_ops; ++i)
@@ -276,27 +329,15 @@ int y3_plan_create_ex(const y3_op *ops, int n_ops, const void *d_zero, const y3_
       return rc;
     }
     if (strncmp(p->kernel[i], "conv_halo_dw_", 13) == 0) {
-      // this kernel reads its weights in MFMA-fragment order: the plan keeps its own copy (made once, here; the plan is
-      // destroyed with the parameters it was compiled for)
-      void *w = nullptr;
-      if (hipMalloc(&w, y3_conv_halo_dw_weight_bytes(p->ops[i])) != hipSuccess) {
-        y3_set_error("y3_plan_create: no memory for the fragment-order weights of block %d", p->ops[i].block_idx);
-        y3_plan_destroy(p);
-        return Y3_ERR_HIP;
-      }
-      p->frag_w[i] = w;
-      const int rc2 = y3_conv_halo_dw_make_weights(p->ops[i], w, nullptr);
+      // this kernel reads its weights in MFMA-fragment order: the caller's shared copy (y3_op.d_weight_frag, ABI 6), or --
+      // callers that pass none -- a private copy that the plan makes here and frees when it is destroyed
+      if (p->ops[i].d_weight_frag) { p->frag_w[i] = const_cast<void *>(p->ops[i].d_weight_frag); continue; }
+      const int rc2 = make_private_fragment_weights(p, i);
       if (rc2 != Y3_OK) {
         y3_plan_destroy(p);
         return rc2;
       }
-      made_weights = true;
     }
-  }
-  if (made_weights && hipStreamSynchronize(nullptr) != hipSuccess) {
-    y3_set_error("y3_plan_create: fragment-order weights: %s", hipGetErrorString(hipGetLastError()));
-    y3_plan_destroy(p);
-    return Y3_ERR_HIP;
   }
   *out_plan = p;
   return Y3_OK;
@@ -305,9 +346,11 @@ int y3_plan_create_ex(const y3_op *ops, int n_ops, const void *d_zero, const y3_
 void y3_plan_destroy(y3_plan *plan) {
   if (!plan) return;
   for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : plan->kstart) (void)hipEventDestroy(e);
+  for (hipEvent_t e : plan->kstop) (void)hipEventDestroy(e);
   for (auto &g : plan->graphs) (void)hipGraphExecDestroy(g.exec);
-  for (void *w : plan->frag_w)
-    if (w) (void)hipFree(w);
+  for (size_t i = 0; i < plan->frag_w.size(); ++i)
+    if (plan->frag_w[i] && plan->frag_own[i]) (void)hipFree(plan->frag_w[i]);
   delete plan;
 }
 
@@ -379,6 +422,43 @@ int y3_plan_run_timed(y3_plan *plan, const void *d_input, void *stream, float *m
   }
   Y3_HIP_CHECK(hipEventSynchronize(plan->events[n]));
   for (size_t i = 0; i < n; ++i) Y3_HIP_CHECK(hipEventElapsedTime(&ms_per_op[i], plan->events[i], plan->events[i + 1]));
+  return Y3_OK;
+}
+
+int y3_plan_run_profiled(y3_plan *plan, const void *d_input, void *stream, float *kernel_ms_per_op) {
+  Y3_REQUIRE(plan && kernel_ms_per_op, "y3_plan_run_profiled: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  OptScope scope(&plan->opt);
+  const size_t n = plan->ops.size(), cap = 2 * n;       // (an op is one launch today; room for two)
+  while (plan->kstart.size() < cap) {
+    hipEvent_t a, b;
+    Y3_HIP_CHECK(hipEventCreate(&a));
+    plan->kstart.push_back(a);
+    Y3_HIP_CHECK(hipEventCreate(&b));
+    plan->kstop.push_back(b);
+  }
+  Y3KernelTimer timer = {plan->kstart.data(), plan->kstop.data(), 0, (int)cap};
+  std::vector<int> first(n + 1, 0);
+  const char *name = nullptr;
+  int rc = Y3_OK;
+  tl_y3_timer = &timer;
+  for (size_t i = 0; i < n && rc == Y3_OK; ++i) {
+    first[i] = timer.n;
+    rc = run_op(plan, i, d_input, s, &name);
+  }
+  first[n] = timer.n;
+  tl_y3_timer = nullptr;
+  if (rc != Y3_OK) return rc;
+  Y3_HIP_CHECK(hipStreamSynchronize(s));
+  for (size_t i = 0; i < n; ++i) {
+    float sum = 0.f;
+    for (int k = first[i]; k < first[i + 1]; ++k) {
+      float ms = 0.f;
+      Y3_HIP_CHECK(hipEventElapsedTime(&ms, plan->kstart[k], plan->kstop[k]));
+      sum += ms;
+    }
+    kernel_ms_per_op[i] = sum;
+  }
   return Y3_OK;
 }
 

@@ -1,6 +1,7 @@
 // Shared device/host helpers for libyolov3_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -56,6 +57,27 @@ void y3_set_error(const char *fmt, ...);
       y3_set_error(__VA_ARGS__);  \
       return Y3_ERR_INVALID;      \
     }                             \
+  } while (0)
+
+// Every kernel of the library is launched through Y3_LAUNCH.  Normally that is hipLaunchKernelGGL.  Inside
+// y3_plan_run_profiled (api.hip) the calling thread has a Y3KernelTimer set and the launch goes through
+// hipExtLaunchKernelGGL with a start / stop event pair BOUND TO THE DISPATCH: their elapsed time is the kernel's own
+// begin -> end on the device (the figure rocprofv3's kernel trace reports), without the ~5 us of dispatch and barrier-packet
+// handling that an event recorded on the stream before and after a launch includes (y3_plan_run_timed).
+struct Y3KernelTimer {
+  hipEvent_t *start, *stop;
+  int n, cap;
+};
+Y3KernelTimer *y3_kernel_timer();
+#define Y3_LAUNCH(kernel, grid, block, lds, stream, ...)                                                             \
+  do {                                                                                                               \
+    Y3KernelTimer *_kt = y3_kernel_timer();                                                                          \
+    if (_kt && _kt->n < _kt->cap) {                                                                                  \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, _kt->start[_kt->n], _kt->stop[_kt->n], 0, __VA_ARGS__); \
+      ++_kt->n;                                                                                                      \
+    } else {                                                                                                         \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                             \
+    }                                                                                                                \
   } while (0)
 
 // One-time set-up per DEVICE (dynamic-LDS function attributes are per device; so is the CU count a persistent grid is

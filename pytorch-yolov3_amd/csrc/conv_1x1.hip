@@ -270,8 +270,8 @@ int y3_launch_conv1x1_wres(const y3_op &op, const void *d_in, const void *d_zero
     int grid = a.n_tiles > n_cu ? a.n_tiles : n_cu - n_cu % a.n_tiles;
     const long long tiles = (long long)a.m_tiles * a.n_tiles;
     if (grid > tiles) grid = (int)tiles;
-    if (bn == 128) hipLaunchKernelGGL((conv1x1_wres_kernel<T, 128>), dim3(grid), dim3(512), lds, s, a);
-    else hipLaunchKernelGGL((conv1x1_wres_kernel<T, 64>), dim3(grid), dim3(512), lds, s, a);
+    if (bn == 128) Y3_LAUNCH((conv1x1_wres_kernel<T, 128>), dim3(grid), dim3(512), lds, s, a);
+    else Y3_LAUNCH((conv1x1_wres_kernel<T, 64>), dim3(grid), dim3(512), lds, s, a);
     Y3_HIP_CHECK(hipGetLastError());
     return Y3_OK;
   });

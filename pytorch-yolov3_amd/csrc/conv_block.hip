@@ -500,7 +500,7 @@ int y3_launch_conv_block_fused(const y3_op &op0, const y3_op &op1, hipStream_t s
     a.inv_pw = (65536u + (uint32_t)(a.TW + 2) - 1u) / (uint32_t)(a.TW + 2);
     a.inv_tw = (65536u + (uint32_t)a.TW - 1u) / (uint32_t)a.TW;
     const int grid = a.tiles_x * a.tiles_y * op0.batch;
-    hipLaunchKernelGGL(conv_block_fused_kernel<T>, dim3(grid), dim3(kNT), kBlockLds, s, a);
+    Y3_LAUNCH(conv_block_fused_kernel<T>, dim3(grid), dim3(kNT), kBlockLds, s, a);
     Y3_HIP_CHECK(hipGetLastError());
     return Y3_OK;
   });

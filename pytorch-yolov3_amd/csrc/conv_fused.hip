@@ -968,8 +968,8 @@ int y3_launch_conv_fused_stem_s2(const y3_op &op0, const y3_op &op1, const void 
     a.tiles_y = y3_ceil_div(a.Ho, pipelined ? kPY : kTO);
     a.n_tiles = a.tiles_x * a.tiles_y * a.batch;
     const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
-    if (pipelined) hipLaunchKernelGGL((conv_stem_s2_ws_kernel<T, 4>), dim3(grid), dim3(1024), kPLds, s, a);
-    else hipLaunchKernelGGL(conv_stem_s2_fused_kernel<T>, dim3(grid), dim3(kThreads), kLds, s, a);
+    if (pipelined) Y3_LAUNCH((conv_stem_s2_ws_kernel<T, 4>), dim3(grid), dim3(1024), kPLds, s, a);
+    else Y3_LAUNCH(conv_stem_s2_fused_kernel<T>, dim3(grid), dim3(kThreads), kLds, s, a);
     Y3_HIP_CHECK(hipGetLastError());
     return Y3_OK;
   });
@@ -1020,7 +1020,7 @@ int y3_launch_conv_fused_resblock(const y3_op &op0, const y3_op &op1, hipStream_
       if (rc != Y3_OK) return rc;
     }
     const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
-    hipLaunchKernelGGL(conv_resblock_fused_kernel<T>, dim3(grid), dim3(kThreads), kRLds, s, a);
+    Y3_LAUNCH(conv_resblock_fused_kernel<T>, dim3(grid), dim3(kThreads), kRLds, s, a);
     Y3_HIP_CHECK(hipGetLastError());
     return Y3_OK;
   });

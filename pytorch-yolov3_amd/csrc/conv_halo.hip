@@ -1233,11 +1233,11 @@ int launch_halo_ws(const HaloArgs &a0, hipStream_t s) {
   }
   const dim3 grid(a.m_tiles * a.n_tiles);
   if (mi == 3) {
-    if (nsb == 4) hipLaunchKernelGGL((conv_halo_ws_kernel<T, 4, 3>), grid, dim3(768), lds, s, a);
-    else hipLaunchKernelGGL((conv_halo_ws_kernel<T, 3, 3>), grid, dim3(768), lds, s, a);
+    if (nsb == 4) Y3_LAUNCH((conv_halo_ws_kernel<T, 4, 3>), grid, dim3(768), lds, s, a);
+    else Y3_LAUNCH((conv_halo_ws_kernel<T, 3, 3>), grid, dim3(768), lds, s, a);
   } else {
-    if (nsb == 4) hipLaunchKernelGGL((conv_halo_ws_kernel<T, 4, 4>), grid, dim3(768), lds, s, a);
-    else hipLaunchKernelGGL((conv_halo_ws_kernel<T, 3, 4>), grid, dim3(768), lds, s, a);
+    if (nsb == 4) Y3_LAUNCH((conv_halo_ws_kernel<T, 4, 4>), grid, dim3(768), lds, s, a);
+    else Y3_LAUNCH((conv_halo_ws_kernel<T, 3, 4>), grid, dim3(768), lds, s, a);
   }
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
@@ -1299,9 +1299,9 @@ int launch_halo_dw(const HaloArgs &a0, hipStream_t s) {
   }
   const dim3 grid(a.m_tiles * a.n_tiles);
   // halo passes per chunk: 4 (rows of up to 30 pixels), 5 (up to 62), 6 (up to 94)
-  if (a.na == 4) hipLaunchKernelGGL((conv_halo_dw_kernel<T, 4>), grid, dim3(512), lds, s, a);
-  else if (a.na == 5) hipLaunchKernelGGL((conv_halo_dw_kernel<T, 5>), grid, dim3(512), lds, s, a);
-  else hipLaunchKernelGGL((conv_halo_dw_kernel<T, 6>), grid, dim3(512), lds, s, a);
+  if (a.na == 4) Y3_LAUNCH((conv_halo_dw_kernel<T, 4>), grid, dim3(512), lds, s, a);
+  else if (a.na == 5) Y3_LAUNCH((conv_halo_dw_kernel<T, 5>), grid, dim3(512), lds, s, a);
+  else Y3_LAUNCH((conv_halo_dw_kernel<T, 6>), grid, dim3(512), lds, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -1328,7 +1328,7 @@ int launch_patch_wsp(const HaloArgs &a0, hipStream_t s) {
   const int tiles_x = y3_ceil_div(a.W, TX), tiles_y = y3_ceil_div(a.H, TY);
   const int tiles = tiles_x * tiles_y * (a.M / a.HW) * a.n_tiles;
   const int grid = tiles < n_cu ? tiles : n_cu;
-  hipLaunchKernelGGL((conv_patch_wsp_kernel<T, 4>), dim3(grid), dim3(768), lds, s, a, tiles, tiles_x, tiles_y);
+  Y3_LAUNCH((conv_patch_wsp_kernel<T, 4>), dim3(grid), dim3(768), lds, s, a, tiles, tiles_x, tiles_y);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -1387,7 +1387,7 @@ size_t y3_conv_halo_dw_weight_bytes(const y3_op &op) { return (size_t)op.cout_pa
 // the fragment-order copy of op's weights into `dst` (y3_conv_halo_dw_weight_bytes), on `s`
 int y3_conv_halo_dw_make_weights(const y3_op &op, void *dst, hipStream_t s) {
   const long long n16 = (long long)op.cout_pad * op.k_ld * 2 / 16;
-  hipLaunchKernelGGL(weights_to_fragment_order_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s,
+  Y3_LAUNCH(weights_to_fragment_order_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s,
                      static_cast<const u32x4 *>(op.d_weight), static_cast<u32x4 *>(dst), op.k_ld / 32, n16);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;

@@ -922,9 +922,9 @@ int launch_cfg3x(IgemmArgs a, int kmode, hipStream_t s) {
   a.m_tiles = y3_ceil_div(a.M, BM);
   a.n_tiles = y3_ceil_div(a.Cout, BN);
   const dim3 grid(a.m_tiles * a.n_tiles), block(128 * WM * WN);
-  if (kmode == 0) hipLaunchKernelGGL((conv_igemm3_kernel<T, BM, BN, WM, WN, 0, NS>), grid, block, 0, s, a);
-  else if (kmode == 2) hipLaunchKernelGGL((conv_igemm3_kernel<T, BM, BN, WM, WN, 2, NS>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((conv_igemm3_kernel<T, BM, BN, WM, WN, 1, NS>), grid, block, 0, s, a);
+  if (kmode == 0) Y3_LAUNCH((conv_igemm3_kernel<T, BM, BN, WM, WN, 0, NS>), grid, block, 0, s, a);
+  else if (kmode == 2) Y3_LAUNCH((conv_igemm3_kernel<T, BM, BN, WM, WN, 2, NS>), grid, block, 0, s, a);
+  else Y3_LAUNCH((conv_igemm3_kernel<T, BM, BN, WM, WN, 1, NS>), grid, block, 0, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -942,9 +942,9 @@ int launch_cfg2(IgemmArgs a, int kmode, hipStream_t s) {
   a.m_tiles = y3_ceil_div(a.M, BM);
   a.n_tiles = y3_ceil_div(a.Cout, BN);
   const dim3 grid(a.m_tiles * a.n_tiles), block(64 * WM * WN);
-  if (kmode == 0) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 0>), grid, block, 0, s, a);
-  else if (kmode == 2) hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 2>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((conv_igemm2_kernel<T, BM, BN, WM, WN, 1>), grid, block, 0, s, a);
+  if (kmode == 0) Y3_LAUNCH((conv_igemm2_kernel<T, BM, BN, WM, WN, 0>), grid, block, 0, s, a);
+  else if (kmode == 2) Y3_LAUNCH((conv_igemm2_kernel<T, BM, BN, WM, WN, 2>), grid, block, 0, s, a);
+  else Y3_LAUNCH((conv_igemm2_kernel<T, BM, BN, WM, WN, 1>), grid, block, 0, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -956,9 +956,9 @@ int launch_cfg(const IgemmArgs &a0, bool generic, hipStream_t s) {
   a.n_tiles = y3_ceil_div(a.Cout, BN);
   const dim3 grid(a.m_tiles * a.n_tiles), block(256);
   if (generic)
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, true>), grid, block, 0, s, a);
+    Y3_LAUNCH((conv_igemm_kernel<T, BM, BN, WM, WN, true>), grid, block, 0, s, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, false>), grid, block, 0, s, a);
+    Y3_LAUNCH((conv_igemm_kernel<T, BM, BN, WM, WN, false>), grid, block, 0, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -1155,7 +1155,7 @@ int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d
   a.n_major = 0;
   a.m_tiles = y3_ceil_div(a.M, 64);
   return y3_by_dtype16(op0.dtype, [&](auto tag) {
-    hipLaunchKernelGGL((conv_igemm2_kernel<decltype(tag), 64, 256, 1, 4, 0, true>), dim3(a.m_tiles), dim3(256), 0, s, a);
+    Y3_LAUNCH((conv_igemm2_kernel<decltype(tag), 64, 256, 1, 4, 0, true>), dim3(a.m_tiles), dim3(256), 0, s, a);
     Y3_HIP_CHECK(hipGetLastError());
     return Y3_OK;
   });

@@ -290,8 +290,8 @@ int y3_launch_conv_small(const y3_op &op, const void *d_in, hipStream_t s, const
   const dim3 grid(y3_ceil_div(a.M, 256)), block(256);
   const size_t lds = ((size_t)27 * op.cout_pad + 256) * sizeof(float);
   return y3_by_dtype(odt, [&](auto tag) {
-    if (u8) hipLaunchKernelGGL((conv_stem3x3_kernel<decltype(tag), 1>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((conv_stem3x3_kernel<decltype(tag), 0>), grid, block, lds, s, a);
+    if (u8) Y3_LAUNCH((conv_stem3x3_kernel<decltype(tag), 1>), grid, block, lds, s, a);
+    else Y3_LAUNCH((conv_stem3x3_kernel<decltype(tag), 0>), grid, block, lds, s, a);
     Y3_HIP_CHECK(hipGetLastError());
     return Y3_OK;
   });
@@ -319,7 +319,7 @@ int y3_launch_conv_stem_mfma(const y3_op &op, const void *d_in, hipStream_t s, c
     a.tiles_x = y3_ceil_div(op.in_w, kStemTW);
     a.tiles_y = y3_ceil_div(op.in_h, kStemTH);
     a.flags = op.flags;
-    hipLaunchKernelGGL(conv_stem_mfma_kernel<T>, dim3(a.tiles_x * a.tiles_y * op.batch), dim3(256), 0, s, a);
+    Y3_LAUNCH(conv_stem_mfma_kernel<T>, dim3(a.tiles_x * a.tiles_y * op.batch), dim3(256), 0, s, a);
     Y3_HIP_CHECK(hipGetLastError());
     return Y3_OK;
   });
@@ -340,7 +340,7 @@ int y3_launch_conv_direct(const y3_op &op, const void *d_in, hipStream_t s, cons
   if (dry_run) return Y3_OK;
   const dim3 grid((unsigned)((a.total + 255) / 256)), block(256);
   return y3_by_dtype(op.dtype, [&](auto tag) {
-    hipLaunchKernelGGL(conv_direct_kernel<decltype(tag)>, grid, block, 0, s, a);
+    Y3_LAUNCH(conv_direct_kernel<decltype(tag)>, grid, block, 0, s, a);
     Y3_HIP_CHECK(hipGetLastError());
     return Y3_OK;
   });

@@ -668,7 +668,7 @@ extern "C" int y3_detect(const float *d_bbox, const float *d_prob, const int64_t
   a.seg = reinterpret_cast<int *>(ws + w.seg);
   a.det_count = d_det_count; a.det_tlbr = reinterpret_cast<long long *>(d_det_tlbr); a.det_prob = d_det_prob;
   a.det_cls = reinterpret_cast<long long *>(d_det_cls); a.det_row = d_det_row;
-  hipLaunchKernelGGL(detect_kernel<false>, dim3(batch), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a);
+  Y3_LAUNCH(detect_kernel<false>, dim3(batch), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -697,7 +697,7 @@ extern "C" int y3_nms(const int64_t *d_tlbr, const float *d_prob, const int64_t 
   a.seg = reinterpret_cast<int *>(ws + w.seg);
   a.det_count = d_keep_count;
   a.keep_idx = reinterpret_cast<long long *>(d_keep);
-  hipLaunchKernelGGL(detect_kernel<true>, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a);
+  Y3_LAUNCH(detect_kernel<true>, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(stream), a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }
@@ -723,10 +723,10 @@ extern "C" int y3_nms_float(const void *d_tlbr, int box_dtype, const double *d_p
   unsigned char *alive = reinterpret_cast<unsigned char *>(static_cast<char *>(d_workspace) + align_up((size_t)np2 * sizeof(int)));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (box_dtype == Y3_F32)
-    hipLaunchKernelGGL(nms_float_kernel<float>, dim3(1), dim3(kThreads), 0, s, static_cast<const float *>(d_tlbr), d_prob,
+    Y3_LAUNCH(nms_float_kernel<float>, dim3(1), dim3(kThreads), 0, s, static_cast<const float *>(d_tlbr), d_prob,
                        reinterpret_cast<const long long *>(d_cls), n, np2, iou_thresh, order, alive, reinterpret_cast<long long *>(d_keep), d_keep_count);
   else
-    hipLaunchKernelGGL(nms_float_kernel<double>, dim3(1), dim3(kThreads), 0, s, static_cast<const double *>(d_tlbr), d_prob,
+    Y3_LAUNCH(nms_float_kernel<double>, dim3(1), dim3(kThreads), 0, s, static_cast<const double *>(d_tlbr), d_prob,
                        reinterpret_cast<const long long *>(d_cls), n, np2, iou_thresh, order, alive, reinterpret_cast<long long *>(d_keep), d_keep_count);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
@@ -739,10 +739,10 @@ extern "C" int y3_cxywh_to_tlbr_float(const void *d_xywh, void *d_tlbr, int n, i
   Y3_REQUIRE(d_xywh && d_tlbr, "y3_cxywh_to_tlbr_float: null pointer argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == Y3_F32)
-    hipLaunchKernelGGL(cxywh_to_tlbr_float_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const float *>(d_xywh),
+    Y3_LAUNCH(cxywh_to_tlbr_float_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const float *>(d_xywh),
                        static_cast<float *>(d_tlbr), n, cols);
   else
-    hipLaunchKernelGGL(cxywh_to_tlbr_float_kernel<double>, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const double *>(d_xywh),
+    Y3_LAUNCH(cxywh_to_tlbr_float_kernel<double>, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const double *>(d_xywh),
                        static_cast<double *>(d_tlbr), n, cols);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
@@ -752,7 +752,7 @@ extern "C" int y3_cxywh_to_tlbr(const int64_t *d_xywh, int64_t *d_tlbr, int n, i
   Y3_REQUIRE(n >= 0 && cols >= 4, "y3_cxywh_to_tlbr: need n >= 0 and at least 4 columns");
   if (n == 0) return Y3_OK;
   Y3_REQUIRE(d_xywh && d_tlbr, "y3_cxywh_to_tlbr: null pointer argument");
-  hipLaunchKernelGGL(cxywh_to_tlbr_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+  Y3_LAUNCH(cxywh_to_tlbr_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const long long *>(d_xywh), reinterpret_cast<long long *>(d_tlbr), n, cols);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
@@ -764,7 +764,7 @@ extern "C" int y3_pack_records(const int32_t *d_det_count, const int64_t *d_det_
   Y3_REQUIRE(batch > 0 && rows > 0 && kmax > 0, "y3_pack_records: sizes must be positive");
   Y3_REQUIRE(d_det_count && d_det_tlbr && d_det_prob && d_det_cls && d_det_row && d_records,
              "y3_pack_records: null pointer argument");
-  hipLaunchKernelGGL(pack_records_kernel, dim3(batch), dim3(256), 0, static_cast<hipStream_t>(stream), d_det_count,
+  Y3_LAUNCH(pack_records_kernel, dim3(batch), dim3(256), 0, static_cast<hipStream_t>(stream), d_det_count,
                      reinterpret_cast<const long long *>(d_det_tlbr), d_det_prob,
                      reinterpret_cast<const long long *>(d_det_cls), d_det_row, rows, kmax, d_records, d_rec_count);
   Y3_HIP_CHECK(hipGetLastError());

@@ -146,10 +146,10 @@ template <typename T, int VEC>
 void launch_one(Which w, const LayerArgs &a, hipStream_t s) {
   const dim3 grid((unsigned)((a.total + 255) / 256)), block(256);
   switch (w) {
-    case MAXPOOL: hipLaunchKernelGGL((maxpool_kernel<T, VEC>), grid, block, 0, s, a); break;
-    case UPSAMPLE: hipLaunchKernelGGL((upsample_kernel<T, VEC>), grid, block, 0, s, a); break;
-    case ADD: hipLaunchKernelGGL((add_kernel<T, VEC>), grid, block, 0, s, a); break;
-    case COPY: hipLaunchKernelGGL((copy_kernel<T, VEC>), grid, block, 0, s, a); break;
+    case MAXPOOL: Y3_LAUNCH((maxpool_kernel<T, VEC>), grid, block, 0, s, a); break;
+    case UPSAMPLE: Y3_LAUNCH((upsample_kernel<T, VEC>), grid, block, 0, s, a); break;
+    case ADD: Y3_LAUNCH((add_kernel<T, VEC>), grid, block, 0, s, a); break;
+    case COPY: Y3_LAUNCH((copy_kernel<T, VEC>), grid, block, 0, s, a); break;
   }
 }
 
@@ -352,7 +352,7 @@ int y3_launch_maxpool_spp(const y3_op &a, const y3_op &b, const y3_op &c, hipStr
   const size_t lds = spp_lds_bytes(a);
   const dim3 grid((unsigned)(a.batch * p.cgroups)), block(256);
   return y3_by_dtype(a.dtype, [&](auto tag) {
-    hipLaunchKernelGGL((maxpool_spp_kernel<decltype(tag)>), grid, block, lds, s, p);
+    Y3_LAUNCH((maxpool_spp_kernel<decltype(tag)>), grid, block, lds, s, p);
     Y3_HIP_CHECK(hipGetLastError());
     return Y3_OK;
   });
@@ -418,7 +418,7 @@ extern "C" int y3_copy_bytes(const void *src, void *dst, size_t nbytes, int bloc
   }
   if (blocks < 1) blocks = 32;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(copy_bytes_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+  Y3_LAUNCH(copy_bytes_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const char *>(src), static_cast<char *>(dst), nbytes / 16, nbytes / 16 * 16, nbytes);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
@@ -428,7 +428,7 @@ extern "C" int y3_resize_bilinear_u8(const uint8_t *d_src, int src_h, int src_w,
                                      const int32_t *d_ytab, const int32_t *d_xtab, void *stream) {
   Y3_REQUIRE(d_src && d_dst && d_ytab && d_xtab, "y3_resize_bilinear_u8: null pointer argument");
   Y3_REQUIRE(src_h > 0 && src_w > 0 && dst_h > 0 && dst_w > 0, "y3_resize_bilinear_u8: empty image");
-  hipLaunchKernelGGL(resize_u8_kernel, dim3((dst_h * dst_w + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+  Y3_LAUNCH(resize_u8_kernel, dim3((dst_h * dst_w + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
                      d_src, src_h, src_w, d_dst, dst_h, dst_w, d_ytab, d_xtab);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;

@@ -142,8 +142,8 @@ int y3_launch_yolo(const y3_op &op, const void *d_in, hipStream_t s, const char 
   const size_t lds = (size_t)kPix * (op.in_ld + 1) * sizeof(float);
   const dim3 grid((unsigned)((npix + kPix - 1) / kPix));
   // bf16 networks (throughput mode) take the four-lanes-per-box form; float32 networks keep the sequential class loop
-  if (y3_is16(op.dtype) && y3_opt().decode_lanes != 1) hipLaunchKernelGGL(yolo_decode_kernel<4>, grid, dim3(384), lds, s, a);
-  else hipLaunchKernelGGL(yolo_decode_kernel<1>, grid, dim3(256), lds, s, a);
+  if (y3_is16(op.dtype) && y3_opt().decode_lanes != 1) Y3_LAUNCH(yolo_decode_kernel<4>, grid, dim3(384), lds, s, a);
+  else Y3_LAUNCH(yolo_decode_kernel<1>, grid, dim3(256), lds, s, a);
   Y3_HIP_CHECK(hipGetLastError());
   return Y3_OK;
 }

@@ -64,6 +64,7 @@ class Y3Op(ctypes.Structure):
         ("net_w", ctypes.c_float), ("net_h", ctypes.c_float),
         ("d_bbox", ctypes.c_void_p), ("d_prob", ctypes.c_void_p), ("d_cls", ctypes.c_void_p),
         ("block_idx", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("d_weight_frag", ctypes.c_void_p),
     ]
 
 
@@ -83,7 +84,7 @@ AM_DEFAULT = AM_HALO_WIDE | AM_HALO_NARROW | AM_IGEMM3_1X1_DEEP | AM_HALO_MID | 
 AM_IGEMM_ONLY = 0
 AM_HALO_ALL = AM_HALO_WIDE | AM_HALO_NARROW | AM_HALO_MID          # conv_bench: the halo kernel wherever it fits
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 # name -> (restype, argtypes); every symbol include/yolov3_hip.h declares
@@ -100,10 +101,14 @@ PROTOTYPES = {
     "y3_plan_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "y3_plan_run_timed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.POINTER(ctypes.c_float)]),
+    "y3_plan_run_profiled": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.POINTER(ctypes.c_float)]),
     "y3_plan_op_kernel": (ctypes.c_char_p, [ctypes.c_void_p, ctypes.c_int]),
     "y3_plan_op_flops": (ctypes.c_double, [ctypes.c_void_p, ctypes.c_int]),
     "y3_plan_op_bytes": (ctypes.c_double, [ctypes.c_void_p, ctypes.c_int]),
     "y3_conv_path": (ctypes.c_int, [ctypes.POINTER(Y3Op)]),
+    "y3_conv_fragment_weight_bytes": (ctypes.c_size_t, [ctypes.POINTER(Y3Op), ctypes.POINTER(Y3Options)]),
+    "y3_conv_make_fragment_weights": (ctypes.c_int, [ctypes.POINTER(Y3Op), ctypes.c_void_p, ctypes.c_void_p]),
     "y3_set_tuning": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "y3_op_run": (ctypes.c_int, [ctypes.POINTER(Y3Op), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "y3_detect_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),

@@ -263,11 +263,32 @@ class Darknet(object):
         dev = torch.device(self.device)
         return dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
 
+    def _fragment_weights(self, slot, dev, op, nbytes):
+        """The conv's weights in MFMA-fragment order (direct-weights strip kernel), ONE copy per (layer, storage type, device)
+        next to the other device layouts: every plan of the network shares it (until round 6 each plan made its own with
+        hipMalloc, ~40 MB per plan for yolov3) and ``set_params`` invalidates it with them.  Made on torch's current stream."""
+        key = (slot, "fragment", self.dtype, str(dev))
+        frag = self._dev_weights.get(key)
+        if frag is None:
+            frag = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            _hip.check(_hip.lib().y3_conv_make_fragment_weights(ctypes.byref(op), frag.data_ptr(), _hip.stream_ptr()))
+            self._dev_weights[key] = frag
+            self._made_fragments = True
+        return frag
+
     def _compile(self, batch, height, width, input_mode, options=None):
+        # every allocation and launch of plan compilation happens on the NETWORK's device, whichever is current (ADVICE r05)
+        with torch.cuda.device(self._torch_device()):
+            return self._compile_on_device(batch, height, width, input_mode, options)
+
+    def _compile_on_device(self, batch, height, width, input_mode, options=None):
         if self._params is None:
             raise RuntimeError("call load_weights() / set_params() before forward()")
         dev = self._torch_device()
         lib = _hip.lib()
+        options = options if options is not None else self.options
+        opt = _hip.options(**options) if options else None
+        self._made_fragments = False
         c_dtype, es = DTYPES[self.dtype][0], DTYPES[self.dtype][1]
         bf16 = es == 2                       # a 16-bit storage mode (bf16 or fp16)
         desc = build_plan(self.blocks, self.net_info, batch, height, width, es, reuse=not self.keep_all, fuse=self.fuse)
@@ -337,6 +358,11 @@ class Darknet(object):
                 op.d_scale = wts["scale"].data_ptr()
                 op.d_bias = wts["bias"].data_ptr()
                 cp.keep.append(wts)
+                nfrag = lib.y3_conv_fragment_weight_bytes(ctypes.byref(op), ctypes.byref(opt) if opt is not None else None)
+                if nfrag:
+                    frag = self._fragment_weights(od["slot"], dev, op, nfrag)
+                    op.d_weight_frag = frag.data_ptr()
+                    cp.keep.append(frag)
             elif kind == "maxpool":
                 op.kind = _hip.OP_MAXPOOL
                 op.ksize, op.stride = od["ksize"], od["stride"]
@@ -373,8 +399,8 @@ class Darknet(object):
                 ops[n].d_bbox, ops[n].d_prob, ops[n].d_cls = (
                     cp.bbox.data_ptr(), cp.prob.data_ptr(), cp.cls.data_ptr())
         handle = ctypes.c_void_p()
-        options = options if options is not None else self.options
-        opt = _hip.options(**options) if options else None
+        if self._made_fragments:          # plans run on other streams than the one the copies were made on
+            torch.cuda.current_stream().synchronize()
         _hip.check(lib.y3_plan_create_ex(ops, cp.n_ops, self._zero.data_ptr(),
                                          ctypes.byref(opt) if opt is not None else None, ctypes.byref(handle)))
         cp.handle = handle
@@ -407,8 +433,11 @@ class Darknet(object):
         cp = self._get_plan(batch, height, width, input_mode, slot, options)
         with torch.cuda.device(dev):
             if timed:
+                # "kernel": events bound to every dispatch (the kernels' own begin -> end); True: events recorded on the
+                # stream around every launch (includes dispatch handling) -- include/yolov3_hip.h
                 ms = (ctypes.c_float * cp.n_ops)()
-                _hip.check(lib.y3_plan_run_timed(cp.handle, x.data_ptr(), _hip.stream_ptr(), ms))
+                run = lib.y3_plan_run_profiled if timed == "kernel" else lib.y3_plan_run_timed
+                _hip.check(run(cp.handle, x.data_ptr(), _hip.stream_ptr(), ms))
                 self.last_op_ms = list(ms)
             else:
                 _hip.check(lib.y3_plan_run(cp.handle, x.data_ptr(), _hip.stream_ptr()))

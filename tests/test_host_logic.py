@@ -167,16 +167,16 @@ def test_resize_and_prepare_frames():
 def test_library_loads_and_exports_every_declared_symbol():
     from yolov3 import _hip
     lib = _hip.lib()
-    assert lib.y3_abi_version() == _hip.ABI_VERSION == 5
+    assert lib.y3_abi_version() == _hip.ABI_VERSION == 6
     with open(os.path.join(ROOT, "include", "yolov3_hip.h")) as fh:
         header = fh.read()
     declared = set(re.findall(r"\b(y3_[a-z0-9_]+)\s*\(", header))
     declared -= {"y3_op", "y3_plan"}
-    assert len(declared) >= 19
+    assert len(declared) >= 22
     for name in sorted(declared):
         assert hasattr(lib, name), "library does not export %s" % name
         assert name in _hip.PROTOTYPES, "no ctypes prototype for %s" % name
-    assert ctypes.sizeof(_hip.Y3Op) == 240 and ctypes.sizeof(_hip.Y3Options) == 64
+    assert ctypes.sizeof(_hip.Y3Op) == 248 and ctypes.sizeof(_hip.Y3Options) == 64
     opt = _hip.options(auto_mask=0)          # plan options: library defaults with overrides, no GPU needed
     assert opt.auto_mask == 0 and opt.igemm_version == 2 and opt.fuse_spp == 1 and opt.decode_lanes == 4
     with pytest.raises(KeyError):

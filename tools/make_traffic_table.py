@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM-side traffic per launch from the rocprofv3 PMC passes of tools/profile_gpu.sh -> profiles/r03_traffic.json.
+"""HBM-side traffic per launch from the rocprofv3 PMC passes of tools/profile_gpu.sh -> profiles/r06_traffic.json.
 
 FETCH_SIZE and WRITE_SIZE are collected in SEPARATE passes (TCC slots, MI355X_MICROARCH.md "rocprofv3 PMC slots"); both
 are reported in KiB.  gfx950 correction from the same guide (HBM section): FETCH_SIZE counts 64 B per 128-B request for
@@ -101,6 +101,23 @@ def kernels_of(prof, suffix):
     return out
 
 
+def trace_durations(prof):
+    """{plan kernel name: (mean us, median us, launches)} from the rocprofv3 kernel trace of the headline workload
+    (tools/profile_gpu.sh: <prof>/trace): the figure bench.py's dispatch-bound events must agree with (roofline.rocprof_avg_us)."""
+    hits = glob.glob(os.path.join(prof, "trace", "**", "*kernel_trace.csv"), recursive=True)
+    if not hits:
+        return {}
+    dur = defaultdict(list)
+    with open(hits[0]) as fh:
+        for r in csv.DictReader(fh):
+            dur[plan_name(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    out = {}
+    for k, v in dur.items():
+        v = sorted(v)
+        out[k] = (sum(v) / len(v), v[len(v) // 2], len(v))
+    return out
+
+
 def main():
     prof, out = sys.argv[1], sys.argv[2]
     with open(os.path.join(ROOT, "pytorch-yolov3_amd", "lib", "libyolov3_hip.so"), "rb") as fh:
@@ -117,6 +134,9 @@ def main():
     main_k = kernels_of(prof, "")
     if main_k is None:
         raise SystemExit("no PMC csv under %s" % prof)
+    for k, (mean_us, med_us, n) in trace_durations(prof).items():
+        if k in main_k:
+            main_k[k].update(rocprof_avg_us=round(mean_us, 2), rocprof_median_us=round(med_us, 2), rocprof_launches=n)
     table["workloads"][WORKLOADS[0]] = {"kernels": main_k}
     table["kernels"] = main_k                            # the headline workload, also at the top level
     for wk in WORKLOADS[1:]:
