@@ -122,6 +122,8 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
               // version with narrower channel tiles has four times the workgroups)
               want_ws = (am & Y3_AM_IGEMM3_1X1_DEEP) &&
                         ((am & Y3_AM_NO_SMALL_GRID) || (long long)y3_ceil_div(op.batch * op.out_h * op.out_w, 128) * y3_ceil_div(op.out_c, 128) >= y3_device_cus() / 4);
+            if ((am & Y3_AM_1X1_DW) && y3_conv1x1_dw_pays(op))
+              return y3_launch_conv1x1_dw(op, in, d_zero, s, name, dry_run, frag_w ? frag_w : op.d_weight_frag);
             if (!(am & Y3_AM_NO_WRES) && y3_conv1x1_wres_supported(op) && ((am & Y3_AM_WRES_ALWAYS) || y3_conv1x1_wres_pays(op)))
               return y3_launch_conv1x1_wres(op, in, d_zero, s, name, dry_run);
             if ((am & Y3_AM_IGEMM3_1X1_BM64) && op.ksize == 1 && op.in_c >= 256 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32) &&
@@ -182,6 +184,11 @@ int run_op(y3_plan *plan, size_t i, const void *d_input, hipStream_t s, const ch
     return y3_launch_conv_fused_stem_s2(op0, plan->ops[i + 1], in, s, name, false);
   }
   return dispatch(plan->ops[i], d_input, plan->d_zero, s, name, false, plan->frag_w[i]);
+}
+
+// the kernels that read their weights from the fragment-order copy
+bool uses_fragment_weights(const char *kernel) {
+  return strncmp(kernel, "conv_halo_dw_", 13) == 0 || strncmp(kernel, "conv1x1_dw_", 11) == 0;
 }
 
 // A private fragment-order copy of op i's weights (callers that pass no y3_op.d_weight_frag).  Made on the device that OWNS
@@ -250,12 +257,12 @@ size_t y3_conv_fragment_weight_bytes(const y3_op *op, const y3_options *options)
   OptScope scope(&o);
   const char *name = "";
   if (dispatch(*op, nullptr, nullptr, nullptr, &name, true) != Y3_OK) return 0;
-  return strncmp(name, "conv_halo_dw_", 13) == 0 ? y3_conv_halo_dw_weight_bytes(*op) : 0;
+  return uses_fragment_weights(name) ? y3_conv_halo_dw_weight_bytes(*op) : 0;
 }
 
 int y3_conv_make_fragment_weights(const y3_op *op, void *d_dst, void *stream) {
   Y3_REQUIRE(op && d_dst && op->d_weight, "y3_conv_make_fragment_weights: bad arguments");
-  Y3_REQUIRE(y3_conv_halo_dw_fits(*op), "conv block %d: not a layer of the direct-weights strip kernel", op->block_idx);
+  Y3_REQUIRE(y3_conv_halo_dw_fits(*op) || y3_conv1x1_dw_pays(*op), "conv block %d: not a layer of a direct-weights kernel", op->block_idx);
   return y3_conv_halo_dw_make_weights(*op, d_dst, static_cast<hipStream_t>(stream));
 }
 
@@ -328,7 +335,7 @@ int y3_plan_create_ex(const y3_op *ops, int n_ops, const void *d_zero, const y3_
       y3_plan_destroy(p);
       return rc;
     }
-    if (strncmp(p->kernel[i], "conv_halo_dw_", 13) == 0) {
+    if (uses_fragment_weights(p->kernel[i])) {
       // this kernel reads its weights in MFMA-fragment order: the caller's shared copy (y3_op.d_weight_frag, ABI 6), or --
       // callers that pass none -- a private copy that the plan makes here and frees when it is destroyed
       if (p->ops[i].d_weight_frag) { p->frag_w[i] = const_cast<void *>(p->ops[i].d_weight_frag); continue; }

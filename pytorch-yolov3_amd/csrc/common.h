@@ -382,6 +382,10 @@ bool y3_conv1x1_wres_supported(const y3_op &op);
 bool y3_conv1x1_wres_pays(const y3_op &op);
 int y3_launch_conv1x1_wres(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s, const char **kernel_name,
                            bool dry_run);
+// direct-weights 1x1 kernel for the short-K bottleneck layers on small maps (conv_1x1.hip; fragment-order weights)
+bool y3_conv1x1_dw_pays(const y3_op &op);
+int y3_launch_conv1x1_dw(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s, const char **kernel_name,
+                         bool dry_run, const void *frag_w);
 // 2-D patch form of the halo kernel for rows wider than 128 pixels (conv_halo.hip)
 bool y3_conv_patch_fits(const y3_op &op);
 int y3_launch_conv_patch(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s,

@@ -17,6 +17,8 @@
 // Geometry: BM = 128 pixels, BN = 128 (K <= 256) or 64 (K <= 512) channels, 4 MFMA waves (2 x 2, wave tile 64 x BN/2)
 // + 4 loader waves, LDS = K*BN*2 (weights) + 128*BN*2 (park) + 4 x 16 KiB (ring) <= 160 KiB, one workgroup per CU.
 // Workgroup b owns channel tile b % n_tiles and the pixel tiles (b / n_tiles) + j * (grid / n_tiles).
+#include <utility>
+
 #include "common.h"
 
 namespace {
@@ -204,6 +206,177 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wres_kernel(WresArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Direct-weights 1x1 kernel (round 6; 16-bit storage modes): for the SHORT-K, SMALL-MAP bottleneck layers (512 -> 256 at 38^2,
+// 1024 -> 512 at 19^2, 768 -> 256 after the route) where the tiled implicit GEMM is latency-bound: 8 or 16 K-steps with ONE
+// step of prefetch means every step waits out an L2 round trip (16.8 us per launch for 2.7 us of L2 traffic and 2.8 us of
+// MFMA work, profiles/r06_*).  Here NOTHING in the K loop waits on a barrier or on a cold load:
+//   * a workgroup owns BM (96 or 48) pixels x 256 channels = ONE tile per CU in one round (241 / 242 tiles at batch 16);
+//   * its whole activation tile -- BM pixels x ALL Cin -- is staged in LDS in the prologue (<= 144 KiB, every LDS-DMA piece in
+//     flight at once: one memory round trip instead of one per K-step);
+//   * the weight fragments come straight from global memory / L2 into registers out of the FRAGMENT-ORDER copy of the
+//     weights (conv_halo.hip: y3_conv_halo_dw_make_weights, rows y3_pair_perm'd), DEPTH K-steps ahead, as plain loads the
+//     compiler counts itself (the loop is fully unrolled: NKT = Cin / 64 is a template parameter);
+//   * eight waves, each BM pixels x 32 channels; no barrier after the prologue's; scale / bias / LeakyReLU / rounding in
+//     registers, one 16-byte store per fragment pair (a lane holds eight consecutive channels of its pixel).
+// Same K order as every other MFMA conv kernel (K ascending in steps of 32): same bits.
+struct DwArgs {
+  const char *in;
+  const char *wgt;     // fragment order: block (channel block cb, K block kb) at ((cb * (k_ld / 32) + kb) << 10)
+  const float *scale;
+  const float *bias;
+  char *out;
+  const char *zero;
+  int M, in_ld, out_ld, k_ld;
+  int n_tiles;         // Cout / 256
+  uint32_t flags;
+};
+
+template <int V>
+struct StepC { static constexpr int value = V; };
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) { (f(StepC<I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// s_waitcnt vmcnt(N) that NAMES the four registers it waits for (see dw_wait_vm in conv_halo.hip): the tie keeps the compiler
+// from moving their uses above the wait and from re-using them while the load is in flight
+template <int N>
+__device__ __forceinline__ void dw1_wait_vm(u32x4 (&w)[2][2]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]) : "n"(N) : "memory");
+}
+
+template <typename T, int BM, int NKT>
+__global__ __launch_bounds__(512, 2) void conv1x1_dw_kernel(DwArgs p) {
+  static_assert(sizeof(T) == 2 && (BM == 96 || BM == 48) && NKT % 2 == 0, "16-bit modes; 96- or 48-pixel tiles; Cin a multiple of 128");
+  constexpr int MI = BM / 16, NI = 2;
+  constexpr int RB = NKT * 128;                       // bytes of one pixel's Cin channels = LDS row pitch (a multiple of 256)
+  constexpr int PIECES = BM * RB / 1024;              // 1-KiB LDS-DMA pieces of the tile
+  constexpr int DEPTH = NKT < 4 ? NKT : 4;            // K-steps of weight fragments in flight (4 loads of 1 KiB per wave and step)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tile = y3_xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / p.n_tiles) * BM;             // channel tiles innermost: they share the activation tile in L2
+  const int n0 = (tile % p.n_tiles) * 256;
+
+  // ---- prologue: the whole activation tile.  A wave-instruction fills 1 KiB of consecutive LDS; the 16-byte chunk c of
+  // pixel row r sits at chunk position c ^ (r & 15) of its row (every row starts on bank 0: the XOR spreads a fragment
+  // read's sixteen rows over the sixteen 16-byte bank groups), applied on the SOURCE address of each lane.
+#pragma unroll
+  for (int j = 0; j < (PIECES + 7) / 8; ++j) {
+    const int i = wave + 8 * j;
+    if (i < PIECES) {
+      const int o = i * 1024 + lane * 16;
+      const int r = o / RB, cpos = (o - r * RB) >> 4;
+      const int c = cpos ^ (r & 15);
+      const long long m = (long long)m0 + r;
+      const char *src = m < p.M ? p.in + (m * p.in_ld) * 2 + c * 16 : p.zero;
+      __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(smem + i * 1024), 16, 0, 0);
+    }
+  }
+  asm volatile("" ::: "memory");
+  // ---- weight fragments of this wave's 32 channels (two 16-channel blocks), K block by K block: inline-asm loads with
+  // hand-counted waits (left to the compiler the loads sink to just above their use: every K-step then waits out an L2 round trip)
+  const uint32_t kblocks = (uint32_t)p.k_ld / 32u;
+  const uint32_t w_voff = (uint32_t)lane * 16;
+  const char *wb[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) wb[ni] = p.wgt + (((long long)((n0 + wave * 32) / 16 + ni) * kblocks) << 10);
+  u32x4 wf[DEPTH][2][NI];
+  auto load_w = [&](int kt, u32x4 (&w)[2][NI]) {     // 4 loads, in the order [kh][ni]
+    const uint32_t voff = w_voff + ((uint32_t)kt << 11);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(w[0][ni]) : "v"(voff), "s"(wb[ni]));
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(w[1][ni]) : "v"(voff), "s"(wb[ni]));
+  };
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load_w(d, wf[d]);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (DEPTH - 1)) : "memory");   // the tile (this wave's pieces) and step 0's weights landed
+  __builtin_amdgcn_s_barrier();                       // ... everyone's pieces: the only barrier of the kernel
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);       // the younger wave of each SIMD (see conv_halo_ws_kernel)
+
+  typedef const __attribute__((address_space(3))) u32x4 lds_u32x4;
+  const int a_base = (int)(size_t)(lds_void *)smem + fr * RB;
+  const int swz = fr & 15;
+  u32x4 xf[2][MI];
+  auto read_x = [&](int kt, int kh, u32x4 (&x)[MI]) {
+    const int c = ((kt * 8 + kh * 4 + fq) ^ swz) << 4;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) x[mi] = *reinterpret_cast<lds_u32x4 *>(a_base + mi * 16 * RB + c);
+  };
+  auto mma = [&](const u32x4 (&x)[MI], const u32x4 (&w)[NI]) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = y3_mfma16<T>(w[ni], x[mi], acc[mi][ni]);
+  };
+  auto interleave = [&]() {                           // one fragment read of the NEXT K-half per two MFMAs of this one
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+  };
+  read_x(0, 0, xf[0]);
+  static_for<NKT>([&](auto ktc) {
+    constexpr int kt = decltype(ktc)::value, slot = kt % DEPTH;
+    // in flight behind step kt's four loads: those of steps kt + 1 .. min(kt + DEPTH, NKT) - 1
+    constexpr int younger = 4 * ((kt + DEPTH < NKT ? kt + DEPTH : NKT) - kt - 1);
+    dw1_wait_vm<younger>(wf[slot]);
+    __builtin_amdgcn_sched_barrier(0);
+    read_x(kt, 1, xf[1]);
+    mma(xf[0], wf[slot][0]);
+    interleave();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (kt + 1 < NKT) read_x(kt + 1, 0, xf[0]);
+    mma(xf[1], wf[slot][1]);
+    interleave();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (kt + DEPTH < NKT) load_w(kt + DEPTH, wf[slot]);
+  });
+  __builtin_amdgcn_s_setprio(0);
+
+  // ---- epilogue in registers: lane (fr, fq) holds channels co .. co + 7 of pixels m0 + mi * 16 + fr
+  const int co = n0 + wave * 32 + fq * 8;             // (y3_pair_perm'd weight rows)
+  const f32x4 sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co), sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+  const f32x4 bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co), bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+  const bool leaky = p.flags & Y3_F_LEAKY;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = m0 + mi * 16 + fr;
+    float v[8];
+    y3_bn_leaky8(v, acc[mi][0], acc[mi][1], sc_lo, sc_hi, bi_lo, bi_hi, leaky);
+    if (m < p.M) *reinterpret_cast<u32x4 *>(p.out + ((long long)m * p.out_ld + co) * 2) = y3_pack8<T>(v);
+  }
+}
+
+// tile height of the direct-weights 1x1 kernel for this op (96 / 48), or 0 when it does not take it
+int dw1x1_bm(const y3_op &op) {
+  if (op.kind != Y3_OP_CONV || !y3_is16(op.dtype) || op.ksize != 1 || op.stride != 1 || op.pad != 0) return 0;
+  if (op.flags & (Y3_F_RESIDUAL | Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT)) return 0;
+  if (op.out_c % 256 != 0 || op.in_ld % 8 != 0 || op.out_ld % 8 != 0 || op.k_ld % 32 != 0 || op.k_ld < op.in_c || op.cout_pad % 32 != 0) return 0;
+  const int nkt = op.in_c / 64;
+  if (op.in_c % 128 != 0 || !(nkt == 4 || nkt == 6 || nkt == 8 || nkt == 12 || nkt == 16)) return 0;
+  const int M = op.batch * op.in_h * op.in_w, n_cu = y3_device_cus(), nt = op.out_c / 256;
+  // one round of workgroups: 96-pixel tiles where they already give every CU (nearly) one, else 48-pixel tiles
+  const long long t96 = (long long)y3_ceil_div(M, 96) * nt, t48 = (long long)y3_ceil_div(M, 48) * nt;
+  if (op.in_c * 2 * 96 <= 144 * 1024 && t96 <= n_cu && 4 * t96 >= 3 * n_cu) return 96;
+  if (op.in_c * 2 * 48 <= 144 * 1024 && t48 <= n_cu && 4 * t48 >= 3 * n_cu) return 48;
+  return 0;
+}
+
 int wres_bn(const y3_op &op) {
   if (op.in_c <= 256 && op.out_c % 128 == 0) return 128;
   if (op.in_c <= 512 && op.out_c % 64 == 0) return 64;
@@ -211,6 +384,64 @@ int wres_bn(const y3_op &op) {
 }
 
 }  // namespace
+
+// the layers the direct-weights 1x1 kernel takes: 16-bit, no shortcut, Cout a multiple of 256, Cin 256 .. 1024, and a map x
+// batch that gives (nearly) every CU exactly one tile
+bool y3_conv1x1_dw_pays(const y3_op &op) { return dw1x1_bm(op) != 0; }
+
+int y3_launch_conv1x1_dw(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s, const char **kernel_name,
+                         bool dry_run, const void *frag_w) {
+  const int bm = dw1x1_bm(op);
+  Y3_REQUIRE(bm != 0, "conv block %d: not a shape for the direct-weights 1x1 kernel", op.block_idx);
+  *kernel_name = bm == 96 ? Y3_KNAME(op.dtype, "conv1x1_dw_", "_96x256") : Y3_KNAME(op.dtype, "conv1x1_dw_", "_48x256");
+  if (dry_run) return Y3_OK;
+  void *tmp = nullptr;
+  if (!frag_w) {                                      // single-op calls without a shared copy: made here, stream-ordered
+    Y3_HIP_CHECK(hipMallocAsync(&tmp, y3_conv_halo_dw_weight_bytes(op), s));
+    const int rc = y3_conv_halo_dw_make_weights(op, tmp, s);
+    if (rc != Y3_OK) { (void)hipFreeAsync(tmp, s); return rc; }
+    frag_w = tmp;
+  }
+  DwArgs a;
+  a.in = static_cast<const char *>(d_in);
+  a.wgt = static_cast<const char *>(frag_w);
+  a.scale = op.d_scale; a.bias = op.d_bias;
+  a.out = static_cast<char *>(op.d_out);
+  a.zero = static_cast<const char *>(d_zero);
+  a.M = op.batch * op.in_h * op.in_w;
+  a.in_ld = op.in_ld; a.out_ld = op.out_ld; a.k_ld = op.k_ld;
+  a.n_tiles = op.out_c / 256;
+  a.flags = op.flags;
+  const int nkt = op.in_c / 64;
+  const int rc = y3_by_dtype16(op.dtype, [&](auto tag) {
+    typedef decltype(tag) T;
+    static Y3DeviceOnce once;
+    {
+      const int rc1 = once.run([]() -> int {
+#define Y3_DW1_ATTR(BM_, NKT_) Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_dw_kernel<T, BM_, NKT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        Y3_DW1_ATTR(96, 4); Y3_DW1_ATTR(96, 6); Y3_DW1_ATTR(96, 8); Y3_DW1_ATTR(96, 12);
+        Y3_DW1_ATTR(48, 4); Y3_DW1_ATTR(48, 6); Y3_DW1_ATTR(48, 8); Y3_DW1_ATTR(48, 12); Y3_DW1_ATTR(48, 16);
+#undef Y3_DW1_ATTR
+        return Y3_OK;
+      });
+      if (rc1 != Y3_OK) return rc1;
+    }
+    const size_t lds = (size_t)bm * op.in_c * 2;
+    const dim3 grid(y3_ceil_div(a.M, bm) * a.n_tiles);
+#define Y3_DW1_GO(BM_, NKT_) Y3_LAUNCH((conv1x1_dw_kernel<T, BM_, NKT_>), grid, dim3(512), lds, s, a)
+    if (bm == 96) {
+      if (nkt == 4) Y3_DW1_GO(96, 4); else if (nkt == 6) Y3_DW1_GO(96, 6); else if (nkt == 8) Y3_DW1_GO(96, 8); else Y3_DW1_GO(96, 12);
+    } else {
+      if (nkt == 4) Y3_DW1_GO(48, 4); else if (nkt == 6) Y3_DW1_GO(48, 6); else if (nkt == 8) Y3_DW1_GO(48, 8);
+      else if (nkt == 12) Y3_DW1_GO(48, 12); else Y3_DW1_GO(48, 16);
+    }
+#undef Y3_DW1_GO
+    Y3_HIP_CHECK(hipGetLastError());
+    return Y3_OK;
+  });
+  if (tmp) (void)hipFreeAsync(tmp, s);
+  return rc;
+}
 
 // 1x1 stride-1 bf16 conv without shortcut operand whose weight panel fits LDS
 bool y3_conv1x1_wres_supported(const y3_op &op) {

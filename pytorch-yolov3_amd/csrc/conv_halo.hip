@@ -894,6 +894,30 @@ __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int 
 // (inline-asm loads the compiler cannot see in flight): profiles/r05s_halo_dw.txt.
 // dw_wait_vm: s_waitcnt vmcnt(N) that NAMES the four registers it waits for -- the tie is what keeps the compiler from
 // moving their uses above the wait, and from re-using them while the load is in flight.
+// Y3_DW_EPI: the kernel's write-out.  0 = two channel halves of 128, each parked in LDS as float32 and written out by all
+// threads (round 5).  1 = straight from the accumulators: the fragment-order copy of the weights carries y3_pair_perm'd rows,
+// so a lane holds eight consecutive channels of its pixel per fragment pair -- scale / bias / LeakyReLU / shortcut / rounding
+// in registers, one 16-byte store per pair; no LDS, no barrier, waves finish independently.  2 = the same arithmetic in
+// registers, the ROUNDED tile (192 x 256 x 2 bytes) parked in LDS once and written out as whole 512-byte pixel rows.
+// Same arithmetic per value in all three: same bits.
+#ifndef Y3_DW_EPI
+#define Y3_DW_EPI 0
+#endif
+// Y3_DW_SMASK: 1 = border-tap masks as wave-wide lane masks in scalar registers (one v_cndmask per select, as in
+// conv_halo_ws_kernel); 0 = nine tap bits per fragment in vector registers (round 5)
+#ifndef Y3_DW_SMASK
+#define Y3_DW_SMASK 1
+#endif
+
+// Y3_DW_PF: 2 = THREE halo buffers: the images of chunks 0, 1 and 2 all go out in the prologue (the waves wait for their first
+// operands there anyway), chunk c + 2 is fetched while chunk c is computed, from chunk 1 on -- a 128-channel layer (76^2) issues NO
+// LDS-DMA from inside its K loop, a 256-channel layer (38^2) one chunk's worth instead of three (an in-loop piece costs the issuing
+// MFMA wave 60-185 cycles; without any of them a launch is 7-15 % shorter: profiles/r05s_halo_dw.txt).  1 = two buffers, chunk
+// c + 1 fetched during chunk c (round 5).
+#ifndef Y3_DW_PF
+#define Y3_DW_PF 2
+#endif
+
 template <int N, typename V>
 __device__ __forceinline__ void dw_wait_vm(V (&w)[4]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N) : "memory");
@@ -939,12 +963,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
   const int pass_hi = hi_px < hi_rows ? (int)hi_px : hi_rows;
   const char *hsrc0 = p.in + (qr * p.in_ld) * ES + kc * 16;
   const long long pass_step = (long long)RPL * p.in_ld * ES;
-  auto issue_halo_pass = [&](int chunk, int pass, bool live) {
+  auto issue_halo_pass_buf = [&](int chunk, int buf_off, int pass, bool live) {
     const bool ok = live && pass >= pass_lo && pass <= pass_hi;
     const char *src = ok ? hsrc0 + (pass * pass_step + (long long)chunk * (BKE * ES)) : p.zero;
-    char *dst = sA + (chunk & 1) * p.a_bytes + pass * (NT * 16) + wave * 1024;
+    char *dst = sA + buf_off + pass * (NT * 16) + wave * 1024;
     __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, Y3_AUX_H);
   };
+  auto issue_halo_pass = [&](int chunk, int pass, bool live) { issue_halo_pass_buf(chunk, (chunk & 1) * p.a_bytes, pass, live); };
 
   // ---- weight fragments, from the FRAGMENT-ORDER copy of the weights (y3_conv_halo_dw_layout): the 1 KiB that the 64 lanes
   // of a wave need for 16 channels x 32 K-elements is contiguous, lane l's 16 bytes at l * 16 -- a fully coalesced load (the
@@ -967,8 +992,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
   };
 
   // ---- pixel fragments ----
-  // nine-bit tap masks of the wave's eight fragments, three per register
+  // border-tap masks of the wave's six fragments: lane masks in scalar registers (Y3_DW_SMASK) or nine tap bits per fragment,
+  // three fragments per vector register
   uint32_t tm[(MI + 2) / 3] = {};
+  unsigned long long mk_top[MI], mk_bot[MI], mk_left[MI], mk_right[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const uint32_t m = (uint32_t)(m0 + wm * WM + mi * 16 + fr);
@@ -976,9 +1003,16 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
     const uint32_t r = m - img * (uint32_t)p.HW;
     const uint32_t oy = (__umulhi(r, p.mul_w) + r) >> p.sh_w;
     const uint32_t ox = r - oy * (uint32_t)p.W;
+#if Y3_DW_SMASK
+    mk_top[mi] = __builtin_amdgcn_ballot_w64(oy >= 1u);
+    mk_bot[mi] = __builtin_amdgcn_ballot_w64(oy + 1u < (uint32_t)p.H);
+    mk_left[mi] = __builtin_amdgcn_ballot_w64(ox >= 1u);
+    mk_right[mi] = __builtin_amdgcn_ballot_w64(ox + 1u < (uint32_t)p.W);
+#else
     const uint32_t vx = (ox >= 1u ? 1u : 0u) | 2u | (ox + 1u < (uint32_t)p.W ? 4u : 0u);
     const uint32_t t9 = (oy >= 1u ? vx : 0u) | (vx << 3) | (oy + 1u < (uint32_t)p.H ? vx << 6 : 0u);
     tm[mi / 3] |= t9 << (9 * (mi % 3));
+#endif
   }
   typedef const __attribute__((address_space(3))) u32x4 lds_u32x4;
   const int sA_lds = (int)(size_t)(lds_void *)sA;
@@ -995,7 +1029,17 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       int off = ap + mi * 2048;
-      if constexpr (tap != 4) off = ((tm[mi / 3] >> (9 * (mi % 3) + tap)) & 1u) ? off : zoff;
+      if constexpr (tap != 4) {
+#if Y3_DW_SMASK
+        unsigned long long ok = ky == 0 ? mk_top[mi] : (ky == 2 ? mk_bot[mi] : ~0ull);
+        if constexpr (kx == 0) ok &= mk_left[mi];
+        if constexpr (kx == 2) ok &= mk_right[mi];
+        const int real = off;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(off) : "v"(zoff), "v"(real), "s"(ok));
+#else
+        off = ((tm[mi / 3] >> (9 * (mi % 3) + tap)) & 1u) ? off : zoff;
+#endif
+      }
       sel[mi] = off;
     }
   };
@@ -1013,10 +1057,25 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
   // ---- prologue: halo of chunk 0, both K-halves of step 0's weights, step 0's first pixel fragments ----
   u32x4 wf[3][NI];
   u32x4 xf[MI];
+#if Y3_DW_PF == 2
+  // chunk 0's image and step 0's weights first, then the images of chunks 1 and 2 (three buffers): the wait below leaves those
+  // 2 NA pieces in flight -- they land under the first K-step
+#pragma unroll 1
+  for (int pass = 0; pass < NA; ++pass) issue_halo_pass_buf(0, 0, pass, true);
+  load_w0(wf[0], b_voff);
+  load_w1(wf[2], b_voff);
+#pragma unroll 1
+  for (int pass = 0; pass < 2 * NA; ++pass) {         // (rolled: unrolled, the 3 NA addresses alone cost 30 registers -> spills)
+    const int c = pass < NA ? 1 : 2;
+    issue_halo_pass_buf(c, c * p.a_bytes, pass < NA ? pass : pass - NA, c < p.nchunks);
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NA) : "memory");
+#else
   for (int pass = 0; pass < p.na; ++pass) issue_halo_pass(0, pass, true);
   load_w0(wf[0], b_voff);
   load_w1(wf[2], b_voff);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   __builtin_amdgcn_s_barrier();
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);       // the younger wave of each SIMD (see conv_halo_ws_kernel)
   frag_addrs(TapC<0>{}, 0);
@@ -1029,40 +1088,75 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
   // Pixel fragments: eight registers sets of one fragment; a half (four fragments) is re-read for the next K-half as soon as
   // the MFMAs that use it are issued.  (A second register set with every read a whole K-half ahead measured 2 % slower: the
   // SIMD's other wave covers the read latency already, r05s.)
+#if Y3_DW_PF == 2
+  int buf_cur = 0, buf_nxt = p.a_bytes, buf_fill = 2 * p.a_bytes;   // halo buffers of chunk, chunk + 1, chunk + 2 (byte offsets)
+  unsigned long long fill_mask = 0ull;
+#endif
   auto kstep = [&](auto tapc, int chunk) {
     constexpr int tap = decltype(tapc)::value, S = tap % 3, tap_n = tap == 8 ? 0 : tap + 1;
+    // the very first step of the tile (tap 0 of chunk 0): the prologue's 2 NA pieces of chunks 1 and 2 may still be in flight
+    // behind its weights -- the same wait with a larger count (a wave-uniform branch around ONE s_waitcnt, not a second copy of the step)
+    auto wait8 = [&](u32x4 (&w)[NI]) {
+      if constexpr (Y3_DW_PF == 2 && tap == 0) {
+        if (chunk == 0) dw_wait_vm<8 + 2 * NA>(w);
+        else dw_wait_vm<8>(w);
+      } else {
+        dw_wait_vm<8>(w);
+      }
+    };
     const int chunk_n = tap == 8 ? chunk + 1 : chunk;
     const uint32_t voff_n = b_voff + ((uint32_t)(tap_n * (p.Cin / 32) + chunk_n * 2) << 10);
     load_w0(wf[(S + 1) % 3], voff_n);
+#if Y3_DW_PF == 2
+    // one 64-row pass of the image of chunk + 2 per step, into the buffer chunk - 1 vacated -- only while there is such a chunk
+    // (a wave-uniform branch: nothing is issued otherwise)
+    // NOT behind a branch (a wave-uniform test here costs the kernel 20-30 registers -> scratch; r05 saw the same): the piece is
+    // issued with EXEC cleared while there is nothing to fetch -- a vector-memory instruction with EXEC = 0 is dropped by the
+    // sequencer, no request reaches the memory path.  (The LDS destination of an LDS-DMA piece is M0 + lane * 16.)
+    if constexpr (tap < NA) {
+      const bool ok = tap >= pass_lo && tap <= pass_hi;
+      const char *src = ok ? hsrc0 + (tap * pass_step + (long long)(chunk + 2) * (BKE * ES)) : p.zero;
+      const int dst = sA_lds + buf_fill + tap * (NT * 16) + wave * 1024;
+      unsigned long long saved;
+      asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %3, off\n\ts_mov_b64 exec, %0"
+                   : "=&s"(saved) : "s"(fill_mask), "s"(dst), "v"(src) : "memory", "m0", "scc");
+    }
+#else
     // one 64-row pass of the next chunk's halo per step while there are any (4-6 of the 9 steps; a piece costs the issuing
     // wave 60-185 cycles: without them the launch is 10-15 % shorter, so none is issued that is not needed)
     // (NA = the number of passes, a template parameter: 4 .. 6 covers every map the wave-specialised kernel takes, rows of up
     // to 94 pixels; as a run-time test the branch costs registers the kernel does not have -- 96 bytes of scratch, 15 % slower)
     if constexpr (tap < NA) issue_halo_pass(chunk + 1, tap, chunk + 1 < p.nchunks);
+#endif
     // younger than wf[S]'s loads: 4 loads of the previous step + 4 of this one for certain, up to two halo pieces maybe --
     // the count that is always safe is 8
-    dw_wait_vm<8>(wf[S]);
+    wait8(wf[S]);
     mma_half(xf, 0, wf[S]);
     read_half(xf, 0, 64);
     mma_half(xf, MH, wf[S]);
     read_half(xf, MH, 64);
     __builtin_amdgcn_sched_barrier(0);
     load_w1(wf[S], voff_n);
-    dw_wait_vm<8>(wf[(S + 2) % 3]);                   // younger for certain: 4 + 4 loads of this step
+    wait8(wf[(S + 2) % 3]);                           // younger for certain: 4 + 4 loads of this step
     mma_half(xf, 0, wf[(S + 2) % 3]);
+#if Y3_DW_PF == 2
+    const int a_off_n = tap == 8 ? buf_nxt : buf_cur;
+#else
+    const int a_off_n = (chunk_n & 1) * p.a_bytes;
+#endif
     if constexpr (tap == 8) {
-      // chunk boundary: the next step reads the other halo buffer.  Its pieces (the youngest was issued before the last
+      // chunk boundary: the next step reads the next halo buffer.  Its pieces (the youngest was issued before the last
       // four loads) have landed for this wave ... and, after the barrier, for all; the barrier also tells that everyone
-      // is done with the buffer that the next chunk's pieces will overwrite -- EXCEPT the second half of this K-half's
+      // is done with the buffer that the coming pieces will overwrite -- EXCEPT the second half of this K-half's
       // fragments, which are in registers already
       mma_half(xf, MH, wf[(S + 2) % 3]);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      frag_addrs(TapC<tap_n>{}, (chunk_n & 1) * p.a_bytes);
+      frag_addrs(TapC<tap_n>{}, a_off_n);
       read_half(xf, 0, 0);
       read_half(xf, MH, 0);
     } else {
-      frag_addrs(TapC<tap_n>{}, (chunk_n & 1) * p.a_bytes);
+      frag_addrs(TapC<tap_n>{}, a_off_n);
       read_half(xf, 0, 0);
         mma_half(xf, MH, wf[(S + 2) % 3]);
         read_half(xf, MH, 0);
@@ -1071,9 +1165,15 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
   };
 #pragma unroll 1
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+#if Y3_DW_PF == 2
+    fill_mask = (chunk >= 1 && chunk + 2 < p.nchunks) ? ~0ull : 0ull;   // is there a chunk + 2 to fetch during this chunk
+#endif
     kstep(TapC<0>{}, chunk); kstep(TapC<1>{}, chunk); kstep(TapC<2>{}, chunk);
     kstep(TapC<3>{}, chunk); kstep(TapC<4>{}, chunk); kstep(TapC<5>{}, chunk);
     kstep(TapC<6>{}, chunk); kstep(TapC<7>{}, chunk); kstep(TapC<8>{}, chunk);
+#if Y3_DW_PF == 2
+    { const int t = buf_cur; buf_cur = buf_nxt; buf_nxt = buf_fill; buf_fill = t; }
+#endif
   }
   __builtin_amdgcn_s_setprio(0);
   // The run-ahead loads of the step after the last are still in flight and nobody uses their data: without the register ties
@@ -1084,6 +1184,67 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
   dw_wait_vm<0>(wf[1]);
   dw_wait_vm<0>(wf[2]);
 
+  const bool leaky = p.flags & Y3_F_LEAKY;
+  const bool has_res = p.flags & Y3_F_RESIDUAL;
+#if Y3_DW_EPI != 0
+  // ---- epilogue in registers (Y3_DW_EPI 1 / 2).  The weight rows were laid out with y3_pair_perm: after both fragments of a
+  // pair (ni = 2 pr, 2 pr + 1) lane (fr, fq) holds channels  n0 + wn * 64 + pr * 32 + 8 fq .. + 7  of pixel  m0 + wm * 96 +
+  // mi * 16 + fr.  All twelve shortcut loads of the wave (16 bytes each, the registers of the weight / pixel fragments are
+  // free now) go out first, then per pair: scale / bias, LeakyReLU, + shortcut, round, store.
+  {
+    constexpr int NP = NI / 2;
+    const int co0 = n0 + wn * 64 + fq * 8;
+    const int mrow = m0 + wm * WM + fr;
+    u32x4 resv[NP][MI];
+    if (has_res) {
+#pragma unroll
+      for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int m = mrow + mi * 16;
+          const char *rp = p.res + ((long long)m * p.res_ld + co0 + pr * 32) * ES;
+          resv[pr][mi] = m < p.M ? *reinterpret_cast<const u32x4 *>(rp) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+#if Y3_DW_EPI == 2
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                     // nobody reads the halo any more: LDS holds the rounded output tile
+    char *sO = smem;                                  // [192 pixels][512 bytes], 16-byte pieces XOR-swizzled by pixel
+#endif
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr) {
+      const int co = co0 + pr * 32;
+      const f32x4 sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co), sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+      const f32x4 bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co), bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m = mrow + mi * 16;
+        float v[8];
+        y3_bn_leaky8(v, acc[mi][2 * pr], acc[mi][2 * pr + 1], sc_lo, sc_hi, bi_lo, bi_hi, leaky);
+        if (has_res) y3_add8<T>(v, resv[pr][mi]);
+        const u32x4 o = y3_pack8<T>(v);
+#if Y3_DW_EPI == 1
+        if (m < p.M) *reinterpret_cast<u32x4 *>(reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + co) = o;
+#else
+        const int pl = wm * WM + mi * 16 + fr;        // piece index inside the pixel's 512 bytes: (channel - n0) / 8
+        *reinterpret_cast<u32x4 *>(sO + pl * 512 + ((((co - n0) >> 3) ^ (pl & 31)) << 4)) = o;
+#endif
+      }
+    }
+#if Y3_DW_EPI == 2
+    __syncthreads();
+    // 512 threads x 16 bytes = 16 pixel rows of 512 bytes per pass: every wave writes 2 KiB of consecutive output bytes
+    const int piece = tid & 31;
+#pragma unroll
+    for (int j = 0; j < BM / 16; ++j) {
+      const int pl = (tid >> 5) + j * 16;
+      const int m = m0 + pl;
+      const u32x4 o = *reinterpret_cast<const u32x4 *>(sO + pl * 512 + ((piece ^ (pl & 31)) << 4));
+      if (m < p.M) *reinterpret_cast<u32x4 *>(reinterpret_cast<T *>(p.out) + (long long)m * p.out_ld + n0 + piece * 8) = o;
+    }
+#endif
+  }
+#else
   // ---- epilogue: two channel halves of 128; the four waves that own a half park it, all 512 threads write it out.  A half's
   // scale / bias / shortcut reads are issued one stage ahead: the first half's before the barrier that ends the K loop, the
   // second half's before the first half's write-out (all at once, before the loop's end, they cost 48 registers: spills) ----
@@ -1091,8 +1252,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
   constexpr int RPP = NT / 16;                        // 32 pixel rows per pass
   constexpr int WR = BM / RPP;                        // 6
   float *sC = reinterpret_cast<float *>(smem);
-  const bool leaky = p.flags & Y3_F_LEAKY;
-  const bool has_res = p.flags & Y3_F_RESIDUAL;
   const int oc_mine = tid & 15;
   f32x4 sc_lo[2], sc_hi[2], bi_lo[2], bi_hi[2];
   u32x4 resv[2][WR];
@@ -1119,7 +1278,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
     if ((wn >> 1) == h) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
-        const int cl = (wn & 1) * 64 + ni * 16 + fq * 4;
+        const int cl = (wn & 1) * 64 + (ni >> 1) * 32 + fq * 8 + (ni & 1) * 4;   // y3_pair_perm'd weight rows
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           const int pl = wm * WM + mi * 16 + fr;
@@ -1145,6 +1304,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
     }
     if (h == 0) __syncthreads();                      // the first half is out of LDS before the second is parked
   }
+#endif
 }
 
 // n / d == (umulhi(n, mul) + n) >> sh for 0 <= n < 2^31 (round-up method, d >= 1)
@@ -1254,7 +1414,10 @@ __global__ __launch_bounds__(256) void weights_to_fragment_order_kernel(const u3
   const long long cb = blk / kblocks;
   const int kb = (int)(blk - cb * kblocks);
   const int fr = l & 15, fq = l >> 4;
-  dst[i] = src[((cb * 16 + fr) * kblocks + kb) * 4 + fq];   // row (cb * 16 + fr): kblocks * 4 pieces of 16 bytes
+  // MFMA row fr of channel block cb carries channel y3_pair_perm(cb * 16 + fr): after both fragments of a pair a lane holds
+  // eight consecutive channels of its pixel (the epilogues work in registers: conv_halo_dw_kernel, conv1x1_dw_kernel)
+  const long long ch = (long long)y3_pair_perm((int)(cb * 16 + fr));
+  dst[i] = src[(ch * kblocks + kb) * 4 + fq];   // row ch: kblocks * 4 pieces of 16 bytes
 }
 
 constexpr int DW_BM = 192;
@@ -1280,7 +1443,7 @@ int launch_halo_dw(const HaloArgs &a0, hipStream_t s) {
   a.na = y3_ceil_div(a.hr + 2, 64);                   // + the two zero rows
   a.hr_pad = a.na * 64;
   a.a_bytes = a.hr_pad * 128;
-  size_t lds = (size_t)2 * a.a_bytes;
+  size_t lds = (size_t)(Y3_DW_PF == 2 ? 3 : 2) * a.a_bytes;   // (three halo images: chunks c, c + 1, c + 2)
   if (lds < (size_t)DW_BM * 128 * 4) lds = (size_t)DW_BM * 128 * 4;
   Y3_REQUIRE(a.na >= 4 && a.na <= 6 && lds <= 160 * 1024, "direct-weights halo kernel: row width %d does not fit", a.W);
   a.m_tiles = y3_ceil_div(a.M, DW_BM);
@@ -1358,7 +1521,7 @@ bool y3_conv_halo_ws_fits(const y3_op &op) {
 // direct-weights strip kernel (round 5): 16-bit modes, Cout a multiple of 256, rows of up to 94 pixels (four to six 64-row halo
 // passes per chunk: the maps the wave-specialised kernel takes)
 bool y3_conv_halo_dw_fits(const y3_op &op) {
-  if (!y3_conv_halo_eligible(op) || !y3_is16(op.dtype) || op.out_c % 256 != 0 || op.cout_pad % 16 != 0 || op.k_ld % 32 != 0) return false;
+  if (!y3_conv_halo_eligible(op) || !y3_is16(op.dtype) || op.out_c % 256 != 0 || op.cout_pad % 32 != 0 || op.k_ld % 32 != 0) return false;
   const int na = y3_ceil_div(DW_BM + 2 * op.in_w + 4, 64);
   return na >= 4 && na <= 6 && y3_conv_halo_ws_fits(op);
 }

@@ -187,6 +187,7 @@ class Darknet(object):
         if len(params) != len(self._convs):
             raise ValueError("expected {} conv parameter sets, got {}".format(len(self._convs), len(params)))
         self._params = params
+        self.__dict__.pop("_f16_range_checked", None)
         self.__dict__.pop("_pipelines", None)      # (their plans hold the old weights' addresses)
         self._dev_weights = {}
         for plan in self._plans.values():
@@ -442,6 +443,16 @@ class Darknet(object):
             else:
                 _hip.check(lib.y3_plan_run(cp.handle, x.data_ptr(), _hip.stream_ptr()))
         self._last_plan = cp
+        if self.dtype == "fp16" and not timed and not self.__dict__.get("_f16_range_checked"):
+            # IEEE half storage has no saturation: a stored activation above 65504 becomes inf and NaN downstream.
+            # The procedural weights stay below 10 (profiles/r05_f16_overflow_audit.txt); real checkpoints are checked here, on
+            # the FIRST forward after new parameters (one synchronising reduction, then never again): scores that are not finite
+            # mean the half range was exceeded -- warn and point at bf16, which has float32's range.
+            self._f16_range_checked = True
+            if not bool(torch.isfinite(cp.prob).all()):     # (box sizes may be inf in any dtype: exp(tw) is unclamped, darknet.py:89-101)
+                import warnings
+                warnings.warn("dtype='fp16': non-finite outputs -- an activation exceeded the IEEE half range (65504); "
+                              "use dtype='bf16' (float32 range) or 'float32' for these weights", RuntimeWarning)
         if fresh:
             return {"bbox_xywh": cp.bbox.clone(), "class_prob": cp.prob.clone(), "class_idx": cp.cls.clone()}
         return {"bbox_xywh": cp.bbox, "class_prob": cp.prob, "class_idx": cp.cls}

@@ -31,11 +31,23 @@ def _device(device=None):
 
 
 def _float_kind(dtype):
-    """numpy float dtype -> (C ABI element type, numpy dtype the kernel computes in): float32 stays float32 (numpy computes
-    float32 arrays in float32), float64 and wider / narrower floats go through float64 resp. float32."""
+    """numpy float dtype -> (C ABI element type, numpy dtype the kernel computes in): float32 and float64 boxes are computed
+    in their own type, step by step as numpy does.  float16 boxes are REFUSED: the reference would compute areas and IoU in
+    float16 (a 300 x 300 box's area overflows to inf there), which the float32 kernel would silently not reproduce
+    (ADVICE r05); wider floats (longdouble) go through float64."""
+    if dtype == np.float16:
+        raise TypeError("float16 boxes are not supported: numpy would compute areas and IoU in float16 (overflow above 255 x 255 "
+                        "pixels); pass float32 / float64 or integer boxes")
     if dtype == np.float64 or dtype.itemsize > 8:
         return _hip.Y3_F64, np.float64
     return _hip.Y3_F32, np.float32
+
+
+def _require_finite(arr, what):
+    """NaN / inf coordinates: numpy's maximum / minimum propagate NaN and ``inf // 2`` is NaN there, the device kernels
+    compare and floor instead -- refuse rather than return a different keep set."""
+    if not np.isfinite(arr).all():
+        raise ValueError("{} holds non-finite values (NaN / inf): not supported on float boxes".format(what))
 
 
 def cxywh_to_tlbr(bbox_xywh):
@@ -49,6 +61,7 @@ def cxywh_to_tlbr(bbox_xywh):
         if arr.shape[0] == 0:
             return arr.copy()
         code, work = _float_kind(arr.dtype)
+        _require_finite(arr, "bbox_xywh")
         dev = _device()
         src = torch.from_numpy(np.ascontiguousarray(arr, dtype=work)).to(dev)
         dst = torch.empty_like(src)
@@ -110,6 +123,7 @@ def non_max_suppression(bbox_tlbr, class_prob, class_idx=None, iou_thresh=0.3):
 
 def _nms_float(barr, class_prob, class_idx, iou_thresh):
     code, work = _float_kind(barr.dtype)
+    _require_finite(barr[:, :4], "bbox_tlbr")
     boxes = np.ascontiguousarray(barr[:, :4], dtype=work)
     prob = np.ascontiguousarray(class_prob, dtype=np.float64)
     n = boxes.shape[0]

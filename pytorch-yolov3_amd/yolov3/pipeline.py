@@ -206,6 +206,11 @@ class Pipeline(object):
                 self.free_ev[j].record(cur)
             det = self.dets[d]
             det.run(out, self.full_hw if orig_hw is None else orig_hw, self.prob_thresh, self.nms_iou_thresh)
+            if n_frames is not None and int(n_frames) < self.batch:
+                # padding frames of a short last batch (copies of real frames, or whatever the staging buffer held) must not
+                # count: their detections are dropped here, BEFORE the records are packed and gathered, so that they can neither
+                # trigger the "some frame kept more than kmax boxes" second fetch / second collective nor reach another rank
+                det.count[int(n_frames):].zero_()
             g = self.gathers[d]
             rec = g.run(det)
             if to_host:
@@ -231,8 +236,12 @@ class Pipeline(object):
         return self.host_rec[d].numpy()
 
     def results(self, ticket, return_rows=False):
-        """Per frame of THIS rank's batch: ``[bbox_tlbr int64 (K,4), class_prob f32 (K,), class_idx int64 (K,)]`` (+ prediction
-        rows), the contract of ``inference()``.  A frame that kept more than ``kmax`` boxes is fetched again in full."""
+        """``[bbox_tlbr int64 (K,4), class_prob f32 (K,), class_idx int64 (K,)]`` (+ prediction rows) per frame, the contract of
+        ``inference()``.  One rank: the ``n_frames`` real frames of this batch.  Under a process group (``world`` > 1): the
+        frames of ALL ranks in rank order, ``world * batch`` lists (padding frames of a short batch come back empty).  A frame
+        that kept more than ``kmax`` boxes is fetched again in full -- under a process group that second fetch is a second
+        all-gather, i.e. a COLLECTIVE: every rank must call ``results()`` (not just ``records()``) for the same tickets in the
+        same order, or the job hangs.  All ranks take the same branch because the first gather carried every frame's true count."""
         rec = self.records(ticket)
         k, d = ticket % self.in_flight, ticket % self.max_open
         mine = rec[:self.batch] if self.world == 1 else rec     # single rank: all frames are ours

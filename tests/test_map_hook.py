@@ -17,7 +17,9 @@ import pytest
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 WEIGHTS = os.environ.get("Y3_WEIGHTS")
-ANNOTATIONS = os.environ.get("Y3_COCO_ANNOTATIONS", "/root/reference/sample_dataset/sample.json")
+# the nine images' COCO annotations: a committed fixture (tools/make_goldens.py g10 copies the reference's data file
+# sample_dataset/sample.json): only the weights and pycocotools are missing on the GPU boxes
+ANNOTATIONS = os.environ.get("Y3_COCO_ANNOTATIONS", os.path.join(ROOT, "tests", "golden", "sample_annotations.json"))
 EXPECTED_MAP = 0.33983872        # tests/test_inference.py:28-32
 ATOL = 0.0015                    # tests/test_inference.py:87
 
@@ -75,3 +77,9 @@ def test_map_hook_is_wired_to_the_package_api():
     assert list(inspect.signature(coco_util.match_ids).parameters)[:2] == ["dataset", "reference_dataset"]
     assert list(inspect.signature(yolov3.inference).parameters)[:2] == ["net", "images"]
     assert EXPECTED_MAP == 0.33983872 and ATOL == 0.0015
+    # the ground truth is a committed fixture: nine images, every file name one of the golden JPEGs
+    from golden_util import SAMPLE_IMAGES
+    with open(ANNOTATIONS) as fh:
+        truth = json.load(fh)
+    assert sorted(im["file_name"] for im in truth["images"]) == sorted(SAMPLE_IMAGES)
+    assert len(truth["annotations"]) == 81 and len(truth["categories"]) == 80

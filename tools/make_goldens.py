@@ -623,8 +623,21 @@ def g9_coco_export():
     print("G9 ok", len(dataset["annotations"]), "annotations")
 
 
+def g10_sample_annotations():
+    """The COCO ground truth of the nine sample images that the reference's accuracy test evaluates against
+    (/root/reference/tests/test_inference.py:61-87 reads sample_dataset/sample.json): a DATA file the reference's tests hold,
+    copied as a fixture (same JSON content, compact separators) so that tests/test_map_hook.py needs only the real weights and
+    pycocotools."""
+    with open(os.path.join("/root/reference", "sample_dataset", "sample.json")) as fh:
+        truth = json.load(fh)
+    out = os.path.join(GOLD, "sample_annotations.json")
+    with open(out, "w") as fh:
+        json.dump(truth, fh, separators=(",", ":"), sort_keys=True)
+    print("G10 ok", len(truth["images"]), "images", len(truth["annotations"]), "annotations", os.path.getsize(out), "bytes")
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"g2", "g3", "g4", "g5", "g6", "g7", "g7p", "g9"}
+    which = set(sys.argv[1:]) or {"g2", "g3", "g4", "g5", "g6", "g7", "g7p", "g9", "g10"}
     torch.manual_seed(0)
     if "g2" in which:
         g2_parse_config()
@@ -638,6 +651,8 @@ if __name__ == "__main__":
         g6f_nms_float()
     if "g9" in which:
         g9_coco_export()
+    if "g10" in which:
+        g10_sample_annotations()
     if "g7p" in which:
         for model in MODELS:
             g7p_bench_regime(model)
