@@ -909,15 +909,11 @@ __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int 
 #define Y3_DW_SMASK 1
 #endif
 
-// Y3_DW_PF: 2 = THREE halo buffers: the images of chunks 0, 1 and 2 all go out in the prologue (the waves wait for their first
-// operands there anyway), chunk c + 2 is fetched while chunk c is computed, from chunk 1 on -- a 128-channel layer (76^2) issues NO
-// LDS-DMA from inside its K loop, a 256-channel layer (38^2) one chunk's worth instead of three (an in-loop piece costs the issuing
-// MFMA wave 60-185 cycles; without any of them a launch is 7-15 % shorter: profiles/r05s_halo_dw.txt).  1 = two buffers, chunk
-// c + 1 fetched during chunk c (round 5).
-#ifndef Y3_DW_PF
-#define Y3_DW_PF 2
-#endif
-
+// Tried in round 6 and removed (profiles/r06_dw_epilogue.txt): THREE halo buffers with the images of chunks 0, 1 and 2 all issued in
+// the prologue and chunk c + 2 fetched during chunk c (EXEC-masked inline-asm LDS-DMA, so that a 128-channel layer issues none
+// from inside its K loop and a 256-channel layer one chunk's worth instead of three).  -8 % at 38^2, -12 % at 76^2, -5 % end to
+// end: all 256 CUs start together and the prologue's burst (144 instead of 48 KiB per CU) is memory-bound; the loads of the
+// second K-step cannot complete before it (vmcnt retires in order).  Spread over the K loop the same bytes cost less.
 template <int N, typename V>
 __device__ __forceinline__ void dw_wait_vm(V (&w)[4]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "n"(N) : "memory");
@@ -963,13 +959,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
   const int pass_hi = hi_px < hi_rows ? (int)hi_px : hi_rows;
   const char *hsrc0 = p.in + (qr * p.in_ld) * ES + kc * 16;
   const long long pass_step = (long long)RPL * p.in_ld * ES;
-  auto issue_halo_pass_buf = [&](int chunk, int buf_off, int pass, bool live) {
+  auto issue_halo_pass = [&](int chunk, int pass, bool live) {
     const bool ok = live && pass >= pass_lo && pass <= pass_hi;
     const char *src = ok ? hsrc0 + (pass * pass_step + (long long)chunk * (BKE * ES)) : p.zero;
-    char *dst = sA + buf_off + pass * (NT * 16) + wave * 1024;
+    char *dst = sA + (chunk & 1) * p.a_bytes + pass * (NT * 16) + wave * 1024;
     __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)dst, 16, 0, Y3_AUX_H);
   };
-  auto issue_halo_pass = [&](int chunk, int pass, bool live) { issue_halo_pass_buf(chunk, (chunk & 1) * p.a_bytes, pass, live); };
 
   // ---- weight fragments, from the FRAGMENT-ORDER copy of the weights (y3_conv_halo_dw_layout): the 1 KiB that the 64 lanes
   // of a wave need for 16 channels x 32 K-elements is contiguous, lane l's 16 bytes at l * 16 -- a fully coalesced load (the
@@ -1057,25 +1052,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
   // ---- prologue: halo of chunk 0, both K-halves of step 0's weights, step 0's first pixel fragments ----
   u32x4 wf[3][NI];
   u32x4 xf[MI];
-#if Y3_DW_PF == 2
-  // chunk 0's image and step 0's weights first, then the images of chunks 1 and 2 (three buffers): the wait below leaves those
-  // 2 NA pieces in flight -- they land under the first K-step
-#pragma unroll 1
-  for (int pass = 0; pass < NA; ++pass) issue_halo_pass_buf(0, 0, pass, true);
-  load_w0(wf[0], b_voff);
-  load_w1(wf[2], b_voff);
-#pragma unroll 1
-  for (int pass = 0; pass < 2 * NA; ++pass) {         // (rolled: unrolled, the 3 NA addresses alone cost 30 registers -> spills)
-    const int c = pass < NA ? 1 : 2;
-    issue_halo_pass_buf(c, c * p.a_bytes, pass < NA ? pass : pass - NA, c < p.nchunks);
-  }
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NA) : "memory");
-#else
   for (int pass = 0; pass < p.na; ++pass) issue_halo_pass(0, pass, true);
   load_w0(wf[0], b_voff);
   load_w1(wf[2], b_voff);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
   __builtin_amdgcn_s_barrier();
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);       // the younger wave of each SIMD (see conv_halo_ws_kernel)
   frag_addrs(TapC<0>{}, 0);
@@ -1088,75 +1068,40 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
   // Pixel fragments: eight registers sets of one fragment; a half (four fragments) is re-read for the next K-half as soon as
   // the MFMAs that use it are issued.  (A second register set with every read a whole K-half ahead measured 2 % slower: the
   // SIMD's other wave covers the read latency already, r05s.)
-#if Y3_DW_PF == 2
-  int buf_cur = 0, buf_nxt = p.a_bytes, buf_fill = 2 * p.a_bytes;   // halo buffers of chunk, chunk + 1, chunk + 2 (byte offsets)
-  unsigned long long fill_mask = 0ull;
-#endif
   auto kstep = [&](auto tapc, int chunk) {
     constexpr int tap = decltype(tapc)::value, S = tap % 3, tap_n = tap == 8 ? 0 : tap + 1;
-    // the very first step of the tile (tap 0 of chunk 0): the prologue's 2 NA pieces of chunks 1 and 2 may still be in flight
-    // behind its weights -- the same wait with a larger count (a wave-uniform branch around ONE s_waitcnt, not a second copy of the step)
-    auto wait8 = [&](u32x4 (&w)[NI]) {
-      if constexpr (Y3_DW_PF == 2 && tap == 0) {
-        if (chunk == 0) dw_wait_vm<8 + 2 * NA>(w);
-        else dw_wait_vm<8>(w);
-      } else {
-        dw_wait_vm<8>(w);
-      }
-    };
     const int chunk_n = tap == 8 ? chunk + 1 : chunk;
     const uint32_t voff_n = b_voff + ((uint32_t)(tap_n * (p.Cin / 32) + chunk_n * 2) << 10);
     load_w0(wf[(S + 1) % 3], voff_n);
-#if Y3_DW_PF == 2
-    // one 64-row pass of the image of chunk + 2 per step, into the buffer chunk - 1 vacated -- only while there is such a chunk
-    // (a wave-uniform branch: nothing is issued otherwise)
-    // NOT behind a branch (a wave-uniform test here costs the kernel 20-30 registers -> scratch; r05 saw the same): the piece is
-    // issued with EXEC cleared while there is nothing to fetch -- a vector-memory instruction with EXEC = 0 is dropped by the
-    // sequencer, no request reaches the memory path.  (The LDS destination of an LDS-DMA piece is M0 + lane * 16.)
-    if constexpr (tap < NA) {
-      const bool ok = tap >= pass_lo && tap <= pass_hi;
-      const char *src = ok ? hsrc0 + (tap * pass_step + (long long)(chunk + 2) * (BKE * ES)) : p.zero;
-      const int dst = sA_lds + buf_fill + tap * (NT * 16) + wave * 1024;
-      unsigned long long saved;
-      asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %3, off\n\ts_mov_b64 exec, %0"
-                   : "=&s"(saved) : "s"(fill_mask), "s"(dst), "v"(src) : "memory", "m0", "scc");
-    }
-#else
     // one 64-row pass of the next chunk's halo per step while there are any (4-6 of the 9 steps; a piece costs the issuing
     // wave 60-185 cycles: without them the launch is 10-15 % shorter, so none is issued that is not needed)
     // (NA = the number of passes, a template parameter: 4 .. 6 covers every map the wave-specialised kernel takes, rows of up
     // to 94 pixels; as a run-time test the branch costs registers the kernel does not have -- 96 bytes of scratch, 15 % slower)
     if constexpr (tap < NA) issue_halo_pass(chunk + 1, tap, chunk + 1 < p.nchunks);
-#endif
     // younger than wf[S]'s loads: 4 loads of the previous step + 4 of this one for certain, up to two halo pieces maybe --
     // the count that is always safe is 8
-    wait8(wf[S]);
+    dw_wait_vm<8>(wf[S]);
     mma_half(xf, 0, wf[S]);
     read_half(xf, 0, 64);
     mma_half(xf, MH, wf[S]);
     read_half(xf, MH, 64);
     __builtin_amdgcn_sched_barrier(0);
     load_w1(wf[S], voff_n);
-    wait8(wf[(S + 2) % 3]);                           // younger for certain: 4 + 4 loads of this step
+    dw_wait_vm<8>(wf[(S + 2) % 3]);                   // younger for certain: 4 + 4 loads of this step
     mma_half(xf, 0, wf[(S + 2) % 3]);
-#if Y3_DW_PF == 2
-    const int a_off_n = tap == 8 ? buf_nxt : buf_cur;
-#else
-    const int a_off_n = (chunk_n & 1) * p.a_bytes;
-#endif
     if constexpr (tap == 8) {
-      // chunk boundary: the next step reads the next halo buffer.  Its pieces (the youngest was issued before the last
+      // chunk boundary: the next step reads the other halo buffer.  Its pieces (the youngest was issued before the last
       // four loads) have landed for this wave ... and, after the barrier, for all; the barrier also tells that everyone
-      // is done with the buffer that the coming pieces will overwrite -- EXCEPT the second half of this K-half's
+      // is done with the buffer that the next chunk's pieces will overwrite -- EXCEPT the second half of this K-half's
       // fragments, which are in registers already
       mma_half(xf, MH, wf[(S + 2) % 3]);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      frag_addrs(TapC<tap_n>{}, a_off_n);
+      frag_addrs(TapC<tap_n>{}, (chunk_n & 1) * p.a_bytes);
       read_half(xf, 0, 0);
       read_half(xf, MH, 0);
     } else {
-      frag_addrs(TapC<tap_n>{}, a_off_n);
+      frag_addrs(TapC<tap_n>{}, (chunk_n & 1) * p.a_bytes);
       read_half(xf, 0, 0);
         mma_half(xf, MH, wf[(S + 2) % 3]);
         read_half(xf, MH, 0);
@@ -1165,15 +1110,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
   };
 #pragma unroll 1
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-#if Y3_DW_PF == 2
-    fill_mask = (chunk >= 1 && chunk + 2 < p.nchunks) ? ~0ull : 0ull;   // is there a chunk + 2 to fetch during this chunk
-#endif
     kstep(TapC<0>{}, chunk); kstep(TapC<1>{}, chunk); kstep(TapC<2>{}, chunk);
     kstep(TapC<3>{}, chunk); kstep(TapC<4>{}, chunk); kstep(TapC<5>{}, chunk);
     kstep(TapC<6>{}, chunk); kstep(TapC<7>{}, chunk); kstep(TapC<8>{}, chunk);
-#if Y3_DW_PF == 2
-    { const int t = buf_cur; buf_cur = buf_nxt; buf_nxt = buf_fill; buf_fill = t; }
-#endif
   }
   __builtin_amdgcn_s_setprio(0);
   // The run-ahead loads of the step after the last are still in flight and nobody uses their data: without the register ties
@@ -1443,7 +1382,7 @@ int launch_halo_dw(const HaloArgs &a0, hipStream_t s) {
   a.na = y3_ceil_div(a.hr + 2, 64);                   // + the two zero rows
   a.hr_pad = a.na * 64;
   a.a_bytes = a.hr_pad * 128;
-  size_t lds = (size_t)(Y3_DW_PF == 2 ? 3 : 2) * a.a_bytes;   // (three halo images: chunks c, c + 1, c + 2)
+  size_t lds = (size_t)2 * a.a_bytes;
   if (lds < (size_t)DW_BM * 128 * 4) lds = (size_t)DW_BM * 128 * 4;
   Y3_REQUIRE(a.na >= 4 && a.na <= 6 && lds <= 160 * 1024, "direct-weights halo kernel: row width %d does not fit", a.W);
   a.m_tiles = y3_ceil_div(a.M, DW_BM);

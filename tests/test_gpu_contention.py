@@ -1,6 +1,6 @@
 """Every kernel family that overlaps its loads with counted waits (``s_waitcnt vmcnt(N)`` with loads still in flight: the
 LDS-DMA rings of conv_halo_ws / conv_igemm2 / conv_igemm3 / conv1x1_wres / conv_patch_wsp / conv_block_fused and the
-register-destination run-ahead loads of conv_halo_dw) run BESIDE a copy kernel that saturates the memory system, against
+register-destination run-ahead loads of conv_halo_dw / conv1x1_dw) run BESIDE a copy kernel that saturates the memory system, against
 its own output when it runs alone.
 
 Why: the waits are hand-counted.  Alone, loads land in issue order and early; under contention one can land late -- in the
@@ -104,6 +104,10 @@ def _cases():
         # weights-resident persistent 1x1 (4-slot pixel ring)
         ("wres_76", "conv1x1_wres_%s_128x128", dict(auto_mask=H.AM_WRES_ALWAYS), 16, 76, 256, 128, 1, 1, False),
         ("wres_152", "conv1x1_wres_%s_128x64", dict(auto_mask=H.AM_WRES_ALWAYS), 16, 152, 128, 64, 1, 1, False),
+        # direct-weights 1x1 kernel (round 6): register-destination run-ahead weight loads, 4 K-steps deep, behind the tile's LDS-DMA
+        ("dw1x1_96", "conv1x1_dw_%s_96x256", dict(auto_mask=H.AM_1X1_DW), 16, 38, 512, 256, 1, 1, False),
+        ("dw1x1_48", "conv1x1_dw_%s_48x256", dict(auto_mask=H.AM_1X1_DW), 16, 19, 1024, 512, 1, 1, False),
+        ("dw1x1_96_k768", "conv1x1_dw_%s_96x256", dict(auto_mask=H.AM_1X1_DW), 16, 38, 768, 256, 1, 1, False),
         # persistent 2-D patch kernel (rows wider than 128 px)
         ("patch_152", "conv_patch_wsp_%s_8x32x128", dict(auto_mask=halo | H.AM_PATCH_WIDE), 16, 152, 64, 128, 3, 1, True),
     ]

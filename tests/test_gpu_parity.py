@@ -620,6 +620,80 @@ def test_new_parameters_replace_the_plans_private_weight_copies():
         assert torch.equal(second[k], want[k]), k
 
 
+@pytest.mark.parametrize("model", ["yolov3", "yolov3-spp"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_direct_weights_1x1_kernel_is_chosen_at_batch16_and_changes_no_bit(model, dtype):
+    """Round 6: at 608 x 608, batch 16 the short-K bottleneck layers on the small maps (512 -> 256 at 38^2, 1024 -> 512 at 19^2,
+    768 -> 256 after the route: /root/reference/models/yolov3.cfg blocks 38-61, 63-80, 87) go to the direct-weights 1x1 kernel
+    (csrc/conv_1x1.hip: conv1x1_dw, one 96- or 48-pixel x 256-channel tile per CU, whole activation tile in LDS, weight
+    fragments straight from the shared fragment-order copy); forbidding it gives the same bits."""
+    from yolov3 import _hip
+    frames = synth_frames(45, 16, 608, 608)
+    a = _net(model, dtype=dtype)
+    oa = {k: v.clone() for k, v in a.forward_frames(frames).items()}
+    names = [r["kernel"] for r in a.plan_report()]
+    assert sum(n.startswith("conv1x1_dw_") for n in names) >= 18, names
+    assert any("_96x256" in n for n in names) and any("_48x256" in n for n in names), names
+    b = _net(model, dtype=dtype, options={"auto_mask": _hip.AM_DEFAULT & ~_hip.AM_1X1_DW})
+    ob = b.forward_frames(frames)
+    assert not any(r["kernel"].startswith("conv1x1_dw_") for r in b.plan_report())
+    for k in ("bbox_xywh", "class_prob", "class_idx"):
+        assert torch.equal(oa[k], ob[k]), k
+    # one frame at a time (inference(), the video loop): too few tiles -- the kernel is not taken, same bits again
+    c = _net(model, dtype=dtype)
+    oc = c.forward_frames(frames[:1])
+    assert not any(r["kernel"].startswith("conv1x1_dw_") for r in c.plan_report())
+    for k in ("bbox_xywh", "class_prob", "class_idx"):
+        assert torch.equal(oc[k], oa[k][:1]), k
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,h,cin,cout,leaky", [
+    (16, 38, 512, 256, True), (16, 19, 1024, 512, True), (16, 38, 768, 256, True), (16, 38, 256, 256, False), (16, 38, 384, 256, True),
+    (15, 38, 512, 256, True),      # 21 660 pixels: the last 96-pixel tile holds 60
+    (13, 19, 1024, 512, False),    # 4 693 pixels: the last 48-pixel tile holds 37
+    (16, 27, 512, 256, True),      # 48-pixel tiles with ONE channel tile
+    (16, 27, 768, 256, True)])
+def test_direct_weights_1x1_kernel_matches_implicit_gemm(B, h, cin, cout, leaky, dtype):
+    """Every instantiation of conv1x1_dw (tile heights 96 / 48; 4, 6, 8, 12, 16 K-steps), full and ragged last tiles, with and
+    without LeakyReLU: a one-op plan through the C ABI, bit-equal to the LDS-DMA implicit GEMM on the same operands (same K
+    order).  The plan makes its own fragment-order copy of the weights here (no y3_op.d_weight_frag): the C caller's path."""
+    import ctypes
+    from yolov3 import _hip
+    lib = _hip.lib()
+    dev = torch.device("cuda:0")
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    g = torch.Generator().manual_seed(B * 1000 + h + cin)
+    zero = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    x = (torch.rand((B, h, h, cin), generator=g) - 0.5).to(tdt).to(dev)
+    w = ((torch.rand((cout, cin), generator=g) - 0.5) * (6.0 / cin) ** 0.5).to(tdt).to(dev)
+    sc, bi = (torch.rand(cout, generator=g) + 0.5).to(dev), (torch.rand(cout, generator=g) - 0.5).to(dev)
+    outs, names = [], []
+    for mask in (_hip.AM_1X1_DW, 0):
+        out = torch.full((B, h, h, cout), 3.0, dtype=tdt, device=dev)
+        op = _hip.Y3Op()
+        op.kind, op.dtype = _hip.OP_CONV, {"bf16": _hip.Y3_BF16, "fp16": _hip.Y3_F16}[dtype]
+        op.flags = _hip.F_LEAKY if leaky else 0
+        op.batch, op.in_h, op.in_w, op.in_c, op.in_ld = B, h, h, cin, cin
+        op.out_h, op.out_w, op.out_c, op.out_ld = h, h, cout, cout
+        op.ksize, op.stride, op.pad, op.k_ld, op.cout_pad = 1, 1, 0, cin, cout
+        op.d_in, op.d_out = x.data_ptr(), out.data_ptr()
+        op.d_weight, op.d_scale, op.d_bias = w.data_ptr(), sc.data_ptr(), bi.data_ptr()
+        opts = _hip.options(auto_mask=mask)
+        handle = ctypes.c_void_p()
+        _hip.check(lib.y3_plan_create_ex((_hip.Y3Op * 1)(op), 1, zero.data_ptr(), ctypes.byref(opts), ctypes.byref(handle)))
+        try:
+            names.append(lib.y3_plan_op_kernel(handle, 0).decode())
+            _hip.check(lib.y3_plan_run(handle, None, _hip.stream_ptr()))
+            torch.cuda.synchronize()
+        finally:
+            lib.y3_plan_destroy(handle)
+        outs.append(out)
+    assert names[0].startswith("conv1x1_dw_") and names[1].startswith("conv_igemm"), names
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[0], outs[1]), (names, float((outs[0].float() - outs[1].float()).abs().max()))
+
+
 @pytest.mark.parametrize("h,cin,cout", [(38, 256, 512), (19, 512, 1024), (62, 128, 256), (76, 128, 256), (94, 256, 256)])
 def test_direct_weights_kernel_beside_a_copy_kernel(h, cin, cout):
     """Regression (round 5): the direct-weights kernel loads its weights with inline-asm global loads, one K-step ahead.  The
