@@ -370,10 +370,12 @@ int dw1x1_bm(const y3_op &op) {
   const int nkt = op.in_c / 64;
   if (op.in_c % 128 != 0 || !(nkt == 4 || nkt == 6 || nkt == 8 || nkt == 12 || nkt == 16)) return 0;
   const int M = op.batch * op.in_h * op.in_w, n_cu = y3_device_cus(), nt = op.out_c / 256;
-  // one round of workgroups: 96-pixel tiles where they already give every CU (nearly) one, else 48-pixel tiles
+  // one round of workgroups: 96-pixel tiles where they already give every CU (nearly) one, else 48-pixel tiles -- down to a
+  // quarter of the CUs (512 -> 256 at 19^2 x 16 frames: 121 tiles, 5.8 against 8.1-8.9 us on the implicit GEMMs, whose eight
+  // K-steps each wait out an L2 round trip whatever the grid; 38^2 x 8 frames 6.6 against 8.7-11.2: profiles/r06_conv1x1_dw.txt); smaller grids (one frame at a time) stay on the tiled kernels
   const long long t96 = (long long)y3_ceil_div(M, 96) * nt, t48 = (long long)y3_ceil_div(M, 48) * nt;
   if (op.in_c * 2 * 96 <= 144 * 1024 && t96 <= n_cu && 4 * t96 >= 3 * n_cu) return 96;
-  if (op.in_c * 2 * 48 <= 144 * 1024 && t48 <= n_cu && 4 * t48 >= 3 * n_cu) return 48;
+  if (op.in_c * 2 * 48 <= 144 * 1024 && t48 <= n_cu && 4 * t48 >= n_cu) return 48;
   return 0;
 }
 

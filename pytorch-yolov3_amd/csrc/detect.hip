@@ -26,8 +26,11 @@ namespace {
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
 constexpr int kIt = 8;          // 1024-row chunks handled per compaction pass (kIt * kWaves == 128)
+// elements sorted in LDS; larger frames sort in global memory.  (8192 -- 96 KiB, the heavy regime of bench.py has 4762 candidates per
+// frame -- was tried in round 6: the detection tail of that regime stayed at 0.79 ms per batch, so the sort is not what it spends
+// its time on, and a 100-KiB workgroup can no longer share a CU with a 64-KiB implicit-GEMM workgroup of another stream: kept at 4096.)
 constexpr int kLdsSort = 4096;
-constexpr int kMaxFlags = 1024;  // chunk flags in LDS; classes beyond that run on one wave  // elements sorted in LDS; larger frames sort in global memory
+constexpr int kMaxFlags = 1024;  // chunk flags in LDS; classes beyond that run on one wave
 
 struct DetectArgs {
   // forward-output mode

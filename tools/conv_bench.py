@@ -38,6 +38,7 @@ LAYERS = [
     ("s38_512-256_k1", 38, 512, 256, 1, 1, False, False),
     ("s19_1024-512_k1", 19, 1024, 512, 1, 1, False, False),
     ("s152_128-64_k1", 152, 128, 64, 1, 1, False, False),
+    ("s19_512-256_k1", 19, 512, 256, 1, 1, False, False),
     ("s38_768-256_k1", 38, 768, 256, 1, 1, False, False),
     ("s76_384-128_k1", 76, 384, 128, 1, 1, False, False),
     ("s76_256-255_k1_head", 76, 256, 255, 1, 1, False, True),
