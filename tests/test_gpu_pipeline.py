@@ -2,6 +2,8 @@
 line run) against per-frame ``inference()`` -- the reference's one-frame-per-call path,
 /root/reference/yolov3/inference.py:286-368 and __main__.py:159-165 -- the tests that start child processes are in test_gpu_a_fresh_process.py.
 Need an MI355X: -m gpu."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -162,3 +164,30 @@ def test_pipeline_is_deterministic_over_many_submits():
     for t, j in tickets:
         take(t, j)
     assert len(first) == 3 and not np.array_equal(first[0], first[1])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the single-GPU boxes skip it; an 8-GPU node runs it)")
+def test_network_on_a_device_that_is_not_current():
+    """plan compilation allocates and launches (arena, zero page, fragment-order weights) and must do so on
+    the NETWORK's device, whichever device is current: a net on cuda:1 compiled and run while cuda:0 is current gives the bits
+    of the same net on cuda:0, and nothing of it lives on GPU 0."""
+    import yolov3
+    from yolov3 import weights as W
+    from yolov3.synthdata import synth_frames
+    cfg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pytorch-yolov3_amd", "models", "yolov3.cfg")
+    frames = synth_frames(5, 16, 608, 608)
+    outs = []
+    torch.cuda.set_device(0)
+    for dev in ("cuda:0", "cuda:1"):
+        net = yolov3.Darknet(cfg, device=dev, dtype="bf16").eval()
+        net.set_params(W.synth_params(net.blocks, net.net_info, seed=0, obj_bias=-5.0, calib=W.load_calibration("yolov3")))
+        assert torch.cuda.current_device() == 0
+        out = net.forward_frames(torch.from_numpy(frames).to(dev))
+        assert any("conv_halo_dw" in r["kernel"] or "conv1x1_dw" in r["kernel"] for r in net.plan_report())
+        assert all(v.device == torch.device(dev) for v in out.values())
+        for key, w in net._dev_weights.items():
+            t = w if isinstance(w, torch.Tensor) else w["weight"]
+            assert t.device == torch.device(dev), key
+        outs.append({k: v.cpu() for k, v in out.items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
