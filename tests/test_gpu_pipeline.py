@@ -69,6 +69,26 @@ def test_pipeline_refetches_frames_with_more_than_kmax_detections():
         assert _same(g, w)
 
 
+def test_padding_frames_of_a_short_batch_do_not_count():
+    """A short last batch (n_frames < batch) is padded up to the pipeline's batch; whatever the padding frames hold -- here
+    dense frames that keep far more than kmax boxes -- their detections are dropped before the records are packed: the records
+    carry a count of zero for them, they cannot trigger the "a frame kept more than kmax boxes" second fetch (under a process
+    group: a second all-gather on every rank), and ``results`` returns exactly the real frames."""
+    net = _net("yolov3-tiny", "float32", obj_bias=-2.0)
+    frames = synth_frames(17, 4, 416, 416)
+    pipe = Pipeline(net, 4, in_flight=2, kmax=2048)
+    full = pipe.records(pipe.submit(frames)).copy()
+    assert int(full[:, 0, 7].min()) > 8                           # every frame keeps more boxes than the small kmax below
+    small = Pipeline(net, 4, in_flight=2, kmax=8)                 # kmax far below what a frame keeps
+    t = small.submit(frames, n_frames=1)
+    rec = small.records(t)
+    assert int(rec[0, 0, 7]) == int(full[0, 0, 7]) and (rec[1:, :, 7] == 0).all(), rec[:, 0, 7]
+    res = small.results(t)                                        # the real frame IS over kmax: fetched again in full
+    assert len(res) == 1 and len(res[0][1]) == int(full[0, 0, 7])
+    t = small.submit(frames[:1].repeat(4, axis=0), n_frames=1)    # the same through a fresh ticket
+    assert len(small.results(t)) == 1
+
+
 def test_upload_done_follows_the_host_buffer_not_the_device_buffer():
     """``upload_done(j)`` must answer for the upload that last READ ``host_frames(j)``.  A caller that
     double-buffers with host buffers 0 / 1 while the pipeline rotates six device buffers: with the copy stream held up (a long
