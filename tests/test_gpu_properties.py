@@ -144,3 +144,41 @@ def test_copy_bytes_kernel_moves_every_byte(nbytes):
         _hip.check(lib.y3_copy_bytes(src_d.data_ptr(), dst_d.data_ptr(), nbytes, 4096, stream))    # grid clamped to 1024
         torch.cuda.synchronize()
         assert torch.equal(dst_d[:nbytes], src_d[:nbytes])
+
+
+def test_dispatch_bound_kernel_times_are_what_the_bracket_contains():
+    """``y3_plan_run_profiled`` (ABI 6; what bench.py's roofline is computed from) binds a start / stop event pair to every
+    kernel DISPATCH: per op the kernel's own begin -> end.  ``y3_plan_run_timed`` records events on the stream around every launch:
+    that interval also holds the dispatch handling.  So, op by op: 0 < kernel time <= bracket time (+ timer resolution), ops fused into
+    their predecessor read exactly 0 in the first and a few microseconds in the second, and both runs leave the outputs bit-equal
+    to a plain run (replaces the timing of the block loop of /root/reference/yolov3/darknet.py:366-399)."""
+    import ctypes
+    import os
+    import torch
+    import yolov3
+    from yolov3 import _hip, weights as W
+    from yolov3.synthdata import synth_frames
+    cfg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pytorch-yolov3_amd", "models", "yolov3.cfg")
+    net = yolov3.Darknet(cfg, device="cuda", dtype="bf16").eval()
+    net.set_params(W.synth_params(net.blocks, net.net_info, seed=0, obj_bias=-5.0, calib=W.load_calibration("yolov3")))
+    frames = torch.from_numpy(synth_frames(3, 4, 608, 608)).cuda()
+    plain = {k: v.clone() for k, v in net.forward_frames(frames).items()}
+    per_mode = {}
+    for mode in ("kernel", True):
+        best = None
+        for _ in range(5):
+            out = net._run(frames, "u8", timed=mode, fresh=True)
+            ms = list(net.last_op_ms)
+            best = ms if best is None else [min(a, b) for a, b in zip(best, ms)]
+            for k in plain:
+                assert torch.equal(out[k], plain[k]), (mode, k)
+        per_mode[mode] = best
+    report = net.plan_report()
+    n_fused = 0
+    for op, k_ms, b_ms in zip(report, per_mode["kernel"], per_mode[True]):
+        if op["kernel"].startswith("(fused"):
+            n_fused += 1
+            assert k_ms == 0.0 and 0.0 < b_ms < 0.05, (op, k_ms, b_ms)      # nothing launched: only the bracket's own cost
+        else:
+            assert 0.0 < k_ms <= b_ms + 0.002, (op, k_ms, b_ms)
+    assert n_fused >= 4 and sum(per_mode["kernel"]) < sum(per_mode[True])

@@ -28,3 +28,12 @@ find $OUT -name "*.csv" | head -50
 python3 $REPO/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 tail -60 $OUT/summary.txt
 python3 $REPO/tools/make_traffic_table.py $OUT $OUT/traffic.json
+# the raw rocprofv3 csv files (a trace + seven counter passes of ~1000 steps) exceed gpurun's 64 MiB copy-back limit: keep the
+# kernel-stats table, the summary and the traffic table, drop the rest (KEEP_RAW=1 keeps everything: run it where the size does not matter)
+if [ "${KEEP_RAW:-0}" != "1" ]; then
+  find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_serial.csv
+  for d in trace pmc_fetch pmc_write pmc_sq; do tail -3 $OUT/$d.log > $OUT/$d.log.tail 2>/dev/null; done
+  find $OUT -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
+  rm -f $OUT/*.log
+fi
+
