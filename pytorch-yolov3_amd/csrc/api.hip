@@ -124,6 +124,9 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
                         ((am & Y3_AM_NO_SMALL_GRID) || (long long)y3_ceil_div(op.batch * op.out_h * op.out_w, 128) * y3_ceil_div(op.out_c, 128) >= y3_device_cus() / 4);
             if ((am & Y3_AM_1X1_DW) && y3_conv1x1_dw_pays(op))
               return y3_launch_conv1x1_dw(op, in, d_zero, s, name, dry_run, frag_w ? frag_w : op.d_weight_frag);
+            // small grids (one frame at a time, small batches): 48-pixel tiles that fill the chip in one round (conv_dw48.hip)
+            if ((am & Y3_AM_SMALL_DW) && !(am & Y3_AM_NO_SMALL_GRID) && y3_conv_dw48_fits(op))
+              return y3_launch_conv_dw48(op, in, d_zero, s, name, dry_run, frag_w ? frag_w : op.d_weight_frag);
             if (!(am & Y3_AM_NO_WRES) && y3_conv1x1_wres_supported(op) && ((am & Y3_AM_WRES_ALWAYS) || y3_conv1x1_wres_pays(op)))
               return y3_launch_conv1x1_wres(op, in, d_zero, s, name, dry_run);
             if ((am & Y3_AM_IGEMM3_1X1_BM64) && op.ksize == 1 && op.in_c >= 256 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32) &&
@@ -188,7 +191,7 @@ int run_op(y3_plan *plan, size_t i, const void *d_input, hipStream_t s, const ch
 
 // the kernels that read their weights from the fragment-order copy
 bool uses_fragment_weights(const char *kernel) {
-  return strncmp(kernel, "conv_halo_dw_", 13) == 0 || strncmp(kernel, "conv1x1_dw_", 11) == 0;
+  return strncmp(kernel, "conv_halo_dw_", 13) == 0 || strncmp(kernel, "conv1x1_dw_", 11) == 0 || strncmp(kernel, "conv_dw48_", 10) == 0;
 }
 
 // A private fragment-order copy of op i's weights (callers that pass no y3_op.d_weight_frag).  Made on the device that OWNS
@@ -262,7 +265,7 @@ size_t y3_conv_fragment_weight_bytes(const y3_op *op, const y3_options *options)
 
 int y3_conv_make_fragment_weights(const y3_op *op, void *d_dst, void *stream) {
   Y3_REQUIRE(op && d_dst && op->d_weight, "y3_conv_make_fragment_weights: bad arguments");
-  Y3_REQUIRE(y3_conv_halo_dw_fits(*op) || y3_conv1x1_dw_pays(*op), "conv block %d: not a layer of a direct-weights kernel", op->block_idx);
+  Y3_REQUIRE(y3_conv_halo_dw_fits(*op) || y3_conv1x1_dw_pays(*op) || y3_conv_dw48_fits(*op), "conv block %d: not a layer of a direct-weights kernel", op->block_idx);
   return y3_conv_halo_dw_make_weights(*op, d_dst, static_cast<hipStream_t>(stream));
 }
 

@@ -216,15 +216,22 @@ def test_bf16_every_block_teacher_forced_mini(mode):
 
 from yolov3 import _hip as _H
 HALO = {"auto_mask": _H.AM_DEFAULT | _H.AM_NO_SMALL_GRID}     # round-1 selection: the halo kernel whatever the grid size
+NO_SMALL_DW = {"auto_mask": _H.AM_DEFAULT & ~_H.AM_SMALL_DW}  # round-5 selection for small grids: the wave-specialised implicit GEMM
+WRES_ALWAYS = {"auto_mask": (_H.AM_DEFAULT & ~_H.AM_SMALL_DW) | _H.AM_WRES_ALWAYS}
 
 
 @pytest.mark.parametrize("model,h,w,batch,options,kernels", [
     ("yolov3-tiny", 416, 416, 2, None, ("conv_stem_mfma", "conv_igemm", "head_decode", "maxpool")),
-    # default selection at these small batches: the 3x3 layers with few tiles go to the wave-specialised implicit GEMM
-    ("yolov3", 608, 608, 1, None, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_patch", "conv_igemm2", "conv_igemm3",
+    # default selection at these small batches (round 6): the small-grid direct-weights kernel, 1x1 and 3x3
+    ("yolov3", 608, 608, 1, None, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_patch", "conv_igemm2", "conv_dw48_k3", "conv_dw48_k1",
                                    "head_decode")),
-    ("yolov3", 352, 480, 2, None, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_igemm3", "head_decode")),
-    ("yolov3-spp", 416, 416, 2, None, ("conv_igemm3", "maxpool_spp", "head_decode")),
+    ("yolov3", 352, 480, 2, None, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_dw48_k3", "conv_dw48_k1", "head_decode")),
+    ("yolov3-spp", 416, 416, 2, None, ("conv_dw48_k3", "conv_dw48_k1", "maxpool_spp", "head_decode")),
+    # ... and without it (round 5's selection): the 3x3 layers with few tiles on the wave-specialised implicit GEMM
+    ("yolov3", 608, 608, 1, NO_SMALL_DW, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_patch", "conv_igemm2", "conv_igemm3",
+                                          "head_decode")),
+    ("yolov3", 352, 480, 2, NO_SMALL_DW, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_igemm3", "head_decode")),
+    ("yolov3-spp", 416, 416, 2, NO_SMALL_DW, ("conv_igemm3", "maxpool_spp", "head_decode")),
     # the halo kernel on every layer it fits (what the batch-16 benchmark runs), 192-pixel tiles at these sizes
     ("yolov3", 608, 608, 1, HALO, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_halo_ws", "conv_patch", "conv_igemm2",
                                    "conv_igemm3", "head_decode")),
@@ -232,15 +239,18 @@ HALO = {"auto_mask": _H.AM_DEFAULT | _H.AM_NO_SMALL_GRID}     # round-1 selectio
     ("yolov3", 320, 320, 3, HALO, ("conv_halo_ws", "head_decode")),
     ("yolov3-spp", 608, 608, 1, HALO, ("conv_halo_ws", "maxpool_spp", "head_decode")),
     ("yolov3-spp", 416, 416, 2, HALO, ("conv_halo_ws", "maxpool_spp", "head_decode")),
-    # batch 8: 76^2 and 38^2 stay on the halo kernel by themselves, 19^2 goes to the implicit GEMM
-    ("yolov3", 608, 608, 8, None, ("conv_halo_ws", "conv_igemm3", "head_decode")),
+    # batch 8: 76^2 and 38^2 stay on the halo kernel by themselves, 19^2 goes to the small-grid kernel (round 5: the implicit GEMM)
+    ("yolov3", 608, 608, 8, None, ("conv_halo_ws", "conv_dw48_k3", "conv1x1_dw", "head_decode")),
+    ("yolov3", 608, 608, 8, NO_SMALL_DW, ("conv_halo_ws", "conv_igemm3", "head_decode")),
     # the weights-resident persistent 1x1 kernel on every layer it supports (Y3_AM_WRES_ALWAYS; by itself it starts at 512 tiles)
-    ("yolov3", 608, 608, 2, {"auto_mask": _H.AM_DEFAULT | _H.AM_WRES_ALWAYS}, ("conv1x1_wres_bf16_128x128", "conv1x1_wres_bf16_128x64")),
-    ("yolov3", 352, 480, 3, {"auto_mask": _H.AM_DEFAULT | _H.AM_WRES_ALWAYS}, ("conv1x1_wres_bf16_128x128", "conv1x1_wres_bf16_128x64")),
-    ("yolov3-spp", 416, 416, 1, {"auto_mask": _H.AM_DEFAULT | _H.AM_WRES_ALWAYS}, ("conv1x1_wres",)),
+    ("yolov3", 608, 608, 2, WRES_ALWAYS, ("conv1x1_wres_bf16_128x128", "conv1x1_wres_bf16_128x64")),
+    ("yolov3", 352, 480, 3, WRES_ALWAYS, ("conv1x1_wres_bf16_128x128", "conv1x1_wres_bf16_128x64")),
+    ("yolov3-spp", 416, 416, 1, WRES_ALWAYS, ("conv1x1_wres",)),
     # THE BENCHMARKED CONFIGURATION, block by block: 16 frames of 608 x 608 with bench.py's plan options (256-pixel halo
-    # tiles in several rounds of workgroups, the weights-resident 1x1 kernel by itself, the stride-2 layer on igemm3)
-    ("yolov3", 608, 608, 16, {"auto_mask": _H.AM_DEFAULT | _H.AM_HALO_TILE256}, ("conv_halo_ws_bf16_256x128", "conv1x1_wres_bf16_128x128",
+    # tiles in several rounds of workgroups, the direct-weights strip and 1x1 kernels, the weights-resident 1x1 kernel by itself, the
+    # stride-2 layer on igemm3)
+    ("yolov3", 608, 608, 16, {"auto_mask": _H.AM_DEFAULT | _H.AM_HALO_TILE256}, ("conv_halo_ws_bf16_256x128", "conv_halo_dw_bf16_192x256",
+                                                        "conv1x1_dw_bf16_96x256", "conv1x1_dw_bf16_48x256", "conv1x1_wres_bf16_128x128",
                                                         "conv1x1_wres_bf16_128x64", "conv_igemm3", "conv_patch", "head_decode")),
 ])
 def test_bf16_every_block_teacher_forced(model, h, w, batch, options, kernels):
@@ -261,12 +271,15 @@ def _every_block(model, h, w, batch, options, kernels, mode):
 # conv + decode, the SPP pyramid -- and on THE BENCHMARKED PLAN (16 frames of 608 x 608, bench.py's options)
 @pytest.mark.parametrize("model,h,w,batch,options,kernels", [
     ("yolov3-tiny", 416, 416, 2, None, ("conv_stem_mfma", "conv_igemm", "head_decode", "maxpool")),
-    ("yolov3", 608, 608, 1, None, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_patch", "conv_igemm2", "conv_igemm3",
+    ("yolov3", 608, 608, 1, None, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_patch", "conv_igemm2", "conv_dw48_k3", "conv_dw48_k1",
                                    "head_decode")),
+    ("yolov3", 608, 608, 1, NO_SMALL_DW, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_patch", "conv_igemm2", "conv_igemm3",
+                                          "head_decode")),
     ("yolov3", 352, 480, 2, HALO, ("conv_stem_s2_fused", "conv_resblock_fused", "conv_halo_ws", "head_decode")),
     ("yolov3-spp", 608, 608, 1, HALO, ("conv_halo_ws", "maxpool_spp", "head_decode")),
-    ("yolov3", 608, 608, 2, {"auto_mask": _H.AM_DEFAULT | _H.AM_WRES_ALWAYS}, ("conv1x1_wres_bf16_128x128", "conv1x1_wres_bf16_128x64")),
-    ("yolov3", 608, 608, 16, {"auto_mask": _H.AM_DEFAULT | _H.AM_HALO_TILE256}, ("conv_halo_ws_bf16_256x128", "conv1x1_wres_bf16_128x128",
+    ("yolov3", 608, 608, 2, WRES_ALWAYS, ("conv1x1_wres_bf16_128x128", "conv1x1_wres_bf16_128x64")),
+    ("yolov3", 608, 608, 16, {"auto_mask": _H.AM_DEFAULT | _H.AM_HALO_TILE256}, ("conv_halo_ws_bf16_256x128", "conv_halo_dw_bf16_192x256",
+                                                        "conv1x1_dw_bf16_96x256", "conv1x1_dw_bf16_48x256", "conv1x1_wres_bf16_128x128",
                                                         "conv1x1_wres_bf16_128x64", "conv_igemm3", "conv_patch", "head_decode")),
 ])
 def test_fp16_every_block_teacher_forced(model, h, w, batch, options, kernels):

@@ -1,6 +1,6 @@
 """Every kernel family that overlaps its loads with counted waits (``s_waitcnt vmcnt(N)`` with loads still in flight: the
 LDS-DMA rings of conv_halo_ws / conv_igemm2 / conv_igemm3 / conv1x1_wres / conv_patch_wsp / conv_block_fused and the
-register-destination run-ahead loads of conv_halo_dw / conv1x1_dw) run BESIDE a copy kernel that saturates the memory system, against
+register-destination run-ahead loads of conv_halo_dw / conv1x1_dw / conv_dw48) run BESIDE a copy kernel that saturates the memory system, against
 its own output when it runs alone.
 
 Why: the waits are hand-counted.  Alone, loads land in issue order and early; under contention one can land late -- in the
@@ -108,6 +108,10 @@ def _cases():
         ("dw1x1_96", "conv1x1_dw_%s_96x256", dict(auto_mask=H.AM_1X1_DW), 16, 38, 512, 256, 1, 1, False),
         ("dw1x1_48", "conv1x1_dw_%s_48x256", dict(auto_mask=H.AM_1X1_DW), 16, 19, 1024, 512, 1, 1, False),
         ("dw1x1_96_k768", "conv1x1_dw_%s_96x256", dict(auto_mask=H.AM_1X1_DW), 16, 38, 768, 256, 1, 1, False),
+        # small-grid direct-weights kernel (round 6): 1 .. 8 waves per workgroup, run-ahead weight loads behind the halo's LDS-DMA
+        ("dw48_k3_76", "conv_dw48_k3_%s", dict(auto_mask=H.AM_SMALL_DW), 1, 76, 128, 256, 3, 1, True),
+        ("dw48_k3_19", "conv_dw48_k3_%s", dict(auto_mask=H.AM_SMALL_DW), 2, 19, 512, 1024, 3, 1, True),
+        ("dw48_k1_38", "conv_dw48_k1_%s", dict(auto_mask=H.AM_SMALL_DW), 1, 38, 512, 256, 1, 1, False),
         # persistent 2-D patch kernel (rows wider than 128 px)
         ("patch_152", "conv_patch_wsp_%s_8x32x128", dict(auto_mask=halo | H.AM_PATCH_WIDE), 16, 152, 64, 128, 3, 1, True),
     ]

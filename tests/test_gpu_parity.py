@@ -113,7 +113,7 @@ def test_mini_fp16_close_to_fp32_and_its_two_stems_agree():
     assert (a["class_idx"] == b["class_idx"]).float().mean() > 0.99
 
 
-DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 0x1409d, "fuse_stem": 1, "decode_lanes": 4, "use_graph": 0, "fuse_head": 1, "fuse_spp": 1}
+DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 0x3409d, "fuse_stem": 1, "decode_lanes": 4, "use_graph": 0, "fuse_head": 1, "fuse_spp": 1}
 
 
 def test_tuning_knobs_do_not_change_results():
@@ -694,6 +694,87 @@ def test_direct_weights_1x1_kernel_matches_implicit_gemm(B, h, cin, cout, leaky,
     assert torch.equal(outs[0], outs[1]), (names, float((outs[0].float() - outs[1].float()).abs().max()))
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,h,w,cin,cout,k,res", [
+    (1, 76, 76, 128, 256, 3, True), (1, 38, 38, 256, 512, 3, True), (1, 19, 19, 512, 1024, 3, True), (2, 19, 19, 512, 1024, 3, False),
+    (3, 13, 13, 512, 1024, 3, False),        # yolov3-tiny's deep layer, three frames: 507 pixels = 10 tiles + 27 pixels
+    (1, 44, 60, 128, 256, 3, True),          # a non-square map (352 x 480 input): rows of 60 pixels, 2640 pixels = 55 tiles
+    (2, 11, 15, 256, 128, 3, True),          # 32-channel workgroups would not fill the chip either: Cout 128
+    (1, 76, 76, 256, 128, 1, False), (1, 38, 38, 512, 256, 1, False), (1, 19, 19, 1024, 512, 1, False), (1, 38, 38, 768, 256, 1, False),
+    (1, 76, 76, 384, 128, 1, False), (5, 19, 19, 1024, 512, 1, False)])
+def test_small_grid_direct_weights_kernel_matches_implicit_gemm(B, h, w, cin, cout, k, res, dtype):
+    """Round 6: conv_dw48 (csrc/conv_dw48.hip), the kernel of small grids -- one frame at a time, the mode the reference's command
+    line runs -- in every instantiation (3x3 with 2 / 4 / 8 channel chunks, 1x1 with 2 .. 16), with and without a shortcut operand,
+    ragged last tiles, non-square maps, 1 .. 8 waves per workgroup: a one-op plan through the C ABI, bit-equal to the LDS-DMA implicit GEMM
+    on the same operands (same K order: chunk outermost, tap innermost)."""
+    import ctypes
+    from yolov3 import _hip
+    lib = _hip.lib()
+    dev = torch.device("cuda:0")
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    g = torch.Generator().manual_seed(B * 1000 + h * 7 + cin + k)
+    zero = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    x = (torch.rand((B, h, w, cin), generator=g) - 0.5).to(tdt).to(dev)
+    kk = k * k * cin
+    wt = ((torch.rand((cout, kk), generator=g) - 0.5) * (6.0 / kk) ** 0.5).to(tdt).to(dev)
+    sc, bi = (torch.rand(cout, generator=g) + 0.5).to(dev), (torch.rand(cout, generator=g) - 0.5).to(dev)
+    r = (torch.rand((B, h, w, cout), generator=g) - 0.5).to(tdt).to(dev) if res else None
+    outs, names = [], []
+    for mask in (_hip.AM_SMALL_DW, 0):
+        out = torch.full((B, h, w, cout), 3.0, dtype=tdt, device=dev)
+        op = _hip.Y3Op()
+        op.kind, op.dtype = _hip.OP_CONV, {"bf16": _hip.Y3_BF16, "fp16": _hip.Y3_F16}[dtype]
+        op.flags = _hip.F_LEAKY | (_hip.F_RESIDUAL if res else 0)
+        op.batch, op.in_h, op.in_w, op.in_c, op.in_ld = B, h, w, cin, cin
+        op.out_h, op.out_w, op.out_c, op.out_ld = h, w, cout, cout
+        op.ksize, op.stride, op.pad, op.k_ld, op.cout_pad = k, 1, (k - 1) // 2, kk, (cout + 127) // 128 * 128
+        op.d_in, op.d_out = x.data_ptr(), out.data_ptr()
+        if res:
+            op.d_res, op.res_ld = r.data_ptr(), cout
+        wpad = torch.zeros((op.cout_pad, kk), dtype=tdt, device=dev)
+        wpad[:cout] = wt
+        scp, bip = torch.zeros(op.cout_pad, device=dev), torch.zeros(op.cout_pad, device=dev)
+        scp[:cout], bip[:cout] = sc, bi
+        op.d_weight, op.d_scale, op.d_bias = wpad.data_ptr(), scp.data_ptr(), bip.data_ptr()
+        opts = _hip.options(auto_mask=mask)
+        handle = ctypes.c_void_p()
+        _hip.check(lib.y3_plan_create_ex((_hip.Y3Op * 1)(op), 1, zero.data_ptr(), ctypes.byref(opts), ctypes.byref(handle)))
+        try:
+            names.append(lib.y3_plan_op_kernel(handle, 0).decode())
+            _hip.check(lib.y3_plan_run(handle, None, _hip.stream_ptr()))
+            torch.cuda.synchronize()
+        finally:
+            lib.y3_plan_destroy(handle)
+        outs.append(out)
+    assert names[0].startswith("conv_dw48_k%d_" % k) and names[1].startswith("conv_igemm"), names
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[0], outs[1]), (names, float((outs[0].float() - outs[1].float()).abs().max()))
+
+
+@pytest.mark.parametrize("model,dim", [("yolov3", 608), ("yolov3-spp", 608), ("yolov3-tiny", 416)])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_small_grid_kernel_is_chosen_for_one_frame_and_changes_no_bit(model, dim, dtype):
+    """One frame at a time (``inference()``, the reference CLI's loop: __main__.py:157-165): most convs of the 16-bit networks run on
+    conv_dw48; forbidding it gives the same bits at batches 1, 2, 3 and 5; at batch 16 it is not chosen at all."""
+    from yolov3 import _hip
+    for batch in (1, 2, 3, 5):
+        frames = synth_frames(70 + batch, batch, dim, dim)
+        a = _net(model, dtype=dtype)
+        oa = {k: v.clone() for k, v in a.forward_frames(frames).items()}
+        n = sum(r["kernel"].startswith("conv_dw48_") for r in a.plan_report())
+        if batch == 1:
+            assert n >= (50 if model != "yolov3-tiny" else 5), [r["kernel"] for r in a.plan_report()]
+        b = _net(model, dtype=dtype, options={"auto_mask": _hip.AM_DEFAULT & ~_hip.AM_SMALL_DW})
+        ob = b.forward_frames(frames)
+        assert not any(r["kernel"].startswith("conv_dw48_") for r in b.plan_report())
+        for k in ("bbox_xywh", "class_prob", "class_idx"):
+            assert torch.equal(oa[k], ob[k]), (batch, k)
+    if model != "yolov3-tiny":
+        c = _net(model, dtype=dtype)
+        c.forward_frames(synth_frames(71, 16, dim, dim))
+        assert not any(r["kernel"].startswith("conv_dw48_") for r in c.plan_report())
+
+
 @pytest.mark.parametrize("h,cin,cout", [(38, 256, 512), (19, 512, 1024), (62, 128, 256), (76, 128, 256), (94, 256, 256)])
 def test_direct_weights_kernel_beside_a_copy_kernel(h, cin, cout):
     """Regression (round 5): the direct-weights kernel loads its weights with inline-asm global loads, one K-step ahead.  The
@@ -1152,7 +1233,8 @@ def test_plan_options_are_per_plan():
     assert not any("halo" in r["kernel"] or "fused" in r["kernel"] or "igemm3" in r["kernel"] for r in plain.plan_report())
     assert any("halo" in r["kernel"] for r in fast.plan_report())
     names_dflt = [r["kernel"] for r in dflt.plan_report()]
-    assert any("igemm3" in k for k in names_dflt) and any("fused" in k for k in names_dflt)
+    # (one frame: the small-grid kernel of round 6 takes what the wave-specialised implicit GEMM took until then)
+    assert any("igemm3" in k or "conv_dw48" in k for k in names_dflt) and any("fused" in k for k in names_dflt)
     try:
         _hip.check(lib.y3_set_tuning(b"auto_mask", 0))       # must not reach into the existing plans
         again = dflt.forward_frames(frames)
@@ -1161,7 +1243,7 @@ def test_plan_options_are_per_plan():
             assert torch.equal(again[k], o_dflt[k])
         late = _net("yolov3", dtype="bf16")                 # created under the changed defaults
         late.forward_frames(frames)
-        assert not any("halo" in r["kernel"] or "igemm3" in r["kernel"] for r in late.plan_report())
+        assert not any("halo" in r["kernel"] or "igemm3" in r["kernel"] or "conv_dw48" in r["kernel"] for r in late.plan_report())
     finally:
         lib.y3_set_tuning(b"auto_mask", DEFAULT_KNOBS["auto_mask"])
     assert float((o_plain["class_prob"] - o_fast["class_prob"]).abs().median()) < 2e-3
