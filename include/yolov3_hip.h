@@ -134,6 +134,7 @@ typedef struct y3_plan y3_plan;
                                      /* memory) for the short-K bottleneck layers whose map x batch gives every CU one tile (round 6) */
 #define Y3_AM_SMALL_DW 0x20000u       /* small-grid direct-weights kernel (48-pixel x 32..256-channel tiles, whole halo in LDS) for 1x1 and   */
                                      /* 3x3 layers whose map x batch fits the chip in ONE round of such tiles: one frame at a time (round 6)  */
+#define Y3_AM_SMALL_DW_ALWAYS 0x40000u /* tests / A-B: that kernel wherever its shape constraints hold, whatever the grid                       */
 #define Y3_AM_WRES_ALWAYS 0x2000u    /* tests: that kernel on every layer it supports, whatever the map size                       */
 #define Y3_AM_DEFAULT (Y3_AM_HALO_WIDE | Y3_AM_HALO_NARROW | Y3_AM_IGEMM3_1X1_DEEP | Y3_AM_HALO_MID | Y3_AM_PATCH_WIDE | Y3_AM_HALO_DW | Y3_AM_1X1_DW | Y3_AM_SMALL_DW)   /* 0x3409d */
 #define Y3_AM_IGEMM_ONLY 0u          /* LDS-DMA implicit GEMM (igemm_version) everywhere                                           */

@@ -125,7 +125,7 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
             if ((am & Y3_AM_1X1_DW) && y3_conv1x1_dw_pays(op))
               return y3_launch_conv1x1_dw(op, in, d_zero, s, name, dry_run, frag_w ? frag_w : op.d_weight_frag);
             // small grids (one frame at a time, small batches): 48-pixel tiles that fill the chip in one round (conv_dw48.hip)
-            if ((am & Y3_AM_SMALL_DW) && !(am & Y3_AM_NO_SMALL_GRID) && y3_conv_dw48_fits(op))
+            if ((am & (Y3_AM_SMALL_DW | Y3_AM_SMALL_DW_ALWAYS)) && !(am & Y3_AM_NO_SMALL_GRID) && y3_conv_dw48_fits(op))
               return y3_launch_conv_dw48(op, in, d_zero, s, name, dry_run, frag_w ? frag_w : op.d_weight_frag);
             if (!(am & Y3_AM_NO_WRES) && y3_conv1x1_wres_supported(op) && ((am & Y3_AM_WRES_ALWAYS) || y3_conv1x1_wres_pays(op)))
               return y3_launch_conv1x1_wres(op, in, d_zero, s, name, dry_run);

@@ -226,8 +226,9 @@ void dw48_fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
   mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
 }
 
-// waves per workgroup (1 / 2 / 4 / 8 = 32 .. 256 channels) for this op, or 0 when the kernel does not take it
-int dw48_waves(const y3_op &op) {
+// waves per workgroup (1 / 2 / 4 / 8 = 32 .. 256 channels) for this op, or 0 when the kernel does not take it.  `any_grid` (tests / A-B:
+// Y3_AM_SMALL_DW_ALWAYS): the shape constraints only -- the widest workgroup the channel count allows, however many rounds that makes
+int dw48_waves(const y3_op &op, bool any_grid = false) {
   if (op.kind != Y3_OP_CONV || !y3_is16(op.dtype) || op.stride != 1) return 0;
   if (!((op.ksize == 1 && op.pad == 0) || (op.ksize == 3 && op.pad == 1))) return 0;
   if (op.flags & (Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT)) return 0;
@@ -244,6 +245,11 @@ int dw48_waves(const y3_op &op) {
   const int n_cu = y3_device_cus();
   // ONE round of workgroups: the fewest waves per workgroup (most workgroups) that still fit the chip; a layer that does not fit
   // with eight waves is not a small grid
+  if (any_grid) {
+    for (int nw = 8; nw >= 1; nw >>= 1)
+      if (op.out_c % (32 * nw) == 0) return nw;
+    return 0;
+  }
   for (int nw = 1; nw <= 8; nw <<= 1) {
     if (op.out_c % (32 * nw) != 0) continue;
     if (nw == 1 && (long long)(hr + 1) * op.in_c * 2 > 64 * 1024) continue;   // one wave alone would issue > 64 LDS-DMA pieces
@@ -254,11 +260,11 @@ int dw48_waves(const y3_op &op) {
 
 }  // namespace
 
-bool y3_conv_dw48_fits(const y3_op &op) { return dw48_waves(op) != 0; }
+bool y3_conv_dw48_fits(const y3_op &op) { return dw48_waves(op, ((unsigned)y3_opt().auto_mask & Y3_AM_SMALL_DW_ALWAYS) != 0) != 0; }
 
 int y3_launch_conv_dw48(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s, const char **kernel_name,
                         bool dry_run, const void *frag_w) {
-  const int nw = dw48_waves(op);
+  const int nw = dw48_waves(op, ((unsigned)y3_opt().auto_mask & Y3_AM_SMALL_DW_ALWAYS) != 0);
   Y3_REQUIRE(nw != 0, "conv block %d: not a shape for the small-grid direct-weights kernel", op.block_idx);
   *kernel_name = op.ksize == 3 ? Y3_KNAME(op.dtype, "conv_dw48_k3_", "") : Y3_KNAME(op.dtype, "conv_dw48_k1_", "");
   if (dry_run) return Y3_OK;

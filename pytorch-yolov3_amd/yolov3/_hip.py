@@ -81,6 +81,7 @@ AM_HALO_MID, AM_IGEMM3_NARROW, AM_IGEMM3_1X1_BM64, AM_PATCH_WIDE = 0x0010, 0x002
 AM_HALO_TILE256, AM_NO_BN_SHRINK, AM_NO_SMALL_GRID, AM_NO_WRES, AM_WRES_ALWAYS = 0x0200, 0x0400, 0x0800, 0x1000, 0x2000
 AM_HALO_DW, AM_HALO_DW_ALWAYS = 0x4000, 0x8000                       # direct-weights strip kernel: where it pays / wherever it fits
 AM_1X1_DW = 0x10000                                                  # direct-weights 1x1 kernel (short-K bottleneck layers, one tile per CU)
+AM_SMALL_DW_ALWAYS = 0x40000                                         # tests / A-B: the small-grid kernel wherever its shape constraints hold
 AM_SMALL_DW = 0x20000                                                # small-grid direct-weights kernel (48-pixel tiles, 1x1 and 3x3: one frame at a time)
 AM_DEFAULT = AM_HALO_WIDE | AM_HALO_NARROW | AM_IGEMM3_1X1_DEEP | AM_HALO_MID | AM_PATCH_WIDE | AM_HALO_DW | AM_1X1_DW | AM_SMALL_DW
 AM_IGEMM_ONLY = 0

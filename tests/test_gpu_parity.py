@@ -701,7 +701,9 @@ def test_direct_weights_1x1_kernel_matches_implicit_gemm(B, h, cin, cout, leaky,
     (1, 44, 60, 128, 256, 3, True),          # a non-square map (352 x 480 input): rows of 60 pixels, 2640 pixels = 55 tiles
     (2, 11, 15, 256, 128, 3, True),          # 32-channel workgroups would not fill the chip either: Cout 128
     (1, 76, 76, 256, 128, 1, False), (1, 38, 38, 512, 256, 1, False), (1, 19, 19, 1024, 512, 1, False), (1, 38, 38, 768, 256, 1, False),
-    (1, 76, 76, 384, 128, 1, False), (5, 19, 19, 1024, 512, 1, False)])
+    (1, 76, 76, 384, 128, 1, False), (5, 19, 19, 1024, 512, 1, False),
+    # grids of several rounds of workgroups (Y3_AM_SMALL_DW_ALWAYS: the launcher would not pick the kernel there by itself)
+    (16, 38, 38, 512, 256, 1, False), (16, 19, 19, 512, 1024, 3, True), (16, 76, 76, 384, 128, 1, False)])
 def test_small_grid_direct_weights_kernel_matches_implicit_gemm(B, h, w, cin, cout, k, res, dtype):
     """Round 6: conv_dw48 (csrc/conv_dw48.hip), the kernel of small grids -- one frame at a time, the mode the reference's command
     line runs -- in every instantiation (3x3 with 2 / 4 / 8 channel chunks, 1x1 with 2 .. 16), with and without a shortcut operand,
@@ -720,7 +722,7 @@ def test_small_grid_direct_weights_kernel_matches_implicit_gemm(B, h, w, cin, co
     sc, bi = (torch.rand(cout, generator=g) + 0.5).to(dev), (torch.rand(cout, generator=g) - 0.5).to(dev)
     r = (torch.rand((B, h, w, cout), generator=g) - 0.5).to(tdt).to(dev) if res else None
     outs, names = [], []
-    for mask in (_hip.AM_SMALL_DW, 0):
+    for mask in (_hip.AM_SMALL_DW_ALWAYS if B == 16 else _hip.AM_SMALL_DW, 0):
         out = torch.full((B, h, w, cout), 3.0, dtype=tdt, device=dev)
         op = _hip.Y3Op()
         op.kind, op.dtype = _hip.OP_CONV, {"bf16": _hip.Y3_BF16, "fp16": _hip.Y3_F16}[dtype]

@@ -61,6 +61,7 @@ VARIANTS = [
     ("halo_dw_auto", dict(BASE, auto_mask=AM.AM_HALO_ALL | AM.AM_HALO_TILE256 | AM.AM_HALO_DW)),   # ... where the launcher's model says it pays
     ("dw_1x1", dict(BASE, auto_mask=AM.AM_1X1_DW)),                  # direct-weights 1x1 kernel (whole activation tile in LDS) where it takes the layer
     ("dw48", dict(BASE, auto_mask=AM.AM_SMALL_DW)),                  # small-grid direct-weights kernel (48-pixel tiles) where the layer fits one round
+    ("dw48_always", dict(BASE, auto_mask=AM.AM_SMALL_DW_ALWAYS)),    # ... wherever its shape constraints hold, whatever the grid (A/B)
     ("wres_1x1", dict(BASE, auto_mask=AM.AM_WRES_ALWAYS)),           # weights-resident persistent 1x1 kernel wherever it is supported
 ]
 
