@@ -632,8 +632,14 @@ class Workload(object):
                    interval also holds the dispatch and the two barrier packets, ~5 us per launch (the whole 52.5 us by
                    rocprofv3 against 57.6-60.6 us by events of round 5: profiles/r06_timing_methods.txt)."""
         net = self.net
-        for i in range(sustain_steps):
-            self.step(i, resident=True)
+        if self.pipe.world > 1 or self.pipe.gathers[0].collective:
+            # N ranks: a pipeline step holds a collective (the record all-gather) and this report runs on rank 0 alone -- the
+            # sustained load is plain forwards here (one batch in flight instead of three: the same kernels back to back)
+            for i in range(sustain_steps):
+                net._run(self.frames, "u8", fresh=False, options=self.options)
+        else:
+            for i in range(sustain_steps):
+                self.step(i, resident=True)
         torch.cuda.synchronize()
         kern, brack = [], []
         tel = telemetry if telemetry is not None else GpuTelemetry(None)
