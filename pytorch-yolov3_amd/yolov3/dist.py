@@ -11,6 +11,8 @@ per frame (payload = frames * kmax * 32 B per rank: latency-bound, KBs).  The co
 the records, so a batch costs exactly one ``all_gather_into_tensor``; on GPUs it is issued on
 a side stream behind an event, so the compute stream goes straight on to the next batch.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist

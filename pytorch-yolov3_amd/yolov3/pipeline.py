@@ -213,12 +213,22 @@ class Pipeline(object):
                 det.count[int(n_frames):].zero_()
             g = self.gathers[d]
             rec = g.run(det)
-            if to_host:
-                if g.done is not None:
-                    cur.wait_event(g.done)
-                _hip.check(lib.y3_copy_bytes(rec.data_ptr(), self.host_rec[d].data_ptr(), rec.numel() * rec.element_size(), 4,
-                                             _hip.stream_ptr(cur)))
-            self.done_ev[d].record(cur)
+            if to_host and g.done is not None:
+                # N ranks: the gathered records go to the host on the SIDE stream, right behind the all-gather -- the compute stream
+                # never waits for the collective (until round 6 it did, and with it every batch queued behind on that stream).
+                # (With ONE rank under a process group the all-gather itself costs 11 % either way: RCCL then runs it as a
+                # device-to-device copy through the runtime's blit path, profiles/r06_gather_one_rank.txt.)
+                with torch.cuda.stream(g.side):
+                    _hip.check(lib.y3_copy_bytes(rec.data_ptr(), self.host_rec[d].data_ptr(), rec.numel() * rec.element_size(), 4,
+                                                 _hip.stream_ptr(g.side)))
+                    self.done_ev[d].record(g.side)
+            else:
+                if to_host:
+                    _hip.check(lib.y3_copy_bytes(rec.data_ptr(), self.host_rec[d].data_ptr(), rec.numel() * rec.element_size(), 4,
+                                                 _hip.stream_ptr(cur)))
+                elif g.done is not None:
+                    cur.wait_event(g.done)                # records left on the device: "done" still means gathered
+                self.done_ev[d].record(cur)
         self._frames_in[d] = self.batch if n_frames is None else int(n_frames)
         self._on_host[d] = bool(to_host)
         self._n += 1
@@ -276,3 +286,6 @@ class Pipeline(object):
     def synchronize(self):
         for s in self.streams + [self.copy_stream]:
             s.synchronize()
+        side = self.gathers[0].side if self.gathers else None
+        if side is not None:                              # (N ranks: the gathers and the records' way home run there)
+            side.synchronize()
