@@ -425,7 +425,10 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       interleave();
       __builtin_amdgcn_sched_barrier(0);
       Y3_W0(4);
-      __builtin_amdgcn_s_waitcnt(0xC07F);
+      // (no s_waitcnt here: until round 6 every wave drained its fragment reads BEFORE the barrier -- the reads issued in this half
+      // are of the NEXT step's slot and halo buffer, which the barrier does not release, and the compiler waits for each fragment
+      // where its first MFMA needs it: the barrier's latency and the reads' now overlap.  +1.3 % on the layer mix of batch 16, +4-9 % on
+      // the 19^2 layers alone; dropping the mid-step wait as well: level.  profiles/r06_ws_tail_wait.txt)
 #if defined(Y3_STAMPS_FINE)
       if (w0) Y3_STAMP(5); else Y3_STAMP(1);
 #else
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(768, 3) void conv_halo_ws_kernel(HaloArgs p) {
       interleave();
       __builtin_amdgcn_sched_barrier(0);
       Y3_W0(4);
-      __builtin_amdgcn_s_waitcnt(0xC07F);
+      // (no s_waitcnt before the barrier: see the 16-bit loop above)
 #if defined(Y3_STAMPS_FINE)
       if (w0) Y3_STAMP(5); else Y3_STAMP(1);
 #else
@@ -788,7 +791,7 @@ __global__ __launch_bounds__(768, 3) void conv_patch_wsp_kernel(HaloArgs p, int 
       mma_all(xf1, wf1, tap);
       interleave();
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0xC07F);
+      // (no s_waitcnt before the next barrier: see conv_halo_ws_kernel)
       tap = tap_n;
       gchunk = gchunk_n;
       ring = ring_n;
