@@ -151,7 +151,11 @@ typedef struct y3_plan y3_plan;
  *                    0 [default]: every kernel is launched individually (measured 1 % faster at batch 16)
  *   fuse_stem        1 [default]: conv pairs flagged Y3_F_FUSE_NEXT run as one kernel where one exists; 2: same, with the
  *                    phase-by-phase form of the fused stem kernel (same bits, slower: A/B and tests); 0: never fused
- *   fuse_head        1 [default]: detection-head conv + YOLO decode in one launch (bf16 networks)
+ *   fuse_head        1 [default]: detection-head conv + YOLO decode in one launch (16-bit networks), on the direct-weights 1x1 kernel
+ *                    where the head conv has 256 / 512 / 1024 input channels (it reads the fragment-order copy of the weights:
+ *                    y3_op.d_weight_frag or a private copy; 48-pixel tiles), else on the tiled kernel; 2: the tiled kernel only; 3 / 4:
+ *                    the direct-weights kernel with 48- / 96-pixel tiles wherever the shape allows (same bits all four: A/B and tests);
+ *                    0: two launches
  *   fuse_spp         1 [default]: three stride-1 max-pools (5 / 9 / 13) of one tensor in one launch
  *   decode_lanes     4 [default]: four lanes per box in the bf16 decode; 1: sequential class loop everywhere
  *   fuse_block       0 [default]: off.  1: a 1x1 conv (-> 128 channels) + the 3x3 conv that is its only reader (+ the

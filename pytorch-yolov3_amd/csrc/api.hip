@@ -178,7 +178,7 @@ int run_op(y3_plan *plan, size_t i, const void *d_input, hipStream_t s, const ch
   if (plan->fuse[i] == 2) return Y3_OK;
   if (plan->fuse[i] == 3) return y3_launch_conv_fused_resblock(plan->ops[i], plan->ops[i + 1], s, name, false);
   if (plan->fuse[i] == 6) return y3_launch_conv_block_fused(plan->ops[i], plan->ops[i + 1], s, name, false);
-  if (plan->fuse[i] == 4) return y3_launch_conv_head_decode(plan->ops[i], plan->ops[i + 1], plan->d_zero, s, name, false);
+  if (plan->fuse[i] == 4) return y3_launch_conv_head_decode(plan->ops[i], plan->ops[i + 1], plan->d_zero, s, name, false, plan->frag_w[i]);
   if (plan->fuse[i] == 5) return y3_launch_maxpool_spp(plan->ops[i], plan->ops[i + 1], plan->ops[i + 2], s, name, false);
   if (plan->fuse[i] == 1) {
     const y3_op &op0 = plan->ops[i];
@@ -191,7 +191,8 @@ int run_op(y3_plan *plan, size_t i, const void *d_input, hipStream_t s, const ch
 
 // the kernels that read their weights from the fragment-order copy
 bool uses_fragment_weights(const char *kernel) {
-  return strncmp(kernel, "conv_halo_dw_", 13) == 0 || strncmp(kernel, "conv1x1_dw_", 11) == 0 || strncmp(kernel, "conv_dw48_", 10) == 0;
+  return strncmp(kernel, "conv_halo_dw_", 13) == 0 || strncmp(kernel, "conv1x1_dw_", 11) == 0 || strncmp(kernel, "conv_dw48_", 10) == 0 ||
+         strncmp(kernel, "conv_head_decode_dw_", 20) == 0;
 }
 
 // A private fragment-order copy of op i's weights (callers that pass no y3_op.d_weight_frag).  Made on the device that OWNS
@@ -259,13 +260,16 @@ size_t y3_conv_fragment_weight_bytes(const y3_op *op, const y3_options *options)
   y3_options o = options ? *options : g_y3_defaults;
   OptScope scope(&o);
   const char *name = "";
+  // (a detection-head conv is dispatched with the YOLO op behind it, at plan creation: asked about by its shape here)
+  if (y3_opt().fuse_head && y3_conv_head_dw_fits(*op)) return y3_conv_halo_dw_weight_bytes(*op);
   if (dispatch(*op, nullptr, nullptr, nullptr, &name, true) != Y3_OK) return 0;
   return uses_fragment_weights(name) ? y3_conv_halo_dw_weight_bytes(*op) : 0;
 }
 
 int y3_conv_make_fragment_weights(const y3_op *op, void *d_dst, void *stream) {
   Y3_REQUIRE(op && d_dst && op->d_weight, "y3_conv_make_fragment_weights: bad arguments");
-  Y3_REQUIRE(y3_conv_halo_dw_fits(*op) || y3_conv1x1_dw_pays(*op) || y3_conv_dw48_fits(*op), "conv block %d: not a layer of a direct-weights kernel", op->block_idx);
+  Y3_REQUIRE(y3_conv_halo_dw_fits(*op) || y3_conv1x1_dw_pays(*op) || y3_conv_dw48_fits(*op) || y3_conv_head_dw_fits(*op),
+             "conv block %d: not a layer of a direct-weights kernel", op->block_idx);
   return y3_conv_halo_dw_make_weights(*op, d_dst, static_cast<hipStream_t>(stream));
 }
 
@@ -321,10 +325,6 @@ int y3_plan_create_ex(const y3_op *ops, int n_ops, const void *d_zero, const y3_
       (void)y3_launch_conv_fused_resblock(p->ops[i], p->ops[i + 1], nullptr, &p->kernel[i], true);
       continue;
     }
-    if (p->fuse[i] == 4) {
-      (void)y3_launch_conv_head_decode(p->ops[i], p->ops[i + 1], d_zero, nullptr, &p->kernel[i], true);
-      continue;
-    }
     if (p->fuse[i] == 6) {
       (void)y3_launch_conv_block_fused(p->ops[i], p->ops[i + 1], nullptr, &p->kernel[i], true);
       continue;
@@ -333,7 +333,8 @@ int y3_plan_create_ex(const y3_op *ops, int n_ops, const void *d_zero, const y3_
       (void)y3_launch_maxpool_spp(p->ops[i], p->ops[i + 1], p->ops[i + 2], nullptr, &p->kernel[i], true);
       continue;
     }
-    const int rc = dispatch(p->ops[i], nullptr, d_zero, nullptr, &p->kernel[i], true);
+    const int rc = p->fuse[i] == 4 ? y3_launch_conv_head_decode(p->ops[i], p->ops[i + 1], d_zero, nullptr, &p->kernel[i], true)
+                                   : dispatch(p->ops[i], nullptr, d_zero, nullptr, &p->kernel[i], true);
     if (rc != Y3_OK) {
       y3_plan_destroy(p);
       return rc;

@@ -120,6 +120,13 @@ static inline int y3_by_dtype16(int dtype, F &&f) {   // kernels that exist for 
   return dtype == Y3_F16 ? f(f16_t{}) : f(bf16_t{});
 }
 static inline int y3_ceil_div(int a, int b) { return (a + b - 1) / b; }
+// n / d == (umulhi(n, mul) + n) >> sh for 0 <= n < 2^31 (round-up method, d >= 1)
+static inline void y3_fast_div(uint32_t d, uint32_t &mul, uint32_t &sh) {
+  if (d <= 1) { mul = 0; sh = 0; return; }
+  sh = 0;
+  while ((1u << sh) < d) ++sh;
+  mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - d)) / d + 1);
+}
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2); give each
 // XCD one contiguous run of logical tile ids so that neighbouring tiles (which share an input
@@ -363,10 +370,14 @@ int y3_launch_conv_fused_resblock(const y3_op &op0, const y3_op &op1, hipStream_
 // 1x1 (-> 128 channels) + 3x3 (+ shortcut) in one kernel, bottleneck tensor in LDS (conv_block.hip)
 bool y3_conv_block_fused_supported(const y3_op &op0, const y3_op &op1);
 int y3_launch_conv_block_fused(const y3_op &op0, const y3_op &op1, hipStream_t s, const char **kernel_name, bool dry_run);
-// detection head: 1x1 conv + YOLO decode in one launch (conv_igemm.hip)
+// detection head: 1x1 conv + YOLO decode in one launch (conv_igemm.hip: the tiled form and the choice between the two; conv_1x1.hip:
+// the direct-weights form, which reads the fragment-order copy of the head conv's weights: `frag_w`, nullptr = made per launch)
 bool y3_conv_head_decode_supported(const y3_op &op0, const y3_op &op1);
 int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d_zero, hipStream_t s,
-                               const char **kernel_name, bool dry_run);
+                               const char **kernel_name, bool dry_run, const void *frag_w = nullptr);
+bool y3_conv_head_dw_fits(const y3_op &op0);
+int y3_launch_conv_head_decode_dw(const y3_op &op0, const y3_op &op1, const void *d_zero, hipStream_t s, const char **kernel_name,
+                                  bool dry_run, const void *frag_w);
 // halo-reuse 3x3 kernel (conv_halo.hip): whether it can take this conv, and its launcher
 bool y3_conv_halo_ws_fits(const y3_op &op);
 bool y3_conv_halo_dw_fits(const y3_op &op);

@@ -20,6 +20,7 @@
 #include <utility>
 
 #include "common.h"
+#include "decode_core.h"
 
 namespace {
 
@@ -230,6 +231,13 @@ struct DwArgs {
   int M, in_ld, out_ld, k_ld;
   int n_tiles;         // Cout / 256
   uint32_t flags;
+  // detection-head form (HEAD = true): the YOLO decode of yolo_decode.hip runs on the workgroup's logit tile (see y3_head_decode_rows)
+  int Ho, Wo, HoWo;
+  uint32_t mul_hw, sh_hw, mul_w, sh_w;   // n / d == (umulhi(n, mul) + n) >> sh  (d = HoWo, Wo)
+  float *y_bbox, *y_prob;
+  long long *y_cls;
+  int y_anchors, y_attr, y_row_offset, y_rows_total;
+  float y_net_w, y_net_h, y_aw[8], y_ah[8];
 };
 
 template <int V>
@@ -246,7 +254,11 @@ __device__ __forceinline__ void dw1_wait_vm(u32x4 (&w)[2][2]) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]) : "n"(N) : "memory");
 }
 
-template <typename T, int BM, int NKT>
+// HEAD = true: the detection-head conv (bias, no activation, <= 256 logits per pixel = ONE channel tile) + YOLOLayer decode
+// (/root/reference/yolov3/darknet.py:86-116) in one launch: after the K loop the float32 logits (sum * scale + bias, one fused rounding
+// -- the arithmetic of the tiled head kernel, conv_igemm.hip) are parked in the LDS the activation tile no longer needs, rows of
+// 260 floats, and decoded four lanes per box by the code every other decode path runs (decode_core.h): same bits.
+template <typename T, int BM, int NKT, bool HEAD = false>
 __global__ __launch_bounds__(512, 2) void conv1x1_dw_kernel(DwArgs p) {
   static_assert(sizeof(T) == 2 && (BM == 96 || BM == 48) && NKT % 2 == 0, "16-bit modes; 96- or 48-pixel tiles; Cin a multiple of 128");
   constexpr int MI = BM / 16, NI = 2;
@@ -350,6 +362,29 @@ __global__ __launch_bounds__(512, 2) void conv1x1_dw_kernel(DwArgs p) {
 
   // ---- epilogue in registers: lane (fr, fq) holds channels co .. co + 7 of pixels m0 + mi * 16 + fr
   const int co = n0 + wave * 32 + fq * 8;             // (y3_pair_perm'd weight rows)
+  if constexpr (HEAD) {
+    constexpr int LDL = 260;                          // 1040 bytes: consecutive pixels of a fragment shift by four banks
+    const f32x4 hs_lo = *reinterpret_cast<const f32x4 *>(p.scale + co), hs_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
+    const f32x4 hb_lo = *reinterpret_cast<const f32x4 *>(p.bias + co), hb_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();                     // nobody reads the activation tile any more: LDS holds the logits
+    float *sL = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      f32x4 lo, hi;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        lo[r] = __builtin_fmaf(acc[mi][0][r], hs_lo[r], hb_lo[r]);
+        hi[r] = __builtin_fmaf(acc[mi][1][r], hs_hi[r], hb_hi[r]);
+      }
+      float *row = sL + (mi * 16 + fr) * LDL + co;
+      *reinterpret_cast<f32x4 *>(row) = lo;
+      *reinterpret_cast<f32x4 *>(row + 4) = hi;
+    }
+    __syncthreads();
+    y3_head_decode_rows<512, LDL>(p, sL, m0, BM, tid);
+    return;
+  }
   const f32x4 sc_lo = *reinterpret_cast<const f32x4 *>(p.scale + co), sc_hi = *reinterpret_cast<const f32x4 *>(p.scale + co + 4);
   const f32x4 bi_lo = *reinterpret_cast<const f32x4 *>(p.bias + co), bi_hi = *reinterpret_cast<const f32x4 *>(p.bias + co + 4);
   const bool leaky = p.flags & Y3_F_LEAKY;
@@ -377,6 +412,24 @@ int dw1x1_bm(const y3_op &op) {
   if (op.in_c * 2 * 96 <= 144 * 1024 && t96 <= n_cu && 4 * t96 >= 3 * n_cu) return 96;
   if (op.in_c * 2 * 48 <= 144 * 1024 && t48 <= n_cu && 4 * t48 >= n_cu) return 48;
   return 0;
+}
+
+// tile height of the detection-head form for this head conv (96 / 48), or 0 when the tiled head kernel keeps it.  y3_options.fuse_head:
+// 1 = 48 (measured at batch 16 / one frame, us per launch: 19^2 x 1024 13.8 / 10.9, 38^2 x 512 16.0 / 8.0, 76^2 x 256 32.9 / 6.7; 96-pixel
+// tiles 13.8 (48: does not fit) / 15.8 / 38.1 and -- / 10.7 / 8.9; the tiled kernel 27.7 / 20.2 / 39.3 and 21.3 / 14.6 / 10.4:
+// profiles/r06_head_dw.txt), 2 = never (the tiled kernel, A/B), 3 / 4 = 48 / 96 wherever the shape allows (A/B, tests)
+int dw_head_bm(const y3_op &op) {
+  const int mode = y3_opt().fuse_head;
+  if (mode == 0 || mode == 2) return 0;
+  if (op.kind != Y3_OP_CONV || !y3_is16(op.dtype) || op.ksize != 1 || op.stride != 1 || op.pad != 0 || !(op.flags & Y3_F_OUT_F32)) return 0;
+  if (op.flags & (Y3_F_LEAKY | Y3_F_RESIDUAL | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT)) return 0;
+  if (op.out_c > 256 || op.cout_pad < 256 || op.cout_pad % 32 != 0 || op.in_ld % 8 != 0 || op.k_ld % 32 != 0 || op.k_ld < op.in_c) return 0;
+  const int nkt = op.in_c / 64;
+  if (op.in_c % 128 != 0 || !(nkt == 4 || nkt == 8 || nkt == 16)) return 0;
+  const long long M = (long long)op.batch * op.in_h * op.in_w;
+  if (M >= (1ll << 31)) return 0;
+  const bool fits96 = nkt <= 8;                       // 96 pixels x 1024 channels would be 192 KiB
+  return mode == 4 && fits96 ? 96 : 48;
 }
 
 int wres_bn(const y3_op &op) {
@@ -438,6 +491,71 @@ int y3_launch_conv1x1_dw(const y3_op &op, const void *d_in, const void *d_zero, 
       else if (nkt == 12) Y3_DW1_GO(48, 12); else Y3_DW1_GO(48, 16);
     }
 #undef Y3_DW1_GO
+    Y3_HIP_CHECK(hipGetLastError());
+    return Y3_OK;
+  });
+  if (tmp) (void)hipFreeAsync(tmp, s);
+  return rc;
+}
+
+// detection-head conv + YOLO decode on the direct-weights 1x1 kernel (op0: the head conv, op1: the Y3_OP_YOLO op reading it; the pair
+// has passed y3_conv_head_decode_supported)
+bool y3_conv_head_dw_fits(const y3_op &op0) { return dw_head_bm(op0) != 0; }
+
+int y3_launch_conv_head_decode_dw(const y3_op &op0, const y3_op &op1, const void *d_zero, hipStream_t s, const char **kernel_name,
+                                  bool dry_run, const void *frag_w) {
+  const int bm = dw_head_bm(op0);
+  Y3_REQUIRE(bm != 0, "conv block %d: not a shape for the direct-weights head kernel", op0.block_idx);
+  *kernel_name = bm == 96 ? Y3_KNAME(op0.dtype, "conv_head_decode_dw_", "_96x256") : Y3_KNAME(op0.dtype, "conv_head_decode_dw_", "_48x256");
+  if (dry_run) return Y3_OK;
+  void *tmp = nullptr;
+  if (!frag_w) {                                      // callers without a shared copy: made here, stream-ordered
+    Y3_HIP_CHECK(hipMallocAsync(&tmp, y3_conv_halo_dw_weight_bytes(op0), s));
+    const int rc = y3_conv_halo_dw_make_weights(op0, tmp, s);
+    if (rc != Y3_OK) { (void)hipFreeAsync(tmp, s); return rc; }
+    frag_w = tmp;
+  }
+  DwArgs a;
+  a.in = static_cast<const char *>(op0.d_in);
+  a.wgt = static_cast<const char *>(frag_w);
+  a.scale = op0.d_scale; a.bias = op0.d_bias;
+  a.out = nullptr;
+  a.zero = static_cast<const char *>(d_zero);
+  a.Ho = op0.out_h; a.Wo = op0.out_w; a.HoWo = op0.out_h * op0.out_w;
+  a.M = op0.batch * a.HoWo;
+  a.in_ld = op0.in_ld; a.out_ld = op0.out_ld; a.k_ld = op0.k_ld;
+  a.n_tiles = 1;
+  a.flags = op0.flags;
+  y3_fast_div((uint32_t)a.HoWo, a.mul_hw, a.sh_hw);
+  y3_fast_div((uint32_t)a.Wo, a.mul_w, a.sh_w);
+  a.y_bbox = op1.d_bbox; a.y_prob = op1.d_prob; a.y_cls = reinterpret_cast<long long *>(op1.d_cls);
+  a.y_anchors = op1.n_anchor; a.y_attr = op1.n_attr;
+  a.y_row_offset = op1.row_offset; a.y_rows_total = op1.rows_total;
+  a.y_net_w = op1.net_w; a.y_net_h = op1.net_h;
+  for (int i = 0; i < 8; ++i) { a.y_aw[i] = op1.anchor_w[i]; a.y_ah[i] = op1.anchor_h[i]; }
+  const int nkt = op0.in_c / 64;
+  const int rc = y3_by_dtype16(op0.dtype, [&](auto tag) {
+    typedef decltype(tag) T;
+    static Y3DeviceOnce once;
+    {
+      const int rc1 = once.run([]() -> int {
+#define Y3_DWH_ATTR(BM_, NKT_) Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_dw_kernel<T, BM_, NKT_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        Y3_DWH_ATTR(96, 4); Y3_DWH_ATTR(96, 8); Y3_DWH_ATTR(48, 4); Y3_DWH_ATTR(48, 8); Y3_DWH_ATTR(48, 16);
+#undef Y3_DWH_ATTR
+        return Y3_OK;
+      });
+      if (rc1 != Y3_OK) return rc1;
+    }
+    const size_t tile = (size_t)bm * op0.in_c * 2, logits = (size_t)bm * 260 * 4;
+    const size_t lds = tile > logits ? tile : logits;
+    const dim3 grid(y3_ceil_div(a.M, bm));
+#define Y3_DWH_GO(BM_, NKT_) Y3_LAUNCH((conv1x1_dw_kernel<T, BM_, NKT_, true>), grid, dim3(512), lds, s, a)
+    if (bm == 96) {
+      if (nkt == 4) Y3_DWH_GO(96, 4); else Y3_DWH_GO(96, 8);
+    } else {
+      if (nkt == 4) Y3_DWH_GO(48, 4); else if (nkt == 8) Y3_DWH_GO(48, 8); else Y3_DWH_GO(48, 16);
+    }
+#undef Y3_DWH_GO
     Y3_HIP_CHECK(hipGetLastError());
     return Y3_OK;
   });

@@ -992,7 +992,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_dw_kernel(HaloArgs p) {
   // ---- pixel fragments ----
   // border-tap masks of the wave's six fragments: lane masks in scalar registers (Y3_DW_SMASK) or nine tap bits per fragment,
   // three fragments per vector register
-  uint32_t tm[(MI + 2) / 3] = {};
+  [[maybe_unused]] uint32_t tm[(MI + 2) / 3] = {};
   unsigned long long mk_top[MI], mk_bot[MI], mk_left[MI], mk_right[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {

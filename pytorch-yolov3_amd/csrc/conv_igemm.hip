@@ -274,37 +274,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmArgs p) {
 }
 
 
-// YOLO decode of `rows` pixels whose float32 logits (conv sums with scale / bias already applied) are parked in LDS with
-// a row stride of LD floats (LD odd in units of banks: the per-box reads of adjacent lanes spread over the banks): four
-// lanes per box, decode_core.h -- the same code as yolo_decode_kernel<4>.
-template <int NT, int LD>
-__device__ __forceinline__ void head_decode_rows(const IgemmArgs &p, const float *sL, int mbase, int rows, int tid) {
-  const int nbox = rows * p.y_anchors;
-  const uint32_t inv_a = (65536u + (uint32_t)p.y_anchors - 1u) / (uint32_t)p.y_anchors;   // box / anchors for box < 8192
-  for (int t = tid; t < nbox * 4; t += NT) {
-    const int box = t >> 2, sub = t & 3;
-    const int pl = (int)(((uint32_t)box * inv_a) >> 16), a = box - pl * p.y_anchors;
-    const long long m = (long long)mbase + pl;
-    const bool live = m < p.M;
-    const uint32_t um = (uint32_t)(live ? m : p.M - 1);
-    const uint32_t b = (__umulhi(um, p.mul_hw) + um) >> p.sh_hw;
-    const uint32_t rem = um - b * (uint32_t)p.HoWo;
-    const uint32_t y = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
-    const uint32_t x = rem - y * (uint32_t)p.Wo;
-    float comp, score;
-    int best_c;
-    y3_decode_box4(sL + pl * LD + a * p.y_attr, p.y_attr, sub, (float)x, (float)y, (float)p.Wo, (float)p.Ho, p.y_aw[a],
-                   p.y_ah[a], p.y_net_w, p.y_net_h, comp, score, best_c);
-    if (!live) continue;
-    const long long row = (long long)b * p.y_rows_total + p.y_row_offset + (long long)a * p.HoWo + (long long)y * p.Wo + x;
-    p.y_bbox[row * 4 + sub] = comp;
-    if (sub == 2) {
-      p.y_prob[row] = score;
-      p.y_cls[row] = best_c;
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // v2: LDS-DMA pipeline.  Same tile geometry and LDS image as above, but
 //   * operands go global -> LDS directly (global_load_lds_dwordx4, 16 B per lane, 1 KiB per wave
@@ -567,7 +536,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm2_kernel(Ige
     __syncthreads();
     if constexpr (DECODE) {
       static_assert(RP * LDL * 4 <= LDS_BYTES, "padded logit tile must fit in the operand stages");
-      head_decode_rows<NT, LDL>(p, sC, m0 + h * RP, RP, tid);
+      y3_head_decode_rows<NT, LDL>(p, sC, m0 + h * RP, RP, tid);
       continue;
     }
     if (nvalid <= 0) continue;
@@ -1119,7 +1088,10 @@ bool y3_conv_head_decode_supported(const y3_op &op0, const y3_op &op1) {
 }
 
 int y3_launch_conv_head_decode(const y3_op &op0, const y3_op &op1, const void *d_zero, hipStream_t s,
-                               const char **kernel_name, bool dry_run) {
+                               const char **kernel_name, bool dry_run, const void *frag_w) {
+  // the direct-weights form (conv_1x1.hip) wherever its shape constraints hold: nothing in its K loop waits on a barrier or a cold
+  // load; this tiled form (one K-step of prefetch) keeps the other shapes
+  if (y3_conv_head_dw_fits(op0)) return y3_launch_conv_head_decode_dw(op0, op1, d_zero, s, kernel_name, dry_run, frag_w ? frag_w : op0.d_weight_frag);
   *kernel_name = Y3_KNAME(op0.dtype, "conv_head_decode_", "_64x256");
   if (dry_run) return Y3_OK;
   IgemmArgs a;

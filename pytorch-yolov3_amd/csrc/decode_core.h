@@ -113,3 +113,35 @@ __device__ __forceinline__ void y3_decode_box4(const float *t_, int n_attr, int 
   score = q * r;
   cls = best_c;
 }
+
+// YOLO decode of `rows` pixels whose float32 logits (conv sums with scale / bias already applied) are parked in LDS with
+// a row stride of LD floats (LD odd in units of banks: the per-box reads of adjacent lanes spread over the banks): four
+// lanes per box, y3_decode_box4 above -- the same code as yolo_decode_kernel<4>.  Args: the launch arguments of a fused head kernel
+// (conv_igemm.hip: IgemmArgs, conv_1x1.hip: DwArgs) -- M, HoWo, Wo, Ho, the fast-division constants and the y_* fields of the decode.
+template <int NT, int LD, typename Args>
+__device__ __forceinline__ void y3_head_decode_rows(const Args &p, const float *sL, int mbase, int rows, int tid) {
+  const int nbox = rows * p.y_anchors;
+  const uint32_t inv_a = (65536u + (uint32_t)p.y_anchors - 1u) / (uint32_t)p.y_anchors;   // box / anchors for box < 8192
+  for (int t = tid; t < nbox * 4; t += NT) {
+    const int box = t >> 2, sub = t & 3;
+    const int pl = (int)(((uint32_t)box * inv_a) >> 16), a = box - pl * p.y_anchors;
+    const long long m = (long long)mbase + pl;
+    const bool live = m < p.M;
+    const uint32_t um = (uint32_t)(live ? m : p.M - 1);
+    const uint32_t b = (__umulhi(um, p.mul_hw) + um) >> p.sh_hw;
+    const uint32_t rem = um - b * (uint32_t)p.HoWo;
+    const uint32_t y = (__umulhi(rem, p.mul_w) + rem) >> p.sh_w;
+    const uint32_t x = rem - y * (uint32_t)p.Wo;
+    float comp, score;
+    int best_c;
+    y3_decode_box4(sL + pl * LD + a * p.y_attr, p.y_attr, sub, (float)x, (float)y, (float)p.Wo, (float)p.Ho, p.y_aw[a],
+                   p.y_ah[a], p.y_net_w, p.y_net_h, comp, score, best_c);
+    if (!live) continue;
+    const long long row = (long long)b * p.y_rows_total + p.y_row_offset + (long long)a * p.HoWo + (long long)y * p.Wo + x;
+    p.y_bbox[row * 4 + sub] = comp;
+    if (sub == 2) {
+      p.y_prob[row] = score;
+      p.y_cls[row] = best_c;
+    }
+  }
+}

@@ -54,15 +54,19 @@ def _conv_op(dev, gen, dtype, B, h, cin, cout, k, stride, res):
     return op, keep, out
 
 
-def _beside_a_copy(handle, out, rounds=20, launches=6):
+def _beside_a_copy(handle, out, rounds=20, launches=6, more=()):
+    """`out` (and the tensors in `more`) after launches beside the copy kernel == after a launch alone."""
     from yolov3 import _hip
     lib = _hip.lib()
     dev = out.device
     _hip.check(lib.y3_plan_run(handle, None, None))
     torch.cuda.synchronize()
     alone = out.clone()
+    alone_more = [t.clone() for t in more]
     assert torch.isfinite(alone.float()).all() and float(alone.float().abs().max()) > 0
     out.zero_()
+    for t in more:
+        t.zero_()
     host = torch.zeros(16 * 608 * 608 * 3, dtype=torch.uint8).pin_memory()
     dst = torch.zeros(16 * 608 * 608 * 3, dtype=torch.uint8, device=dev)
     cs, st = torch.cuda.Stream(), torch.cuda.Stream()
@@ -75,6 +79,8 @@ def _beside_a_copy(handle, out, rounds=20, launches=6):
             torch.cuda.synchronize()
             assert torch.equal(out, alone), "round %d: %d values differ from the kernel's own quiet output" % (
                 i, int((out != alone).sum()))
+            for t, a in zip(more, alone_more):
+                assert torch.equal(t, a), "round %d: a second output differs from the kernel's own quiet output" % i
     torch.cuda.synchronize()
 
 
@@ -161,5 +167,50 @@ def test_fused_bottleneck_block_beside_a_copy_kernel(res):
     try:
         assert lib.y3_plan_op_kernel(handle, 0).decode() == "conv_block_fused_bf16_x128"
         _beside_a_copy(handle, out)
+    finally:
+        lib.y3_plan_destroy(handle)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("mode,kernel,B,h,cin", [
+    (2, "conv_head_decode_%s_64x256", 16, 38, 512),            # tiled head kernel: LDS-DMA double buffer
+    (4, "conv_head_decode_dw_%s_96x256", 16, 38, 512),         # direct-weights head kernel (round 6): run-ahead weight loads, 96-pixel tiles
+    (1, "conv_head_decode_dw_%s_48x256", 16, 19, 1024),        # ... 48-pixel tiles (the default), sixteen K-steps
+    (1, "conv_head_decode_dw_%s_48x256", 1, 76, 256)])         # ... one frame
+def test_head_kernels_beside_a_copy_kernel(mode, kernel, B, h, cin, dtype):
+    """The fused detection-head kernels (1x1 conv + YOLO decode in one launch; /root/reference/yolov3/darknet.py:244-257 + :86-116):
+    boxes, scores and classes beside a copy kernel == alone."""
+    from yolov3 import _hip
+    lib = _hip.lib()
+    _hip.require_gpu()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(50 + h)
+    op, keep, _ = _conv_op(dev, gen, dtype, B, h, cin, 255, 1, 1, False)
+    op.flags = _hip.F_OUT_F32                                   # a head conv: bias only, float32 logits
+    logits = torch.zeros((B, h, h, 256), dtype=torch.float32, device=dev)
+    op.d_out, op.out_ld = logits.data_ptr(), 256
+    rows = 3 * h * h
+    bbox = torch.zeros((B, rows, 4), dtype=torch.float32, device=dev)
+    prob = torch.zeros((B, rows), dtype=torch.float32, device=dev)
+    cls = torch.zeros((B, rows), dtype=torch.int64, device=dev)
+    yo = _hip.Y3Op()
+    yo.kind, yo.dtype = _hip.OP_YOLO, op.dtype
+    yo.batch, yo.in_h, yo.in_w, yo.in_c, yo.in_ld = B, h, h, 255, 256
+    yo.out_h, yo.out_w = h, h
+    yo.d_in = logits.data_ptr()
+    yo.n_anchor, yo.n_attr = 3, 85
+    for a, (aw, ah) in enumerate(((116, 90), (156, 198), (373, 326))):
+        yo.anchor_w[a], yo.anchor_h[a] = float(aw), float(ah)
+    yo.row_offset, yo.rows_total = 0, rows
+    yo.net_w = yo.net_h = 608.0
+    yo.d_bbox, yo.d_prob, yo.d_cls = bbox.data_ptr(), prob.data_ptr(), cls.data_ptr()
+    zero = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    opts = _hip.options(fuse_head=mode)
+    handle = ctypes.c_void_p()
+    _hip.check(lib.y3_plan_create_ex((_hip.Y3Op * 2)(op, yo), 2, zero.data_ptr(), ctypes.byref(opts), ctypes.byref(handle)))
+    try:
+        want = kernel % {"bf16": "bf16", "fp16": "f16"}[dtype]
+        assert lib.y3_plan_op_kernel(handle, 0).decode() == want, (lib.y3_plan_op_kernel(handle, 0).decode(), want)
+        _beside_a_copy(handle, bbox, more=(prob, cls))
     finally:
         lib.y3_plan_destroy(handle)

@@ -695,20 +695,27 @@ def test_direct_weights_1x1_kernel_matches_implicit_gemm(B, h, cin, cout, leaky,
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("B,h,w,cin,cout,k,res", [
-    (1, 76, 76, 128, 256, 3, True), (1, 38, 38, 256, 512, 3, True), (1, 19, 19, 512, 1024, 3, True), (2, 19, 19, 512, 1024, 3, False),
-    (3, 13, 13, 512, 1024, 3, False),        # yolov3-tiny's deep layer, three frames: 507 pixels = 10 tiles + 27 pixels
-    (1, 44, 60, 128, 256, 3, True),          # a non-square map (352 x 480 input): rows of 60 pixels, 2640 pixels = 55 tiles
-    (2, 11, 15, 256, 128, 3, True),          # 32-channel workgroups would not fill the chip either: Cout 128
-    (1, 76, 76, 256, 128, 1, False), (1, 38, 38, 512, 256, 1, False), (1, 19, 19, 1024, 512, 1, False), (1, 38, 38, 768, 256, 1, False),
-    (1, 76, 76, 384, 128, 1, False), (5, 19, 19, 1024, 512, 1, False),
+@pytest.mark.parametrize("B,h,w,cin,cout,k,res,stride", [
+    (1, 76, 76, 128, 256, 3, True, 1), (1, 38, 38, 256, 512, 3, True, 1), (1, 19, 19, 512, 1024, 3, True, 1), (2, 19, 19, 512, 1024, 3, False, 1),
+    (3, 13, 13, 512, 1024, 3, False, 1),     # yolov3-tiny's deep layer, three frames: 507 pixels = 10 tiles + 27 pixels
+    (1, 44, 60, 128, 256, 3, True, 1),       # a non-square map (352 x 480 input): rows of 60 pixels, 2640 pixels = 55 tiles
+    (2, 11, 15, 256, 128, 3, True, 1),       # 32-channel workgroups would not fill the chip either: Cout 128
+    (1, 76, 76, 256, 128, 1, False, 1), (1, 38, 38, 512, 256, 1, False, 1), (1, 19, 19, 1024, 512, 1, False, 1), (1, 38, 38, 768, 256, 1, False, 1),
+    (1, 76, 76, 384, 128, 1, False, 1), (5, 19, 19, 1024, 512, 1, False, 1),
     # grids of several rounds of workgroups (Y3_AM_SMALL_DW_ALWAYS: the launcher would not pick the kernel there by itself)
-    (16, 38, 38, 512, 256, 1, False), (16, 19, 19, 512, 1024, 3, True), (16, 76, 76, 384, 128, 1, False)])
-def test_small_grid_direct_weights_kernel_matches_implicit_gemm(B, h, w, cin, cout, k, res, dtype):
+    (16, 38, 38, 512, 256, 1, False, 1), (16, 19, 19, 512, 1024, 3, True, 1), (16, 76, 76, 384, 128, 1, False, 1),
+    # stride 2 (the four downsampling layers with 128+ input channels; the four parity planes of the input in LDS): Darknet-53's three at one
+    # frame -- 512 input channels as TWO images of 256 --, ragged last tiles over several frames, non-square maps (rows of 30 / 22
+    # output pixels), a shortcut operand (not in any cfg, but the op allows it), many rounds of workgroups
+    (1, 152, 152, 128, 256, 3, False, 2), (1, 76, 76, 256, 512, 3, False, 2), (1, 38, 38, 512, 1024, 3, False, 2),
+    (3, 38, 38, 512, 1024, 3, False, 2), (2, 26, 26, 512, 1024, 3, True, 2), (1, 88, 120, 128, 256, 3, False, 2),
+    (3, 44, 60, 256, 512, 3, True, 2), (5, 22, 30, 512, 256, 3, False, 2), (1, 104, 104, 256, 128, 3, False, 2),
+    (16, 76, 76, 256, 512, 3, False, 2), (16, 38, 38, 512, 1024, 3, False, 2)])
+def test_small_grid_direct_weights_kernel_matches_implicit_gemm(B, h, w, cin, cout, k, res, stride, dtype):
     """Round 6: conv_dw48 (csrc/conv_dw48.hip), the kernel of small grids -- one frame at a time, the mode the reference's command
-    line runs -- in every instantiation (3x3 with 2 / 4 / 8 channel chunks, 1x1 with 2 .. 16), with and without a shortcut operand,
-    ragged last tiles, non-square maps, 1 .. 8 waves per workgroup: a one-op plan through the C ABI, bit-equal to the LDS-DMA implicit GEMM
-    on the same operands (same K order: chunk outermost, tap innermost)."""
+    line runs -- in every instantiation (3x3 with 2 / 4 / 8 channel chunks, 1x1 with 2 .. 16, 3x3 stride 2 with 2 / 4 chunks in one or two
+    images), with and without a shortcut operand, ragged last tiles, non-square maps, 1 .. 8 waves per workgroup: a one-op plan through
+    the C ABI, bit-equal to the LDS-DMA implicit GEMM on the same operands (same K order: chunk outermost, tap innermost)."""
     import ctypes
     from yolov3 import _hip
     lib = _hip.lib()
@@ -720,16 +727,17 @@ def test_small_grid_direct_weights_kernel_matches_implicit_gemm(B, h, w, cin, co
     kk = k * k * cin
     wt = ((torch.rand((cout, kk), generator=g) - 0.5) * (6.0 / kk) ** 0.5).to(tdt).to(dev)
     sc, bi = (torch.rand(cout, generator=g) + 0.5).to(dev), (torch.rand(cout, generator=g) - 0.5).to(dev)
-    r = (torch.rand((B, h, w, cout), generator=g) - 0.5).to(tdt).to(dev) if res else None
+    ho, wo = (h + 2 * ((k - 1) // 2) - k) // stride + 1, (w + 2 * ((k - 1) // 2) - k) // stride + 1
+    r = (torch.rand((B, ho, wo, cout), generator=g) - 0.5).to(tdt).to(dev) if res else None
     outs, names = [], []
     for mask in (_hip.AM_SMALL_DW_ALWAYS if B == 16 else _hip.AM_SMALL_DW, 0):
-        out = torch.full((B, h, w, cout), 3.0, dtype=tdt, device=dev)
+        out = torch.full((B, ho, wo, cout), 3.0, dtype=tdt, device=dev)
         op = _hip.Y3Op()
         op.kind, op.dtype = _hip.OP_CONV, {"bf16": _hip.Y3_BF16, "fp16": _hip.Y3_F16}[dtype]
         op.flags = _hip.F_LEAKY | (_hip.F_RESIDUAL if res else 0)
         op.batch, op.in_h, op.in_w, op.in_c, op.in_ld = B, h, w, cin, cin
-        op.out_h, op.out_w, op.out_c, op.out_ld = h, w, cout, cout
-        op.ksize, op.stride, op.pad, op.k_ld, op.cout_pad = k, 1, (k - 1) // 2, kk, (cout + 127) // 128 * 128
+        op.out_h, op.out_w, op.out_c, op.out_ld = ho, wo, cout, cout
+        op.ksize, op.stride, op.pad, op.k_ld, op.cout_pad = k, stride, (k - 1) // 2, kk, (cout + 127) // 128 * 128
         op.d_in, op.d_out = x.data_ptr(), out.data_ptr()
         if res:
             op.d_res, op.res_ld = r.data_ptr(), cout
@@ -748,7 +756,7 @@ def test_small_grid_direct_weights_kernel_matches_implicit_gemm(B, h, w, cin, co
         finally:
             lib.y3_plan_destroy(handle)
         outs.append(out)
-    assert names[0].startswith("conv_dw48_k%d_" % k) and names[1].startswith("conv_igemm"), names
+    assert names[0].startswith("conv_dw48_k%d%s_" % (k, "s2" if stride == 2 else "")) and names[1].startswith("conv_igemm"), names
     assert torch.isfinite(outs[1].float()).all()
     assert torch.equal(outs[0], outs[1]), (names, float((outs[0].float() - outs[1].float()).abs().max()))
 
@@ -1058,7 +1066,7 @@ def test_fused_head_conv_and_decode_matches_separate_kernels(model, dim, batch):
         net = _net(model, dtype="bf16")
         fused = {k: v.clone() for k, v in net.forward_frames(frames).items()}
         names = [r["kernel"] for r in net.plan_report()]
-        assert sum(k == "conv_head_decode_bf16_64x256" for k in names) == (2 if model == "yolov3-tiny" else 3)
+        assert sum(k.startswith("conv_head_decode_") for k in names) == (2 if model == "yolov3-tiny" else 3)
         _hip.check(lib.y3_set_tuning(b"fuse_head", 0))
         net2 = _net(model, dtype="bf16")
         plain = net2.forward_frames(frames)
@@ -1068,6 +1076,35 @@ def test_fused_head_conv_and_decode_matches_separate_kernels(model, dim, batch):
         torch.testing.assert_close(fused["bbox_xywh"], plain["bbox_xywh"], rtol=2e-6, atol=1e-9)
     finally:
         lib.y3_set_tuning(b"fuse_head", 1)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("model,dim,batch", [("yolov3", 608, 1), ("yolov3", 608, 16), ("yolov3", 352, 3), ("yolov3-tiny", 416, 5),
+                                             ("yolov3-spp", 416, 2)])
+def test_direct_weights_head_kernel_equals_tiled_head_kernel(model, dim, batch, dtype):
+    """Round 6: the detection heads on the direct-weights 1x1 kernel (conv_head_decode_dw: whole activation tile in LDS, weight
+    fragments from the fragment-order copy, logits parked in the same LDS, the shared four-lane decode) against the tiled head kernel
+    (y3_options.fuse_head = 2): the same K order and the same epilogue arithmetic -- every output bit-equal; 48- and 96-pixel tiles
+    forced (fuse_head = 3 / 4) as well.  Replaces /root/reference/yolov3/darknet.py:244-257 (head conv) + :86-116 (YOLOLayer)."""
+    frames = synth_frames(23 + dim + batch, batch, dim, dim)
+    outs = {}
+    for mode in (1, 2, 3, 4):
+        net = _net(model, dtype=dtype, options={"fuse_head": mode})
+        outs[mode] = {k: v.clone() for k, v in net.forward_frames(frames).items()}
+        names = [r["kernel"] for r in net.plan_report() if r["kernel"].startswith("conv_head_decode_")]
+        assert len(names) == (2 if model == "yolov3-tiny" else 3), names
+        if mode == 2:
+            assert all("_dw_" not in k for k in names), names
+        else:
+            assert all(k.startswith("conv_head_decode_dw_") for k in names), names
+        if mode == 3:
+            assert all(k.endswith("_48x256") for k in names), names
+        if mode == 4:
+            assert any(k.endswith("_96x256") for k in names), names
+    assert float(outs[2]["class_prob"].max()) > 0
+    for mode in (1, 3, 4):
+        for k in ("bbox_xywh", "class_prob", "class_idx"):
+            assert torch.equal(outs[mode][k], outs[2][k]), (mode, k)
 
 
 def test_split_class_decode_matches_sequential_decode():
@@ -1098,7 +1135,7 @@ activation=leaky
 
 [convolutional]
 batch_normalize=1
-filters=128
+filters=%(mid)d
 size=3
 stride=1
 pad=1
@@ -1119,13 +1156,15 @@ num=4
 """
 
 
-@pytest.mark.parametrize("ncls,mask", [(60, "0,1,2"), (23, "1,2,3,0"), (80, "0,1,2"), (122, "0,1")])
-def test_fused_head_other_class_counts(tmp_path, ncls, mask):
+@pytest.mark.parametrize("ncls,mask,mid", [(60, "0,1,2", 128), (23, "1,2,3,0", 128), (80, "0,1,2", 128), (122, "0,1", 128),
+                                           (60, "0,1,2", 256), (23, "1,2,3,0", 512), (122, "0,1", 256)])
+def test_fused_head_other_class_counts(tmp_path, ncls, mask, mid):
     """Fused head conv + decode for heads that are not COCO's 3 x 85: generic class loop of the four-lane decode, 2-4
-    anchors per head, against the two-kernel path and against the bf16-emulating oracle."""
+    anchors per head, against the two-kernel path and against the bf16-emulating oracle.  128 channels in front of the head: the
+    tiled head kernel; 256 / 512: the direct-weights head kernel (round 6)."""
     n_anchor = len(mask.split(","))
     cfg = tmp_path / "head.cfg"
-    cfg.write_text(_HEAD_CFG % dict(dim=96, filters=n_anchor * (5 + ncls), mask=mask, ncls=ncls))
+    cfg.write_text(_HEAD_CFG % dict(dim=96, filters=n_anchor * (5 + ncls), mask=mask, ncls=ncls, mid=mid))
     from yolov3.cfgparse import parse_config
     blocks, net_info = parse_config(str(cfg))
     params = W.synth_params(blocks, net_info, seed=3, obj_bias=-2.0, calib=None)
@@ -1138,6 +1177,8 @@ def test_fused_head_other_class_counts(tmp_path, ncls, mask):
         names = [r["kernel"] for r in net.plan_report()]
         # (heads of at most 128 channels keep the two kernels: the fused tile is 256 channels wide)
         assert any("head_decode" in k for k in names) == (bool(fuse) and n_anchor * (5 + ncls) > 128), names
+        if fuse and n_anchor * (5 + ncls) > 128:
+            assert any("head_decode_dw_" in k for k in names) == (mid >= 256), names
     fused, plain = outs[1], outs[0]
     assert torch.equal(fused["class_idx"], plain["class_idx"])
     torch.testing.assert_close(fused["class_prob"], plain["class_prob"], rtol=2e-6, atol=1e-9)

@@ -54,6 +54,9 @@ def plan_name(kernel):
     m = re.search(r"conv_patch_wsp_kernelI" + _T, k)
     if m:
         return "conv_patch_wsp_%s_8x32x128" % DT[m.group(1)]
+    m = re.search(r"conv1x1_dw_kernelI" + _T + r"Li(\d+)ELi\d+ELb1E", k) or re.match(r"conv1x1_dw_kernel<(__bf16|_Float16), (\d+), \d+, true", k)
+    if m:                                      # HEAD = true: the detection-head form
+        return "conv_head_decode_dw_%s_%sx256" % (DT[m.group(1)], m.group(2))
     m = re.search(r"conv1x1_dw_kernelI" + _T + r"Li(\d+)E", k) or re.match(r"conv1x1_dw_kernel<(__bf16|_Float16), (\d+)", k)
     if m:
         return "conv1x1_dw_%s_%sx256" % (DT[m.group(1)], m.group(2))
