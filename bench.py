@@ -1108,9 +1108,10 @@ def latency_report(dev, model, dim, params, n_calls=200, n_video=300):
                                                          "ms_per_frame": round(dt / max(len(res), 1) * 1e3, 3)}
         loops["y4m_decode_alone_ms_per_frame"] = round(decode_ms, 3)
     out["loops_bf16"] = loops
-    out["note"] = ("batch 1 is launch- and round-trip-bound, not kernel-bound (75 launches + one synchronising copy per call); "
-                   "use_graph=1 replays the forward as one hipGraph launch; detect_in_video's rate is the numpy YUV decoder's "
-                   "and draw_boxes' (host), compare y4m_decode_alone_ms_per_frame")
+    out["note"] = ("one frame per call: the 16-bit modes' time is the frame's 75 kernels (0.59 ms of kernel time + ~2 us of dispatch gap "
+                   "behind each, profiles/r06_per_op_dispatch_times_batch1*.txt) plus one synchronising copy; *_graph = use_graph=1, the "
+                   "forward replayed as one hipGraph launch (no faster: the gaps are the GPU's, not the host's); detect_in_video's rate "
+                   "is the numpy YUV decoder's and draw_boxes' (host), compare y4m_decode_alone_ms_per_frame")
     return out
 
 
