@@ -151,8 +151,11 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
             if (want_ws) return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
             // 3x3 stride-2 layer with 256 input channels (76^2 -> 38^2): 865 against 762 TFLOP/s on the wave-specialised
             // implicit GEMM at batch 16; the other stride-2 layers measured faster on the LDS-DMA version
-            if (!(am & Y3_AM_NO_SMALL_GRID) && op.ksize == 3 && op.stride == 2 && op.in_c == 256 && op.out_c >= 128 && y3_is16(op.dtype) &&
-                !(op.flags & Y3_F_OUT_F32) && (long long)op.batch * op.out_h * op.out_w >= 16384)
+            // (64 input channels -- 304^2 -> 152^2 -- at one or two frames: 9.6 against 12.3 us at one frame, level at four, 109 against
+            // 97 at sixteen: profiles/r06_conv_dw48.txt)
+            if (!(am & Y3_AM_NO_SMALL_GRID) && op.ksize == 3 && op.stride == 2 && op.out_c >= 128 && y3_is16(op.dtype) && !(op.flags & Y3_F_OUT_F32) &&
+                ((op.in_c == 256 && (long long)op.batch * op.out_h * op.out_w >= 16384) ||
+                 (op.in_c == 64 && (long long)op.batch * op.out_h * op.out_w <= 49152)))
               return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3);
           }
           return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run);

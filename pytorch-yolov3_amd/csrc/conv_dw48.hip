@@ -76,7 +76,8 @@ __device__ __forceinline__ void dw48_wait_vm(u32x4 (&w)[2]) {
 // end of an image and is primed again behind the next image's pieces (the two latencies overlap).
 template <typename T, int KS, int NKT, int ST = 1, int NH = 1>
 __global__ __launch_bounds__(512) void conv_dw48_kernel(Dw48Args p) {
-  static_assert(sizeof(T) == 2 && (KS == 1 || KS == 3) && NKT % 2 == 0, "16-bit modes; 1x1 or 3x3; Cin a multiple of 128");
+  static_assert(sizeof(T) == 2 && (KS == 1 || KS == 3) && (NKT % 2 == 0 || NKT == 1), "16-bit modes; 1x1 or 3x3; Cin 64 or a multiple of 128");
+  constexpr int SWZ = NKT == 1 ? 7 : 15;               // a row of 64 channels has eight 16-byte chunks, not sixteen
   static_assert((ST == 1 && NH == 1) || (ST == 2 && KS == 3), "stride 2 and channel halves: the 3x3 form only");
   constexpr int BM = 48, MI = 3, NI = 2;
   constexpr int TAPS = KS * KS;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(512) void conv_dw48_kernel(Dw48Args p) {
     for (int i = wave; i < pieces; i += nwaves) {
       const int o = i * 1024 + lane * 16;
       const int r = o / RB, cpos = (o - r * RB) >> 4;
-      const int c = cpos ^ (r & 15);
+      const int c = cpos ^ (r & SWZ);
       long long q;
       bool ok;
       if constexpr (ST == 1) {
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(512) void conv_dw48_kernel(Dw48Args p) {
         const int ky = tap / 3, kx = tap % 3;
         r0 = fr + (ky == 1 ? (kx == 1 ? 0 : 48) : (kx == 1 ? 97 : 145 + p.W)) + (kx == 2 ? 1 : 0) + (ky == 2 ? p.W : 0);
       }
-      fk4[tap] = (fq ^ (r0 & 15)) << 4;                // chunk c of the row sits at position c ^ (row & 15); c = 8 kt + 4 kh + fq
+      fk4[tap] = (fq ^ (r0 & SWZ)) << 4;                // chunk c of the row sits at position c ^ (row & 15); c = 8 kt + 4 kh + fq
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
         abase[tap][mi] = ((tapmask[mi] >> tap) & 1u) ? lds0 + (mi * 16 + r0) * RB : zrow;
@@ -316,7 +317,7 @@ Dw48Shape dw48_shape(const y3_op &op) {
   if (op.flags & (Y3_F_OUT_F32 | Y3_F_IN_NCHW_F32 | Y3_F_IN_NHWC_U8BGR | Y3_F_PLAN_INPUT)) return z;
   if (op.out_c % 32 != 0 || op.cout_pad % 32 != 0 || op.in_ld % 8 != 0 || op.out_ld % 8 != 0 || op.k_ld % 32 != 0) return z;
   if ((op.flags & Y3_F_RESIDUAL) && op.res_ld % 8 != 0) return z;
-  if (op.in_c % 128 != 0 || op.k_ld < op.ksize * op.ksize * op.in_c) return z;
+  if ((op.in_c % 128 != 0 && !(k3s2 && op.in_c == 64)) || op.k_ld < op.ksize * op.ksize * op.in_c) return z;
   Dw48Shape sh;
   sh.rows = k1 ? 48 : (k3 ? 48 + 2 * op.in_w + 2 : 194 + 2 * op.out_w);
   sh.cin_img = op.in_c;
@@ -326,7 +327,7 @@ Dw48Shape dw48_shape(const y3_op &op) {
   if ((long long)(sh.rows + 1) * sh.cin_img * 2 + 1024 > 160 * 1024) return z;
   const int nkt = sh.cin_img / 64;
   const bool inst = k1 ? (nkt == 2 || nkt == 4 || nkt == 6 || nkt == 8 || nkt == 12 || nkt == 16)
-                       : (k3 ? (nkt == 2 || nkt == 4 || nkt == 8) : (nkt == 2 || nkt == 4));
+                       : (k3 ? (nkt == 2 || nkt == 4 || nkt == 8) : (nkt == 1 || nkt == 2 || nkt == 4));
   if (!inst) return z;
   if ((long long)op.batch * op.out_h * op.out_w >= (1ll << 31)) return z;
   return sh;
@@ -409,7 +410,7 @@ int y3_launch_conv_dw48(const y3_op &op, const void *d_in, const void *d_zero, h
         Y3_DW48_ATTR(1, 2); Y3_DW48_ATTR(1, 4); Y3_DW48_ATTR(1, 6); Y3_DW48_ATTR(1, 8); Y3_DW48_ATTR(1, 12); Y3_DW48_ATTR(1, 16);
 #undef Y3_DW48_ATTR
 #define Y3_DW48_ATTR2(NKT_, NH_) Y3_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_dw48_kernel<T, 3, NKT_, 2, NH_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-        Y3_DW48_ATTR2(2, 1); Y3_DW48_ATTR2(4, 1); Y3_DW48_ATTR2(2, 2); Y3_DW48_ATTR2(4, 2);
+        Y3_DW48_ATTR2(1, 1); Y3_DW48_ATTR2(2, 1); Y3_DW48_ATTR2(4, 1); Y3_DW48_ATTR2(2, 2); Y3_DW48_ATTR2(4, 2);
 #undef Y3_DW48_ATTR2
         return Y3_OK;
       });
@@ -418,7 +419,7 @@ int y3_launch_conv_dw48(const y3_op &op, const void *d_in, const void *d_zero, h
 #define Y3_DW48_GO(KS_, NKT_) Y3_LAUNCH((conv_dw48_kernel<T, KS_, NKT_>), grid, block, lds, s, a)
     if (ks == 3 && st == 2) {
 #define Y3_DW48_GO2(NKT_, NH_) Y3_LAUNCH((conv_dw48_kernel<T, 3, NKT_, 2, NH_>), grid, block, lds, s, a)
-      if (nkt == 2 && nh == 1) Y3_DW48_GO2(2, 1); else if (nkt == 4 && nh == 1) Y3_DW48_GO2(4, 1);
+      if (nkt == 1) Y3_DW48_GO2(1, 1); else if (nkt == 2 && nh == 1) Y3_DW48_GO2(2, 1); else if (nkt == 4 && nh == 1) Y3_DW48_GO2(4, 1);
       else if (nkt == 2) Y3_DW48_GO2(2, 2); else Y3_DW48_GO2(4, 2);
 #undef Y3_DW48_GO2
     } else if (ks == 3) {

@@ -118,6 +118,9 @@ def _cases():
         ("dw48_k3_76", "conv_dw48_k3_%s", dict(auto_mask=H.AM_SMALL_DW), 1, 76, 128, 256, 3, 1, True),
         ("dw48_k3_19", "conv_dw48_k3_%s", dict(auto_mask=H.AM_SMALL_DW), 2, 19, 512, 1024, 3, 1, True),
         ("dw48_k1_38", "conv_dw48_k1_%s", dict(auto_mask=H.AM_SMALL_DW), 1, 38, 512, 256, 1, 1, False),
+        # ... its stride-2 form (four parity planes; 512 channels as two LDS images, re-staged by helper and computing waves in the K loop)
+        ("dw48_k3s2_76", "conv_dw48_k3s2_%s", dict(auto_mask=H.AM_SMALL_DW), 1, 76, 256, 512, 3, 2, False),
+        ("dw48_k3s2_38", "conv_dw48_k3s2_%s", dict(auto_mask=H.AM_SMALL_DW), 2, 38, 512, 1024, 3, 2, False),
         # persistent 2-D patch kernel (rows wider than 128 px)
         ("patch_152", "conv_patch_wsp_%s_8x32x128", dict(auto_mask=halo | H.AM_PATCH_WIDE), 16, 152, 64, 128, 3, 1, True),
     ]

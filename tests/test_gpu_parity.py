@@ -710,7 +710,8 @@ def test_direct_weights_1x1_kernel_matches_implicit_gemm(B, h, cin, cout, leaky,
     (1, 152, 152, 128, 256, 3, False, 2), (1, 76, 76, 256, 512, 3, False, 2), (1, 38, 38, 512, 1024, 3, False, 2),
     (3, 38, 38, 512, 1024, 3, False, 2), (2, 26, 26, 512, 1024, 3, True, 2), (1, 88, 120, 128, 256, 3, False, 2),
     (3, 44, 60, 256, 512, 3, True, 2), (5, 22, 30, 512, 256, 3, False, 2), (1, 104, 104, 256, 128, 3, False, 2),
-    (16, 76, 76, 256, 512, 3, False, 2), (16, 38, 38, 512, 1024, 3, False, 2)])
+    (16, 76, 76, 256, 512, 3, False, 2), (16, 38, 38, 512, 1024, 3, False, 2),
+    (16, 88, 120, 64, 128, 3, False, 2)])   # 64 input channels (rows of eight 16-byte chunks)
 def test_small_grid_direct_weights_kernel_matches_implicit_gemm(B, h, w, cin, cout, k, res, stride, dtype):
     """Round 6: conv_dw48 (csrc/conv_dw48.hip), the kernel of small grids -- one frame at a time, the mode the reference's command
     line runs -- in every instantiation (3x3 with 2 / 4 / 8 channel chunks, 1x1 with 2 .. 16, 3x3 stride 2 with 2 / 4 chunks in one or two
