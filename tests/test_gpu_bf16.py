@@ -101,7 +101,9 @@ def _close_bf16(got, want, what, slack=None, mode="bf16"):
     return frac
 
 
-def _teacher_forced(model, frames, expect_kernels=(), options=None, mode="bf16"):
+def _teacher_forced(model, frames, expect_kernels=(), options=None, mode="bf16", frames_checked=None):
+    """``frames_checked``: the frames of the batch whose blocks are compared with the oracle (the product runs the WHOLE batch, so the plan
+    and every kernel's grid are the batch's; the CPU oracle, 95 % of this test's time at batch 16, emulates only these).  None = all."""
     rnd, emulate = MODES[mode]["rnd"], MODES[mode]["emulate"]
     expect_kernels = tuple(k.replace("bf16", MODES[mode]["tag"]) for k in expect_kernels)
     net = _net(model, mode, keep_all=True, fuse=True, options=options)
@@ -118,10 +120,11 @@ def _teacher_forced(model, frames, expect_kernels=(), options=None, mode="bf16")
     ref = orc.OracleDarknet(MODELS[model]).set_params(net._params)
     blocks = ref.blocks
     rounds = ref.bf16_rounding_points()
-    x_net = rnd(torch.from_numpy(orc.frames_to_input(list(frames))))
+    sel = list(range(len(frames))) if frames_checked is None else sorted(set(frames_checked))
+    x_net = rnd(torch.from_numpy(orc.frames_to_input([frames[j] for j in sel])))
 
     def hip(i):
-        return x_net if i < 0 else net.block_output(i).cpu()
+        return x_net if i < 0 else net.block_output(i)[sel].cpu()
 
     def conv(i, x):
         blk = blocks[i]
@@ -181,9 +184,9 @@ def _teacher_forced(model, frames, expect_kernels=(), options=None, mode="bf16")
             checked += 1
     # detection heads: decode of the oracle's float32 logits (from the product's head-conv input) against the
     # rows this head wrote into the final outputs
-    bb = out["bbox_xywh"].cpu()
-    pr = out["class_prob"].cpu()
-    ci = out["class_idx"].cpu()
+    bb = out["bbox_xywh"][sel].cpu()
+    pr = out["class_prob"][sel].cpu()
+    ci = out["class_idx"][sel].cpu()
     row = 0
     for yi, logits in heads:
         blk = blocks[yi]
@@ -261,7 +264,10 @@ def _every_block(model, h, w, batch, options, kernels, mode):
     frames = synth_frames(1000 + h + w + batch, batch, h, w)
     if (h, w) == (608, 608):
         frames[0] = resize_bilinear_u8(load_jpeg_bgr("000000035279.jpg"), h, w)
-    checked, frac, names = _teacher_forced(model, frames, kernels, options=options, mode=mode)
+    # batches of 8 / 16: the first, a middle and the last frame against the oracle (tiles of the raster strips straddle frames; that every
+    # frame of a full-size batch equals the same frame alone is test_frames_are_independent_at_full_size's job)
+    some = (0, batch // 2, batch - 1) if batch >= 8 else None
+    checked, frac, names = _teacher_forced(model, frames, kernels, options=options, mode=mode, frames_checked=some)
     print("%s %s %dx%d b%d %s: %d blocks checked, worst mismatch share %.4f" % (mode, model, h, w, batch, options, checked, frac))
     assert checked >= (20 if model == "yolov3-tiny" else 75)      # 107 blocks, 23 convs checked with their shortcut, 3 yolo
 
