@@ -135,8 +135,11 @@ typedef struct y3_plan y3_plan;
 #define Y3_AM_SMALL_DW 0x20000u       /* small-grid direct-weights kernel (48-pixel x 32..256-channel tiles, whole halo in LDS) for 1x1 and   */
                                      /* 3x3 layers whose map x batch fits the chip in ONE round of such tiles: one frame at a time (round 6)  */
 #define Y3_AM_SMALL_DW_ALWAYS 0x40000u /* tests / A-B: that kernel wherever its shape constraints hold, whatever the grid                       */
+#define Y3_AM_SMALL_DW_WIDE 0x80000u  /* ... and for grids a little over one round where it measured faster than what the layer ran on: 3x3 layers  */
+                                     /* up to 1.5 rounds of its widest tiles; 1x1 layers with ONE channel tile per pixel tile (128+ channels) up   */
+                                     /* to 8 rounds, after the weights-resident kernel has had its say (batches of 3-8; two layers at batch 16)   */
 #define Y3_AM_WRES_ALWAYS 0x2000u    /* tests: that kernel on every layer it supports, whatever the map size                       */
-#define Y3_AM_DEFAULT (Y3_AM_HALO_WIDE | Y3_AM_HALO_NARROW | Y3_AM_IGEMM3_1X1_DEEP | Y3_AM_HALO_MID | Y3_AM_PATCH_WIDE | Y3_AM_HALO_DW | Y3_AM_1X1_DW | Y3_AM_SMALL_DW)   /* 0x3409d */
+#define Y3_AM_DEFAULT (Y3_AM_HALO_WIDE | Y3_AM_HALO_NARROW | Y3_AM_IGEMM3_1X1_DEEP | Y3_AM_HALO_MID | Y3_AM_PATCH_WIDE | Y3_AM_HALO_DW | Y3_AM_1X1_DW | Y3_AM_SMALL_DW | Y3_AM_SMALL_DW_WIDE)   /* 0xb409d */
 #define Y3_AM_IGEMM_ONLY 0u          /* LDS-DMA implicit GEMM (igemm_version) everywhere                                           */
 
 /*

@@ -125,10 +125,14 @@ int dispatch(const y3_op &op, const void *d_input, const void *d_zero, hipStream
             if ((am & Y3_AM_1X1_DW) && y3_conv1x1_dw_pays(op))
               return y3_launch_conv1x1_dw(op, in, d_zero, s, name, dry_run, frag_w ? frag_w : op.d_weight_frag);
             // small grids (one frame at a time, small batches): 48-pixel tiles that fill the chip in one round (conv_dw48.hip)
-            if ((am & (Y3_AM_SMALL_DW | Y3_AM_SMALL_DW_ALWAYS)) && !(am & Y3_AM_NO_SMALL_GRID) && y3_conv_dw48_fits(op))
+            const bool small_dw = (am & (Y3_AM_SMALL_DW | Y3_AM_SMALL_DW_ALWAYS)) && !(am & Y3_AM_NO_SMALL_GRID);
+            if (small_dw && (y3_conv_dw48_fits(op) || (op.ksize == 3 && y3_conv_dw48_fits_wide(op))))
               return y3_launch_conv_dw48(op, in, d_zero, s, name, dry_run, frag_w ? frag_w : op.d_weight_frag);
             if (!(am & Y3_AM_NO_WRES) && y3_conv1x1_wres_supported(op) && ((am & Y3_AM_WRES_ALWAYS) || y3_conv1x1_wres_pays(op)))
               return y3_launch_conv1x1_wres(op, in, d_zero, s, name, dry_run);
+            // 1x1 layers on grids of a few rounds, where the weights-resident kernel does not pay
+            if (small_dw && op.ksize == 1 && y3_conv_dw48_fits_wide(op))
+              return y3_launch_conv_dw48(op, in, d_zero, s, name, dry_run, frag_w ? frag_w : op.d_weight_frag);
             if ((am & Y3_AM_IGEMM3_1X1_BM64) && op.ksize == 1 && op.in_c >= 256 && op.out_c >= 128 && !(op.flags & Y3_F_OUT_F32) &&
                 y3_is16(op.dtype))
               return y3_launch_conv_igemm(op, in, d_zero, s, name, dry_run, 3, 3, 64);
@@ -271,7 +275,7 @@ size_t y3_conv_fragment_weight_bytes(const y3_op *op, const y3_options *options)
 
 int y3_conv_make_fragment_weights(const y3_op *op, void *d_dst, void *stream) {
   Y3_REQUIRE(op && d_dst && op->d_weight, "y3_conv_make_fragment_weights: bad arguments");
-  Y3_REQUIRE(y3_conv_halo_dw_fits(*op) || y3_conv1x1_dw_pays(*op) || y3_conv_dw48_fits(*op) || y3_conv_head_dw_fits(*op),
+  Y3_REQUIRE(y3_conv_halo_dw_fits(*op) || y3_conv1x1_dw_pays(*op) || y3_conv_dw48_fits(*op) || y3_conv_dw48_fits_wide(*op) || y3_conv_head_dw_fits(*op),
              "conv block %d: not a layer of a direct-weights kernel", op->block_idx);
   return y3_conv_halo_dw_make_weights(*op, d_dst, static_cast<hipStream_t>(stream));
 }

@@ -399,6 +399,7 @@ int y3_launch_conv1x1_dw(const y3_op &op, const void *d_in, const void *d_zero, 
                          bool dry_run, const void *frag_w);
 // small-grid direct-weights kernel, 1x1 and 3x3 (conv_dw48.hip; fragment-order weights): 48-pixel x 32..256-channel tiles
 bool y3_conv_dw48_fits(const y3_op &op);
+bool y3_conv_dw48_fits_wide(const y3_op &op);
 int y3_launch_conv_dw48(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s, const char **kernel_name,
                         bool dry_run, const void *frag_w);
 // 2-D patch form of the halo kernel for rows wider than 128 pixels (conv_halo.hip)

@@ -333,38 +333,58 @@ Dw48Shape dw48_shape(const y3_op &op) {
   return sh;
 }
 
-// waves per workgroup (1 / 2 / 4 / 8 = 32 .. 256 channels) for this op, or 0 when the kernel does not take it.  `any_grid` (tests / A-B:
-// Y3_AM_SMALL_DW_ALWAYS): the shape constraints only -- the widest workgroup the channel count allows, however many rounds that makes
-int dw48_waves(const y3_op &op, bool any_grid = false) {
+// waves per workgroup (1 / 2 / 4 / 8 = 32 .. 256 channels) for this op, or 0 when the kernel does not take it.
+// grid: 0 = ONE round of workgroups (the rule the kernel was built for), 1 = a little over one round (Y3_AM_SMALL_DW_WIDE), 2 = any
+// (tests / A-B: Y3_AM_SMALL_DW_ALWAYS -- the shape constraints only, the widest workgroup the channel count allows)
+int dw48_waves(const y3_op &op, int grid) {
   const Dw48Shape sh = dw48_shape(op);
   if (sh.rows == 0) return 0;
   const long long M = (long long)op.batch * op.out_h * op.out_w;
   const long long mt = (M + 47) / 48;
   const int n_cu = y3_device_cus();
-  // ONE round of workgroups: the fewest waves per workgroup (most workgroups) that still fit the chip; a layer that does not fit
-  // with eight waves is not a small grid
-  if (any_grid) {
-    for (int nw = 8; nw >= 1; nw >>= 1)
-      if (op.out_c % (32 * nw) == 0) return nw;
+  int widest = 0;
+  for (int nw = 8; nw >= 1 && !widest; nw >>= 1)
+    if (op.out_c % (32 * nw) == 0) widest = nw;
+  if (grid == 2 || widest == 0) return widest;
+  if (grid == 0) {
+    // ONE round of workgroups: the fewest waves per workgroup (most workgroups) that still fit the chip
+    for (int nw = 1; nw <= 8; nw <<= 1) {
+      if (op.out_c % (32 * nw) != 0) continue;
+      // (not one computing wave per workgroup for a big image: with 256 workgroups each staging 64+ KiB the L2 traffic doubles for
+      // nothing -- with or without the rule the layers it touches measure the same, profiles/r06_conv_dw48.txt)
+      if (nw == 1 && (long long)(sh.rows + 1) * op.in_c * 2 > 64 * 1024) continue;
+      if (mt * (op.out_c / (32 * nw)) <= n_cu) return nw;
+    }
     return 0;
   }
-  for (int nw = 1; nw <= 8; nw <<= 1) {
-    if (op.out_c % (32 * nw) != 0) continue;
-    // (not one computing wave per workgroup for a big image: with 256 workgroups each staging 64+ KiB the L2 traffic doubles for
-    // nothing -- with or without the rule the layers it touches measure the same, profiles/r06_conv_dw48.txt)
-    if (nw == 1 && (long long)(sh.rows + 1) * op.in_c * 2 > 64 * 1024) continue;
-    if (mt * (op.out_c / (32 * nw)) <= n_cu) return nw;
-  }
-  return 0;
+  // A little over one round, widest workgroups (profiles/r06_conv_dw48.txt, "grids over one round": us per launch against what the layer
+  // ran on).  3x3 (stride 1 and 2): up to 1.5 rounds -- 128 -> 256 @76^2 x 3 frames 19.1 against 26.0, 256 -> 512 @38^2 x 6 frames 30.0
+  // against 39.3; at 1.9 rounds the strip kernel's 192-pixel tiles win (76^2 x 4 frames 17.3 against 21.0).  1x1 with ONE channel tile
+  // per pixel tile (every pixel is staged once) and 128+ output channels: up to 8 rounds -- 256 -> 128 @76^2 x 3 / 4 / 8 frames 5.2 /
+  // 5.6 / 9.1 against 6.5-7.8 / 6.8-8.1 / 10.7-11.1, 384 -> 128 @76^2 x 16 frames 22.7 against 24.0; the weights-resident kernel, where
+  // it pays, is asked first (256 -> 128 @76^2 x 16 frames: 14.5 against 17.1).
+  const long long tiles = mt * (op.out_c / (32 * widest));
+  if (op.ksize == 3) return 2 * tiles <= 3 * (long long)n_cu ? widest : 0;
+  return op.out_c >= 128 && op.out_c == 32 * widest && tiles <= 8ll * n_cu ? widest : 0;
+}
+
+int dw48_waves_for(const y3_op &op) {
+  const unsigned am = (unsigned)y3_opt().auto_mask;
+  if (am & Y3_AM_SMALL_DW_ALWAYS) return dw48_waves(op, 2);
+  const int nw = dw48_waves(op, 0);
+  return nw || !(am & Y3_AM_SMALL_DW_WIDE) ? nw : dw48_waves(op, 1);
 }
 
 }  // namespace
 
-bool y3_conv_dw48_fits(const y3_op &op) { return dw48_waves(op, ((unsigned)y3_opt().auto_mask & Y3_AM_SMALL_DW_ALWAYS) != 0) != 0; }
+// one round of workgroups (or any grid under Y3_AM_SMALL_DW_ALWAYS)
+bool y3_conv_dw48_fits(const y3_op &op) { return dw48_waves(op, ((unsigned)y3_opt().auto_mask & Y3_AM_SMALL_DW_ALWAYS) ? 2 : 0) != 0; }
+// ... or a grid a little over one round (Y3_AM_SMALL_DW_WIDE): asked after the kernels that win on such grids where they apply
+bool y3_conv_dw48_fits_wide(const y3_op &op) { return ((unsigned)y3_opt().auto_mask & Y3_AM_SMALL_DW_WIDE) && dw48_waves(op, 1) != 0; }
 
 int y3_launch_conv_dw48(const y3_op &op, const void *d_in, const void *d_zero, hipStream_t s, const char **kernel_name,
                         bool dry_run, const void *frag_w) {
-  const int nw = dw48_waves(op, ((unsigned)y3_opt().auto_mask & Y3_AM_SMALL_DW_ALWAYS) != 0);
+  const int nw = dw48_waves_for(op);
   Y3_REQUIRE(nw != 0, "conv block %d: not a shape for the small-grid direct-weights kernel", op.block_idx);
   *kernel_name = op.ksize == 3 ? (op.stride == 2 ? Y3_KNAME(op.dtype, "conv_dw48_k3s2_", "") : Y3_KNAME(op.dtype, "conv_dw48_k3_", ""))
                                : Y3_KNAME(op.dtype, "conv_dw48_k1_", "");

@@ -83,7 +83,9 @@ AM_HALO_DW, AM_HALO_DW_ALWAYS = 0x4000, 0x8000                       # direct-we
 AM_1X1_DW = 0x10000                                                  # direct-weights 1x1 kernel (short-K bottleneck layers, one tile per CU)
 AM_SMALL_DW_ALWAYS = 0x40000                                         # tests / A-B: the small-grid kernel wherever its shape constraints hold
 AM_SMALL_DW = 0x20000                                                # small-grid direct-weights kernel (48-pixel tiles, 1x1 and 3x3: one frame at a time)
-AM_DEFAULT = AM_HALO_WIDE | AM_HALO_NARROW | AM_IGEMM3_1X1_DEEP | AM_HALO_MID | AM_PATCH_WIDE | AM_HALO_DW | AM_1X1_DW | AM_SMALL_DW
+AM_SMALL_DW_WIDE = 0x80000                                           # ... on grids a little over one round as well (3x3: 1.5 rounds; 1x1 with one channel tile: 8)
+AM_DEFAULT = (AM_HALO_WIDE | AM_HALO_NARROW | AM_IGEMM3_1X1_DEEP | AM_HALO_MID | AM_PATCH_WIDE | AM_HALO_DW | AM_1X1_DW | AM_SMALL_DW |
+              AM_SMALL_DW_WIDE)
 AM_IGEMM_ONLY = 0
 AM_HALO_ALL = AM_HALO_WIDE | AM_HALO_NARROW | AM_HALO_MID          # conv_bench: the halo kernel wherever it fits
 

@@ -113,7 +113,7 @@ def test_mini_fp16_close_to_fp32_and_its_two_stems_agree():
     assert (a["class_idx"] == b["class_idx"]).float().mean() > 0.99
 
 
-DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 0x3409d, "fuse_stem": 1, "decode_lanes": 4, "use_graph": 0, "fuse_head": 1, "fuse_spp": 1}
+DEFAULT_KNOBS = {"igemm_version": 2, "igemm_bm": 0, "igemm_ns": 2, "auto_mask": 0xb409d, "fuse_stem": 1, "decode_lanes": 4, "use_graph": 0, "fuse_head": 1, "fuse_spp": 1}
 
 
 def test_tuning_knobs_do_not_change_results():
@@ -781,9 +781,68 @@ def test_small_grid_kernel_is_chosen_for_one_frame_and_changes_no_bit(model, dim
         for k in ("bbox_xywh", "class_prob", "class_idx"):
             assert torch.equal(oa[k], ob[k]), (batch, k)
     if model != "yolov3-tiny":
+        # batch 16: no 3x3 layer runs on it, and only the two 1x1 layers that Y3_AM_SMALL_DW_WIDE routes there (256 -> 128 @38^2,
+        # 384 -> 128 @76^2: a few rounds of single-channel-tile workgroups, faster than the tiled implicit GEMM they ran on)
         c = _net(model, dtype=dtype)
         c.forward_frames(synth_frames(71, 16, dim, dim))
-        assert not any(r["kernel"].startswith("conv_dw48_") for r in c.plan_report())
+        on = [r["kernel"] for r in c.plan_report() if r["kernel"].startswith("conv_dw48_")]
+        assert all(k.startswith("conv_dw48_k1_") for k in on) and len(on) <= 2, on
+
+
+@pytest.mark.parametrize("B,h,cin,cout,k,stride,want", [
+    (3, 76, 128, 256, 3, 1, "conv_dw48_k3_"),      # 361 tiles = 1.4 rounds: taken (19.1 against 26.0 us on the wave-specialised implicit GEMM)
+    (4, 76, 128, 256, 3, 1, "conv_igemm"),         # 482 tiles = 1.9 rounds: left to the others (the strip kernel in a network's plan)
+    (6, 38, 256, 512, 3, 1, "conv_dw48_k3_"),      # 362 tiles
+    (16, 38, 256, 128, 1, 1, "conv_dw48_k1_"),     # 1x1, one channel tile, 482 tiles
+    (16, 76, 384, 128, 1, 1, "conv_dw48_k1_"),     # ... 1926 tiles = 7.5 rounds
+    (16, 76, 256, 128, 1, 1, "conv1x1_wres_"),     # the weights-resident kernel pays here: asked first
+    (16, 152, 128, 64, 1, 1, "conv1x1_wres_"),     # 64 output channels: never the small-grid kernel on a big grid
+    (3, 152, 128, 256, 3, 2, "conv_dw48_k3s2_")])  # stride 2, 361 tiles
+def test_small_grid_kernel_on_grids_over_one_round(B, h, cin, cout, k, stride, want):
+    """Y3_AM_SMALL_DW_WIDE: conv_dw48 beyond ONE round of workgroups where it measured faster than what the layer ran on (3x3: up to 1.5
+    rounds; 1x1 with one channel tile per pixel tile: up to 8, after the weights-resident kernel) -- which kernel a one-op plan gets
+    under the default mask, and the same bits as the implicit GEMM."""
+    import ctypes
+    from yolov3 import _hip
+    lib = _hip.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 100 + h + cin)
+    pad = (k - 1) // 2
+    ho = (h + 2 * pad - k) // stride + 1
+    kk = k * k * cin
+    cp = (cout + 127) // 128 * 128
+    x = (torch.rand((B, h, h, cin), generator=g) - 0.5).to(torch.bfloat16).to(dev)
+    wt = torch.zeros((cp, kk), dtype=torch.bfloat16, device=dev)
+    wt[:cout] = ((torch.rand((cout, kk), generator=g) - 0.5) * (6.0 / kk) ** 0.5).to(torch.bfloat16).to(dev)
+    sc, bi = torch.zeros(cp, device=dev), torch.zeros(cp, device=dev)
+    sc[:cout], bi[:cout] = (torch.rand(cout, generator=g) + 0.5).to(dev), (torch.rand(cout, generator=g) - 0.5).to(dev)
+    zero = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    outs, names = [], []
+    for mask in (_hip.AM_DEFAULT, 0):
+        out = torch.full((B, ho, ho, cout), 3.0, dtype=torch.bfloat16, device=dev)
+        op = _hip.Y3Op()
+        op.kind, op.dtype, op.flags = _hip.OP_CONV, _hip.Y3_BF16, _hip.F_LEAKY
+        op.batch, op.in_h, op.in_w, op.in_c, op.in_ld = B, h, h, cin, cin
+        op.out_h, op.out_w, op.out_c, op.out_ld = ho, ho, cout, cout
+        op.ksize, op.stride, op.pad, op.k_ld, op.cout_pad = k, stride, pad, kk, cp
+        op.d_in, op.d_out = x.data_ptr(), out.data_ptr()
+        op.d_weight, op.d_scale, op.d_bias = wt.data_ptr(), sc.data_ptr(), bi.data_ptr()
+        opts = _hip.options(auto_mask=mask)
+        handle = ctypes.c_void_p()
+        _hip.check(lib.y3_plan_create_ex((_hip.Y3Op * 1)(op), 1, zero.data_ptr(), ctypes.byref(opts), ctypes.byref(handle)))
+        try:
+            names.append(lib.y3_plan_op_kernel(handle, 0).decode())
+            _hip.check(lib.y3_plan_run(handle, None, _hip.stream_ptr()))
+            torch.cuda.synchronize()
+        finally:
+            lib.y3_plan_destroy(handle)
+        outs.append(out)
+    if want == "conv_igemm":                               # (under the default mask a strip kernel or an implicit GEMM: not conv_dw48)
+        assert not names[0].startswith("conv_dw48_"), names
+    else:
+        assert names[0].startswith(want), names
+    assert names[1].startswith("conv_igemm") and torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[0], outs[1]), (names, float((outs[0].float() - outs[1].float()).abs().max()))
 
 
 @pytest.mark.parametrize("h,cin,cout", [(38, 256, 512), (19, 512, 1024), (62, 128, 256), (76, 128, 256), (94, 256, 256)])

@@ -9,8 +9,8 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # serial steps (one stream) with the plan options of the default three-stream bench run (Y3_AM_DEFAULT | Y3_AM_HALO_TILE256 =
-# 0x3429d = 213661), so that every kernel runs the layers it runs in the headline measurement
-TUNE="--streams 1 --tuning auto_mask=213661"
+# 0xb429d = 737949), so that every kernel runs the layers it runs in the headline measurement
+TUNE="--streams 1 --tuning auto_mask=737949"
 ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-extras $TUNE $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
